@@ -1,0 +1,109 @@
+"""ctypes binding of ``libogpsx.so`` (C ABI: ``include/ogpsx.h``).
+
+The library is the product: nothing here falls back to NumPy when it is missing.  It is built
+in-tree by ``__graft_entry__.build()`` / :func:`opengoddard_amd.build.build_core`; if the
+shared object is absent and ``hipcc`` exists it is compiled on first use, otherwise loading
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int32_p = C.POINTER(C.c_int32)
+
+
+class OgDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n", C.c_int32),
+                ("m_eq", C.c_int32), ("m_ineq", C.c_int32), ("n_phase", C.c_int32),
+                ("nodes", _c_int32_p), ("D", C.POINTER(_c_double_p)), ("cvec", _c_double_p),
+                ("n_cvec", C.c_int32), ("module_path", C.c_char_p)]
+
+
+OG_ABI_VERSION = 1
+
+# every symbol include/ogpsx.h declares: (restype, argtypes)
+SIGNATURES = {
+    "og_lgl": (C.c_int, [C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    "og_lgl_dev": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_fd_step": (C.c_int, [C.c_int32, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    "og_problem_create": (C.c_int, [C.POINTER(OgDesc), C.POINTER(C.c_void_p)]),
+    "og_problem_destroy": (None, [C.c_void_p]),
+    "og_problem_dims": (C.c_int, [C.c_void_p, _c_int32_p, _c_int32_p, _c_int32_p, _c_int32_p]),
+    "og_eval": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
+    "og_fd_sweep": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_int32, C.c_int32,
+                              _c_double_p, _c_double_p]),
+    "og_eval_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_fd_sweep_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_last_error": (C.c_char_p, []),
+    "og_device_count": (C.c_int, []),
+}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+@functools.lru_cache(maxsize=None)
+def lib():
+    """Load (building if necessary) libogpsx.so.  Import torch first when it is installed so
+    that both share one HIP runtime (same ``libamdhip64.so.7`` SONAME)."""
+    try:
+        import torch  # noqa: F401  (side effect: its bundled HIP runtime gets loaded first)
+    except Exception:
+        pass
+    path = _build.CORE_LIB
+    if not os.path.exists(path):
+        path = _build.build_core()
+    handle = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    return handle
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().og_last_error()
+        raise NativeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def dptr(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+@functools.lru_cache(maxsize=64)
+def _lgl_cached(n):
+    tau, w, D = np.empty(n), np.empty(n), np.empty((n, n))
+    check(lib().og_lgl(n, dptr(tau), dptr(w), dptr(D)), "og_lgl")
+    for a in (tau, w, D):
+        a.setflags(write=False)
+    return tau, w, D
+
+
+def lgl(n):
+    """LGL nodes, weights, differentiation matrix (fresh writable copies)."""
+    tau, w, D = _lgl_cached(int(n))
+    return tau.copy(), w.copy(), D.copy()
+
+
+def fd_step(x, lb, ub):
+    """SciPy's forward-difference step with bound handling."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    lb = np.ascontiguousarray(lb, dtype=np.float64)
+    ub = np.ascontiguousarray(ub, dtype=np.float64)
+    h = np.empty_like(x)
+    check(lib().og_fd_step(x.shape[0], dptr(x), dptr(lb), dptr(ub), dptr(h)), "og_fd_step")
+    return h
+
+
+def device_count():
+    return int(lib().og_device_count())

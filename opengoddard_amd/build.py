@@ -1,0 +1,93 @@
+"""Compile the HIP sources of this package for gfx950 (in-tree, no JIT cache elsewhere).
+
+Two artefacts:
+
+* ``lib/libogpsx.so`` - the generic runtime and public C ABI (``include/ogpsx.h``), from
+  ``csrc/ogpsx_core.hip``.
+* ``lib/jit/libogk_<hash>.so`` - one callback module per traced problem: the hand-written
+  sweep kernels ``csrc/ogk_kernels.hip`` instantiated with the generated device functions of
+  that problem (``codegen.emit_header``).  Keyed by a hash of the generated source, so a
+  problem is compiled once and the shared object travels with the tree.
+
+``-ffp-contract=off`` is part of the numerical contract (bit parity with the CPU oracle,
+SURVEY.md section 7.4 item 2); fused multiply-adds only happen where the code asks for them.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+JITDIR = os.path.join(LIBDIR, "jit")
+CORE_LIB = os.path.join(LIBDIR, "libogpsx.so")
+ARCH = "gfx950"
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+             "-Wno-unused-value"]
+
+
+class BuildError(RuntimeError):
+    pass
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise BuildError("hipcc not found: the HIP extension cannot be built on this machine")
+    return exe
+
+
+def _run(cmd):
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise BuildError("command failed: %s\n%s" % (" ".join(cmd), proc.stdout[-4000:]))
+    return proc.stdout
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _csrc_files():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
+            if f.endswith((".h", ".hip"))] + [os.path.join(HERE, "..", "include", "ogpsx.h")]
+
+
+def build_core(force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not force and _newer(CORE_LIB, _csrc_files()):
+        return CORE_LIB
+    tmp = CORE_LIB + ".tmp%d" % os.getpid()
+    _run([hipcc()] + HIP_FLAGS + [os.path.join(CSRC, "ogpsx_core.hip"), "-o", tmp, "-ldl"])
+    os.replace(tmp, CORE_LIB)
+    return CORE_LIB
+
+
+def module_path(digest):
+    return os.path.join(JITDIR, "libogk_%s.so" % digest)
+
+
+def build_module(header_source, digest, force=False):
+    """Compile the sweep kernels against one generated header -> shared object path."""
+    os.makedirs(JITDIR, exist_ok=True)
+    out = module_path(digest)
+    kernels = os.path.join(CSRC, "ogk_kernels.hip")
+    deps = [kernels, os.path.join(CSRC, "ogk.h"), os.path.join(CSRC, "og_math.h")]
+    if not force and _newer(out, deps):
+        return out
+    header = os.path.join(JITDIR, "og_gen_%s.h" % digest)
+    with tempfile.NamedTemporaryFile("w", dir=JITDIR, suffix=".h", delete=False) as fh:
+        fh.write(header_source)
+        tmp_header = fh.name
+    os.replace(tmp_header, header)
+    tmp = out + ".tmp%d" % os.getpid()
+    _run([hipcc()] + HIP_FLAGS + ["-I" + CSRC, "-DOG_GEN_HEADER=\"%s\"" % header, kernels,
+                                  "-o", tmp])
+    os.replace(tmp, out)
+    return out

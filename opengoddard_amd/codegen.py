@@ -1,0 +1,627 @@
+"""Lower a traced NLP (``trace.Graph``) to the device-function header the sweep kernels include.
+
+Pipeline::
+
+    trace_problem(prob, obj)          run cost / equality+defects+knots / inequality once on Sym
+        -> Program                    rows of F = [cost | c_eq | c_ineq] as *pieces*
+        -> emit_header(program)       C++17 text: struct OgGen { tables; group_eval; mv_operand }
+
+A *piece* is ``(row_start, length, elem)``: rows ``row_start + k`` for ``k in [0, length)`` are
+the element expression ``elem`` evaluated at ``k``.  Element expressions only have leaves that
+are affine in ``k`` - ``p[base + stride*k]`` (stride 0 or 1), constant-table entries, and the
+collocation products ``(D_phase @ operand)[k]`` that the kernel computes with MFMA - so a piece
+is branch-free device code.  ``np.hstack`` of per-phase slices (``states_all_section``) simply
+becomes several pieces.  Pieces of equal length are bundled into *groups* that share common
+sub-expressions (e.g. all state derivatives of one phase share density / speed terms).
+
+Row order is the reference's: cost; user equalities, defects (phase-major, state-major,
+node), knot rows (``OpenGoddard/optimize.py:674-696``); user inequalities (``:727``).
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from . import trace as _tr
+
+MAX_GROUP_OUTPUTS = 8
+
+
+# ------------------------------------------------------------------------------ element graph
+class EGraph:
+    def __init__(self):
+        self.nodes = []
+        self._index = {}
+
+    def add(self, node):
+        hit = self._index.get(node)
+        if hit is not None:
+            return hit
+        self.nodes.append(node)
+        self._index[node] = len(self.nodes) - 1
+        return len(self.nodes) - 1
+
+
+class MvSlot:
+    """One collocation product ``D[phase] @ operand`` (operand: ``length`` elements)."""
+
+    def __init__(self, phase, length, operand_eid, leaf_base):
+        self.phase, self.length, self.operand, self.leaf_base = phase, length, operand_eid, leaf_base
+
+
+class Group:
+    def __init__(self, kind, length, phase=-1):
+        self.kind = kind              # "rows" | "defect"
+        self.length = length
+        self.phase = phase
+        self.outputs = []             # [(row_start, eid)]
+        self.mv_slots = []            # slot ids feeding y[] (defect groups)
+
+
+class Program:
+    def __init__(self):
+        self.eg = EGraph()
+        self.n = 0
+        self.m_eq = 0
+        self.m_ineq = 0
+        self.nodes = []               # per-phase node counts
+        self.pieces = []              # [(row_start, length, eid, kind)] kind in cost/eq/ineq
+        self.mv = []                  # [MvSlot]
+        self.groups = []
+        self.cvec = np.zeros(0)       # flat constant table
+        self.cvec_off = []            # table id -> offset into cvec
+
+    @property
+    def m(self):
+        return 1 + self.m_eq + self.m_ineq
+
+
+class _Lowerer:
+    """trace.Graph (vector nodes) -> EGraph (element nodes) + pieces."""
+
+    def __init__(self, graph, program):
+        self.g = graph
+        self.P = program
+        self.eg = program.eg
+        self._pieces = {}
+        self._fix = {}
+        self._shift = {}
+        off, at = [], 0
+        for v in graph.cvecs:
+            off.append(at)
+            at += v.shape[0]
+        program.cvec_off = off
+        program.cvec = np.concatenate(graph.cvecs) if graph.cvecs else np.zeros(0)
+        self._mv_index = {}
+
+    # -- substitution helpers ----------------------------------------------------------------
+    def _map(self, eid, leaf_fn, memo):
+        hit = memo.get(eid)
+        if hit is not None:
+            return hit
+        node = self.eg.nodes[eid]
+        tag = node[0]
+        if tag in ("P", "CV", "Y"):
+            out = leaf_fn(node)
+        elif tag in ("C", "sum"):
+            out = eid
+        elif tag == "un":
+            out = self.eg.add(("un", node[1], self._map(node[2], leaf_fn, memo)))
+        elif tag in ("bin", "cmp", "logic"):
+            out = self.eg.add((tag, node[1], self._map(node[2], leaf_fn, memo),
+                               self._map(node[3], leaf_fn, memo)))
+        elif tag == "where":
+            out = self.eg.add(("where",) + tuple(self._map(c, leaf_fn, memo) for c in node[1:]))
+        else:
+            raise AssertionError(tag)
+        memo[eid] = out
+        return out
+
+    def fix(self, eid, i):
+        """Substitute k := i (element becomes k-invariant)."""
+        memo = self._fix.setdefault(i, {})
+
+        def leaf(node):
+            tag = node[0]
+            if tag == "P":
+                return self.eg.add(("P", node[1] + node[2] * i, 0))
+            if tag == "CV":
+                if node[3] == 0:
+                    return self.eg.add(node)
+                value = self.P.cvec[self.P.cvec_off[node[1]] + node[2] + i]
+                return self.eg.add(("C", np.float64(value).tobytes()))
+            return self.eg.add(("Y", node[1], node[2] + node[3] * i, 0))
+        return self._map(eid, leaf, memo)
+
+    def shift(self, eid, d):
+        """Substitute k := k + d."""
+        if d == 0:
+            return eid
+        memo = self._shift.setdefault(d, {})
+
+        def leaf(node):
+            tag = node[0]
+            if tag == "P":
+                return self.eg.add(("P", node[1] + node[2] * d, node[2]))
+            if tag == "CV":
+                return self.eg.add(("CV", node[1], node[2] + node[3] * d, node[3]))
+            return self.eg.add(("Y", node[1], node[2] + node[3] * d, node[3]))
+        return self._map(eid, leaf, memo)
+
+    # -- vector nodes -> pieces ---------------------------------------------------------------
+    def pieces(self, nid):
+        """List of (length, eid); a scalar node gives [(None, eid)]."""
+        hit = self._pieces.get(nid)
+        if hit is not None:
+            return hit
+        node = self.g.nodes[nid]
+        length = self.g.length[nid]
+        tag = node[0]
+        if tag == "p":
+            out = [(node[2], self.eg.add(("P", node[1], 1)))]
+        elif tag == "const":
+            out = [(None, self.eg.add(("C", node[1])))]
+        elif tag == "cvec":
+            out = [(length, self.eg.add(("CV", node[1], 0, 1)))]
+        elif tag == "un":
+            out = [(ln, self.eg.add(("un", node[1], e))) for ln, e in self.pieces(node[2])]
+        elif tag in ("bin", "cmp", "logic"):
+            out = [(ln, self.eg.add((tag, node[1], a, b)))
+                   for ln, (a, b) in self._align([node[2], node[3]], length)]
+        elif tag == "where":
+            out = [(ln, self.eg.add(("where",) + tuple(es)))
+                   for ln, es in self._align(list(node[1:]), length)]
+        elif tag == "idx":
+            out = [(None, self._element(node[1], node[2]))]
+        elif tag == "slice":
+            out = self._subrange(node[1], node[2], node[3])
+        elif tag == "cat":
+            out = []
+            for child in node[1]:
+                for ln, e in self.pieces(child):
+                    out.append((1 if ln is None else ln, e))
+        elif tag == "mv":
+            out = [(length, self.eg.add(("Y", self._mv_slot(node[1], node[2]), 0, 1)))]
+        elif tag == "seqsum":
+            body = tuple((1 if ln is None else ln, e) for ln, e in self.pieces(node[1]))
+            out = [(None, self.eg.add(("sum", body)))]
+        else:
+            raise AssertionError(tag)
+        self._pieces[nid] = out
+        return out
+
+    def _element(self, nid, i):
+        if self.g.length[nid] is None:
+            raise _tr.TraceError("indexing a scalar")
+        at = 0
+        for ln, e in self.pieces(nid):
+            ln = 1 if ln is None else ln
+            if i < at + ln:
+                return self.fix(e, i - at)
+            at += ln
+        raise IndexError(i)
+
+    def _subrange(self, nid, start, count):
+        out, at = [], 0
+        for ln, e in self.pieces(nid):
+            ln = 1 if ln is None else ln
+            lo, hi = max(start, at), min(start + count, at + ln)
+            if lo < hi:
+                out.append((hi - lo, self.shift(e, lo - at)))
+            at += ln
+        return out
+
+    def _align(self, nids, length):
+        """Common refinement of the operands' piece boundaries.  -> [(len, (eids...))]."""
+        lists = []
+        for nid in nids:
+            pcs = self.pieces(nid)
+            ln_total = self.g.length[nid]
+            if ln_total is None:
+                lists.append(("scalar", pcs[0][1]))
+            elif ln_total == 1 and length not in (None, 1):
+                lists.append(("scalar", self.fix(pcs[0][1], 0)))
+            else:
+                lists.append(("vec", [(1 if ln is None else ln, e) for ln, e in pcs]))
+        if length is None:
+            return [(None, tuple(item[1] for item in lists))]
+        cuts = {0, length}
+        for kind, val in lists:
+            if kind == "vec":
+                at = 0
+                for ln, _ in val:
+                    at += ln
+                    cuts.add(at)
+        cuts = sorted(cuts)
+        out = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            es = []
+            for kind, val in lists:
+                if kind == "scalar":
+                    es.append(val)
+                    continue
+                at = 0
+                for ln, e in val:
+                    if at <= lo < at + ln:
+                        es.append(self.shift(e, lo - at))
+                        break
+                    at += ln
+                else:
+                    raise AssertionError("piece lookup")
+            out.append((hi - lo, tuple(es)))
+        return out
+
+    def _mv_slot(self, phase, operand_nid):
+        key = (phase, operand_nid)
+        hit = self._mv_index.get(key)
+        if hit is not None:
+            return hit
+        pcs = self.pieces(operand_nid)
+        if len(pcs) != 1 or pcs[0][0] != self.P.nodes[phase]:
+            raise _tr.TraceError("collocation operand must be one contiguous phase slice")
+        operand = pcs[0][1]
+        leaves = sorted(_leaves(self.eg, operand, ("P",)))
+        strided = [lf for lf in leaves if lf[2] == 1]
+        if len(strided) != 1 or len(leaves) != 1:
+            raise _tr.TraceError("collocation operand must depend on exactly one state slice")
+        self.P.mv.append(MvSlot(phase, pcs[0][0], operand, strided[0][1]))
+        self._mv_index[key] = len(self.P.mv) - 1
+        return len(self.P.mv) - 1
+
+
+def _leaves(eg, eid, tags, seen=None, into_sums=True):
+    """Set of leaf nodes with a tag in ``tags`` reachable from ``eid``."""
+    seen = set() if seen is None else seen
+    out = set()
+    stack = [eid]
+    while stack:
+        e = stack.pop()
+        if e in seen:
+            continue
+        seen.add(e)
+        node = eg.nodes[e]
+        tag = node[0]
+        if tag in tags:
+            out.add(node)
+        if tag == "un":
+            stack.append(node[2])
+        elif tag in ("bin", "cmp", "logic"):
+            stack.extend(node[2:4])
+        elif tag == "where":
+            stack.extend(node[1:])
+        elif tag == "sum" and into_sums:
+            for _, body in node[1]:
+                stack.append(body)
+    return out
+
+
+# ------------------------------------------------------------------------------ tracing driver
+def trace_problem(prob, obj):
+    """Run the NLP assembly once on a symbolic decision vector and lower it to a Program."""
+    n = int(prob.number_of_variables)
+    sym_p = _tr.new_decision_vector(n)
+    graph = sym_p.g
+    saved = prob.p
+    prob.p = sym_p
+    try:
+        cost = prob._assemble_cost(obj)
+        ceq = prob._assemble_equality(obj)
+        cineq = prob.inequality(prob, obj)
+    finally:
+        prob.p = saved
+
+    probe = _tr.Sym(graph, graph.const(0.0))
+
+    def as_sym(v, what):
+        if _tr.is_sym(v):
+            return v
+        lifted = probe._lift(np.asarray(v, dtype=np.float64) if not np.isscalar(v) else v)
+        if lifted is NotImplemented:
+            raise _tr.TraceError("%s returned an untraceable %r" % (what, type(v)))
+        return lifted
+
+    P = Program()
+    P.n = n
+    P.nodes = [int(v) for v in prob.nodes]
+    low = _Lowerer(graph, P)
+
+    cost = as_sym(cost, "cost")
+    if cost.length not in (None, 1):
+        raise _tr.TraceError("cost must be a scalar")
+    cost_eid = low.pieces(cost.id)[0][1]
+    if cost.length == 1:
+        cost_eid = low.fix(cost_eid, 0)
+    P.pieces.append((0, 1, cost_eid, "cost"))
+
+    row = 1
+    for kind, value in (("eq", ceq), ("ineq", cineq)):
+        start = row
+        if isinstance(value, np.ndarray) and value.size == 0:
+            pcs = []                                     # quirk Q14: empty constraint set
+        else:
+            value = as_sym(value, kind)
+            pcs = low.pieces(value.id)
+        for ln, e in pcs:
+            ln = 1 if ln is None else ln
+            P.pieces.append((row, ln, e, kind))
+            row += ln
+        if kind == "eq":
+            P.m_eq = row - start
+        else:
+            P.m_ineq = row - start
+    _make_groups(P)
+    return P
+
+
+def _make_groups(P):
+    eg = P.eg
+    defect = {}
+    buckets = {}
+    order = []
+    for row, ln, e, kind in P.pieces:
+        ys = _leaves(eg, e, ("Y",))
+        if ys:
+            phases = {P.mv[y[1]].phase for y in ys}
+            if len(phases) != 1 or any(y[2] != 0 or y[3] != 1 for y in ys) or \
+                    ln != P.nodes[next(iter(phases))]:
+                raise _tr.TraceError("collocation products may only appear in defect rows")
+            ph = next(iter(phases))
+            if ph not in defect:
+                defect[ph] = Group("defect", ln, ph)
+                order.append(defect[ph])
+            defect[ph].outputs.append((row, e))
+            continue
+        key = (kind, ln)
+        grp = buckets.get(key)
+        if grp is None or len(grp.outputs) >= MAX_GROUP_OUTPUTS:
+            grp = Group("rows", ln)
+            buckets[key] = grp
+            order.append(grp)
+        grp.outputs.append((row, e))
+    for grp in order:
+        if grp.kind == "defect":
+            slots = set()
+            for _, e in grp.outputs:
+                slots |= {y[1] for y in _leaves(eg, e, ("Y",))}
+            grp.mv_slots = sorted(slots)
+            lo = grp.mv_slots[0]
+            if grp.mv_slots != list(range(lo, lo + len(grp.mv_slots))):
+                raise _tr.TraceError("collocation products of a phase must be consecutive")
+            if len(grp.mv_slots) > 16:
+                raise _tr.TraceError("more than 16 states per phase are not supported")
+    P.groups = order
+
+
+# ------------------------------------------------------------------------------ C++ emission
+_UN_C = {"neg": "-(%s)", "sqrt": "ogm::sqrt_(%s)", "exp": "ogm::exp_(%s)", "log": "ogm::log_(%s)",
+         "sin": "ogm::sin_(%s)", "cos": "ogm::cos_(%s)", "tan": "ogm::tan_(%s)",
+         "abs": "ogm::fabs_(%s)"}
+_BIN_C = {"add": "%s + %s", "sub": "%s - %s", "mul": "%s * %s", "div": "%s / %s"}
+_CMP_C = {"lt": "<", "le": "<=", "gt": ">", "ge": ">=", "eq": "==", "ne": "!="}
+
+
+def _cdouble(raw):
+    v = float(np.frombuffer(raw, dtype=np.float64)[0])
+    if v != v:
+        return "__builtin_nan(\"\")"
+    if v in (float("inf"), float("-inf")):
+        return "(-__builtin_inf())" if v < 0 else "__builtin_inf()"
+    return "(%s)" % v.hex()
+
+
+class _Emitter:
+    def __init__(self, program):
+        self.P = program
+        self.eg = program.eg
+
+    def _idx(self, base, stride, var):
+        if stride == 0:
+            return "%d" % base
+        return "%d + %s" % (base, var) if base else var
+
+    def _emit_expr(self, roots, var, lines, names, indent, ymap):
+        """Emit SSA temporaries for every node reachable from ``roots`` (topological order)."""
+        eg = self.eg
+        order, seen = [], set()
+
+        def visit(e):
+            stack = [(e, False)]
+            while stack:
+                cur, done = stack.pop()
+                if done:
+                    order.append(cur)
+                    continue
+                if cur in seen or cur in names:
+                    continue
+                seen.add(cur)
+                stack.append((cur, True))
+                node = eg.nodes[cur]
+                tag = node[0]
+                if tag == "un":
+                    stack.append((node[2], False))
+                elif tag in ("bin", "cmp", "logic"):
+                    stack.append((node[3], False))
+                    stack.append((node[2], False))
+                elif tag == "where":
+                    for c in reversed(node[1:]):
+                        stack.append((c, False))
+        for r in roots:
+            visit(r)
+        pad = " " * indent
+        for e in order:
+            node = eg.nodes[e]
+            tag = node[0]
+            name = "t%d" % e
+            ctype = "const double"
+            if tag == "P":
+                rhs = "x(%s)" % self._idx(node[1], node[2], var)
+            elif tag == "C":
+                rhs = _cdouble(node[1])
+            elif tag == "CV":
+                rhs = "cv[%s]" % self._idx(self.P.cvec_off[node[1]] + node[2], node[3], var)
+            elif tag == "Y":
+                rhs = "y[%d]" % ymap[node[1]]
+            elif tag == "un":
+                rhs = _UN_C[node[1]] % names[node[2]]
+            elif tag == "bin":
+                a, b = names[node[2]], names[node[3]]
+                if node[1] == "max":      # np.maximum: propagate NaN from either side
+                    rhs = "((%s >= %s || %s != %s) ? %s : %s)" % (a, b, a, a, a, b)
+                elif node[1] == "min":
+                    rhs = "((%s <= %s || %s != %s) ? %s : %s)" % (a, b, a, a, a, b)
+                else:
+                    rhs = _BIN_C[node[1]] % (a, b)
+            elif tag == "cmp":
+                ctype = "const bool"
+                rhs = "%s %s %s" % (names[node[2]], _CMP_C[node[1]], names[node[3]])
+            elif tag == "logic":
+                ctype = "const bool"
+                rhs = "%s %s %s" % (names[node[2]], "&&" if node[1] == "and" else "||",
+                                    names[node[3]])
+            elif tag == "where":
+                rhs = "(%s ? %s : %s)" % (names[node[1]], names[node[2]], names[node[3]])
+            elif tag == "sum":
+                raise AssertionError("sum nodes are emitted by _emit_sums")
+            else:
+                raise AssertionError(tag)
+            names[e] = name
+            lines.append("%s%s %s = %s;" % (pad, ctype, name, rhs))
+
+    def _collect_sums(self, roots):
+        eg, out, seen = self.eg, [], set()
+        stack = list(roots)
+        while stack:
+            e = stack.pop()
+            if e in seen:
+                continue
+            seen.add(e)
+            node = eg.nodes[e]
+            tag = node[0]
+            if tag == "sum":
+                out.append(e)
+            elif tag == "un":
+                stack.append(node[2])
+            elif tag in ("bin", "cmp", "logic"):
+                stack.extend(node[2:4])
+            elif tag == "where":
+                stack.extend(node[1:])
+        return out
+
+    def _emit_sums(self, roots, lines, names, indent):
+        pad = " " * indent
+        for e in self._collect_sums(roots):
+            node = self.eg.nodes[e]
+            name = "t%d" % e
+            # Python's sum(): 0 + v[0] + v[1] + ... left to right
+            lines.append("%sdouble %s = 0.0;" % (pad, name))
+            for ln, body in node[1]:
+                if self._collect_sums([body]):
+                    raise _tr.TraceError("nested sums are not supported")
+                lines.append("%sfor (int q = 0; q < %d; ++q) {" % (pad, ln))
+                inner = {}
+                self._emit_expr([body], "q", lines, inner, indent + 4, {})
+                lines.append("%s    %s = %s + %s;" % (pad, name, name, inner[body]))
+                lines.append("%s}" % pad)
+            names[e] = name
+
+    def group_function(self, gi, grp):
+        lines = ["    template <class X> OG_HD static void group%d(const int k, const X& x, "
+                 "const double* y, const double* cv, double* out) {" % gi,
+                 "        (void)k; (void)y; (void)cv;"]
+        names = {}
+        roots = [e for _, e in grp.outputs]
+        ymap = {s: i for i, s in enumerate(grp.mv_slots)}
+        self._emit_sums(roots, lines, names, 8)
+        self._emit_expr(roots, "k", lines, names, 8, ymap)
+        for o, (_, e) in enumerate(grp.outputs):
+            lines.append("        out[%d] = %s;" % (o, names[e]))
+        lines.append("    }")
+        return lines
+
+    def operand_function(self):
+        lines = ["    template <class X> OG_HD static double mv_operand(const int slot, "
+                 "const int k, const X& x, const double* cv) {",
+                 "        (void)cv;",
+                 "        switch (slot) {"]
+        for si, slot in enumerate(self.P.mv):
+            lines.append("        case %d: {" % si)
+            names = {}
+            self._emit_expr([slot.operand], "k", lines, names, 12, {})
+            lines.append("            return %s;" % names[slot.operand])
+            lines.append("        }")
+        lines += ["        default: return 0.0;", "        }", "    }"]
+        return lines
+
+
+def _int_table(name, values):
+    """Table as a host+device accessor (a local constexpr array is usable from device code
+    without a separate device-side definition)."""
+    values = list(values) or [0]
+    body = ", ".join(str(int(v)) for v in values)
+    return ("    OG_HD static int %s(const int i) { constexpr int t[%d] = {%s}; return t[i]; }"
+            % (name, len(values), body))
+
+
+def emit_header(P):
+    """C++17 source of ``struct OgGen`` for this program (host+device, no includes of its own
+    beyond og_math.h)."""
+    em = _Emitter(P)
+    max_out = max(len(g.outputs) for g in P.groups)
+    n_rowitems = sum(g.length for g in P.groups if g.kind == "rows")
+    L = ["// generated by opengoddard_amd.codegen -- do not edit",
+         "#pragma once",
+         "#include \"og_math.h\"",
+         "",
+         "struct OgGen {",
+         "    static constexpr int N_VAR = %d;" % P.n,
+         "    static constexpr int M = %d;" % P.m,
+         "    static constexpr int M_EQ = %d;" % P.m_eq,
+         "    static constexpr int M_INEQ = %d;" % P.m_ineq,
+         "    static constexpr int N_PHASE = %d;" % len(P.nodes),
+         "    static constexpr int N_MV = %d;" % len(P.mv),
+         "    static constexpr int N_GROUPS = %d;" % len(P.groups),
+         "    static constexpr int N_CVEC = %d;" % P.cvec.shape[0],
+         "    static constexpr int MAX_OUT = %d;" % max_out,
+         "    static constexpr int MAX_NMV = %d;" % max([len(g.mv_slots) for g in P.groups] + [1]),
+         "    static constexpr int N_ROW_ITEMS = %d;" % n_rowitems,
+         _int_table("PHASE_NODES", P.nodes),
+         _int_table("MV_PHASE", [s.phase for s in P.mv]),
+         _int_table("MV_LEN", [s.length for s in P.mv]),
+         _int_table("MV_LEAF", [s.leaf_base for s in P.mv]),
+         _int_table("G_KIND", [1 if g.kind == "defect" else 0 for g in P.groups]),
+         _int_table("G_LEN", [g.length for g in P.groups]),
+         _int_table("G_NOUT", [len(g.outputs) for g in P.groups]),
+         _int_table("G_PHASE", [g.phase for g in P.groups]),
+         _int_table("G_MV0", [g.mv_slots[0] if g.mv_slots else 0 for g in P.groups]),
+         _int_table("G_NMV", [len(g.mv_slots) for g in P.groups])]
+    rows = []
+    for g in P.groups:
+        r = [row for row, _ in g.outputs]
+        rows += r + [0] * (max_out - len(r))
+    L.append(_int_table("G_ROW_FLAT", rows))
+    L.append("    OG_HD static int G_ROW(const int g, const int o) { return G_ROW_FLAT(g * MAX_OUT + o); }")
+    # prefix of row-group item counts: row item ri -> (group, k)
+    starts, at = [], 0
+    for g in P.groups:
+        starts.append(at if g.kind == "rows" else -1)
+        if g.kind == "rows":
+            at += g.length
+    L.append(_int_table("G_ITEM0", starts))
+    L.append("")
+    for gi, g in enumerate(P.groups):
+        L += em.group_function(gi, g)
+        L.append("")
+    L += em.operand_function()
+    L.append("")
+    L.append("    template <class X> OG_HD static void group_eval(const int g, const int k, "
+             "const X& x, const double* y, const double* cv, double* out) {")
+    L.append("        switch (g) {")
+    for gi in range(len(P.groups)):
+        L.append("        case %d: group%d(k, x, y, cv, out); break;" % (gi, gi))
+    L += ["        default: break;", "        }", "    }", "};", ""]
+    return "\n".join(L)
+
+
+def program_hash(source):
+    return hashlib.sha256(source.encode()).hexdigest()[:16]

@@ -1,0 +1,55 @@
+// ogk.h -- internal ABI between libogpsx.so (generic runtime) and a compiled callback module
+// libogk_<hash>.so (sweep kernels instantiated for one traced problem).  Not part of the public
+// C ABI (include/ogpsx.h); both sides are built from this tree.
+#pragma once
+#include <stdint.h>
+
+#define OGK_ABI 2
+#define OGK_MAX_PHASE 32
+
+// MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
+// v_mfma_f64_16x16x4_f64 with the state vectors as A and D^T as B:
+//   frag[(nt*KS + ks)*64 + lane] = D[16*nt + (lane & 15)][4*ks + (lane >> 4)]   (0 when padded)
+// nt in [0, NT) output-node tiles, ks in [0, KS) steps over the contraction index l.
+static inline int ogk_frag_nt(int N) { return (N + 15) / 16; }
+static inline int ogk_frag_ks(int N) { return (N + 3) / 4; }
+static inline long ogk_frag_size(int N) { return (long)ogk_frag_nt(N) * ogk_frag_ks(N) * 64; }
+static inline void ogk_frag_pack(int N, const double* D, double* frag) {
+    const int NT = ogk_frag_nt(N), KS = ogk_frag_ks(N);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int k = 16 * nt + (lane & 15), l = 4 * ks + (lane >> 4);
+                frag[((long)nt * KS + ks) * 64 + lane] = (k < N && l < N) ? D[(long)k * N + l] : 0.0;
+            }
+}
+
+typedef struct ogk_info {
+    int32_t abi;
+    int32_t n, m, m_eq, m_ineq;
+    int32_t n_phase, n_mv, n_groups, n_cvec;
+    int32_t phase_nodes[OGK_MAX_PHASE];
+} ogk_info;
+
+typedef struct ogk_args {
+    const double* x0;       // [n] decision vector (device)
+    const double* h;        // [n] signed FD steps (device; unused for a plain evaluation)
+    const double* dfrag;    // packed D fragments of all phases (device)
+    const double* cvec;     // constant table (device, may be NULL when n_cvec == 0)
+    double* f0;             // [m] F(x0): written by mode 0, read by mode 1
+    double* jt;             // [(col_hi-col_lo) * m] transposed Jacobian rows (mode 1)
+    int32_t col_lo, col_hi; // FD columns handled by this launch
+    int64_t dfrag_off[OGK_MAX_PHASE];
+} ogk_args;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// exported by every callback module
+int ogk_get_info(ogk_info* out);
+// mode 0: evaluate F(x0) into f0.  mode 1: FD sweep over [col_lo, col_hi) into jt (needs f0).
+// Only enqueues kernels on `stream`; returns a hipError_t value (0 = success).
+int ogk_launch(const ogk_args* args, int mode, void* stream);
+#ifdef __cplusplus
+}
+#endif

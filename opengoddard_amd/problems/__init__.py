@@ -1,0 +1,46 @@
+"""Problem definitions for the BASELINE.json configurations.
+
+Every module exposes ``build(api=None, **options) -> (prob, obj)``: it constructs a ``Problem``
+from the given API module (default :mod:`opengoddard_amd.optimize`; the golden-vector script
+passes the reference's ``OpenGoddard.optimize`` instead), sets units / guesses / bounds and
+assigns the callbacks.  The callbacks are plain OpenGoddard-style Python on NumPy arrays - the
+same code is run by the reference engine (goldens), by the NumPy oracle, and traced into the
+HIP kernels.
+
+========================  =====  ==========================================================
+name                      n      what
+========================  =====  ==========================================================
+``brachistochrone``        81    C1: 1 phase, 3 states, 1 control, 20 nodes (reference ex. 01)
+``goddard``               201    C2: 1 phase, 3 states, 1 control, 50 nodes (reference ex. 04)
+``polar_tsto_shipped``    282    C3': 2 phases, 5 states, 2 controls, 20 nodes (reference ex. 09)
+``polar_tsto``           1442    C3: 2 phases, 6 states, 3 controls, 80 nodes/phase
+``low_thrust_shipped``    701    C4': 1 phase, 3 states, 4 controls, 100 nodes (reference ex. 10)
+``low_thrust``           2001    C4: 1 phase, 7 states, 3 controls, 200 nodes
+``launch4``              6148    C5: 4 knotted phases, 8 states, 4 controls, 128 nodes/phase
+========================  =====  ==========================================================
+"""
+from __future__ import annotations
+
+import importlib
+
+_REGISTRY = {
+    "brachistochrone": ("brachistochrone", {}),
+    "goddard": ("goddard", {}),
+    "polar_tsto_shipped": ("polar_tsto", {"variant": "5x2", "nodes": [20, 20]}),
+    "polar_tsto": ("polar_tsto", {"variant": "6x3", "nodes": [80, 80]}),
+    "low_thrust_shipped": ("low_thrust", {"variant": "3x4", "nodes": [100]}),
+    "low_thrust": ("low_thrust", {"variant": "7x3", "nodes": [200]}),
+    "launch4": ("launch4", {}),
+}
+
+NAMES = tuple(_REGISTRY)
+
+
+def build(name, api=None, **options):
+    """Instantiate a registered configuration -> ``(prob, obj)``."""
+    module, defaults = _REGISTRY[name]
+    kwargs = dict(defaults)
+    kwargs.update(options)
+    if api is None:
+        from .. import optimize as api
+    return importlib.import_module("." + module, __name__).build(api, **kwargs)

@@ -1,0 +1,416 @@
+"""Callback tracer: turns the user's NumPy-style OpenGoddard callbacks into an expression graph.
+
+The reference evaluates ``dynamics / equality / inequality / cost / running_cost`` as arbitrary
+Python on every one of the 3n+2 callback evaluations of an SLSQP major iteration
+(reference ``OpenGoddard/optimize.py:670-715``).  A GPU sweep needs the same
+arithmetic as device code.  During ``Problem.solve`` the decision vector ``prob.p`` is replaced
+*once* by a :class:`Sym` vector; the unmodified callbacks then run on symbolic slices, and
+every NumPy ufunc / operator they apply is recorded in exactly the order NumPy would execute
+it.  :mod:`opengoddard_amd.codegen` lowers the recorded graph to HIP device functions.
+
+Supported (this is what the shipped examples use, SURVEY.md section 0 finding 1): ``+ - * /``,
+unary minus, ``**`` with exponent 2 / 0.5 / 1 / -1 (NumPy's fast paths), ``np.sqrt exp log sin
+cos tan abs square deg2rad rad2deg maximum minimum where``, comparisons, integer / negative
+indexing, unit-step slicing, boolean-mask assignment with a scalar (``h[h < a] = a``,
+reference ``examples/09_Rocket_Ascent_Polar_TSTO.py:36``), ``np.hstack / concatenate / append``.
+Anything else raises :class:`TraceError` - there is no silent CPU fallback.
+"""
+from __future__ import annotations
+
+import numbers
+
+import numpy as np
+
+
+class TraceError(RuntimeError):
+    """A callback did something the tracer cannot turn into device code."""
+
+
+# ----------------------------------------------------------------------------- graph nodes
+class Graph:
+    """Hash-consed expression DAG.  A node is a tuple; ``length`` None means scalar."""
+
+    def __init__(self):
+        self.nodes = []          # id -> tuple
+        self.length = []         # id -> int | None
+        self.isbool = []         # id -> bool
+        self._index = {}
+        self.cvecs = []          # constant vectors referenced by ("cvec", i)
+        self._cvec_index = {}
+
+    def add(self, node, length, isbool=False):
+        key = (node, length, isbool)
+        hit = self._index.get(key)
+        if hit is not None:
+            return hit
+        self.nodes.append(node)
+        self.length.append(length)
+        self.isbool.append(isbool)
+        self._index[key] = len(self.nodes) - 1
+        return len(self.nodes) - 1
+
+    def const(self, value):
+        value = float(value)
+        # key on the bit pattern so that -0.0 and 0.0, and NaNs, stay distinct / hashable
+        return self.add(("const", np.float64(value).tobytes()), None)
+
+    def cvec(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        key = arr.tobytes()
+        idx = self._cvec_index.get(key)
+        if idx is None:
+            idx = len(self.cvecs)
+            self.cvecs.append(arr.copy())
+            self._cvec_index[key] = idx
+        return self.add(("cvec", idx), int(arr.shape[0]))
+
+
+def const_value(node):
+    return float(np.frombuffer(node[1], dtype=np.float64)[0])
+
+
+_UNARY = {
+    np.negative: "neg", np.sqrt: "sqrt", np.exp: "exp", np.log: "log", np.sin: "sin",
+    np.cos: "cos", np.tan: "tan", np.absolute: "abs", np.fabs: "abs", np.square: "square",
+    np.positive: "pos", np.reciprocal: "recip",
+}
+_BINARY = {
+    np.add: "add", np.subtract: "sub", np.multiply: "mul", np.true_divide: "div",
+    np.maximum: "max", np.minimum: "min",
+}
+_COMPARE = {
+    np.less: "lt", np.less_equal: "le", np.greater: "gt", np.greater_equal: "ge",
+    np.equal: "eq", np.not_equal: "ne",
+}
+_LOGICAL = {np.logical_and: "and", np.logical_or: "or", np.bitwise_and: "and", np.bitwise_or: "or"}
+
+_DEG2RAD = float(np.pi / 180.0)    # NumPy: deg2rad(x) = x * (pi/180), rad2deg(x) = x * (180/pi)
+_RAD2DEG = float(180.0 / np.pi)
+
+
+def _norm_index(i, length):
+    if length is None:
+        raise TraceError("indexing a scalar")
+    i = int(i)
+    if i < 0:
+        i += length
+    if not 0 <= i < length:
+        raise IndexError("index %d out of range for traced vector of length %d" % (i, length))
+    return i
+
+
+class Sym:
+    """A traced value: scalar (``length is None``) or 1-D vector of ``length`` elements."""
+
+    __array_priority__ = 1000.0
+
+    def __init__(self, graph, nid):
+        self.g = graph
+        self.id = nid
+
+    # ------------------------------------------------------------------ basics
+    @property
+    def length(self):
+        return self.g.length[self.id]
+
+    @property
+    def shape(self):
+        return () if self.length is None else (self.length,)
+
+    @property
+    def ndim(self):
+        return 0 if self.length is None else 1
+
+    @property
+    def size(self):
+        return 1 if self.length is None else self.length
+
+    def __len__(self):
+        if self.length is None:
+            raise TypeError("len() of traced scalar")
+        return self.length
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __bool__(self):
+        raise TraceError("Python control flow on a traced value (if/while/and/or on the decision "
+                         "variables) cannot be turned into a GPU kernel")
+
+    def __float__(self):
+        raise TraceError("float() of a traced value: the callback needs a concrete number")
+
+    __int__ = __float__
+    __index__ = __float__
+
+    def __array__(self, *a, **k):
+        raise TraceError("a traced value was passed to a NumPy routine the tracer does not "
+                         "understand (only elementwise ufuncs, hstack/concatenate/append, where)")
+
+    def __repr__(self):
+        return "Sym(#%d, len=%s)" % (self.id, self.length)
+
+    def copy(self):
+        return Sym(self.g, self.id)
+
+    # ------------------------------------------------------------------ lifting
+    def _lift(self, other):
+        """-> Sym or NotImplemented.  ndarray of size 1 is a scalar like NumPy broadcasting."""
+        if isinstance(other, Sym):
+            if other.g is not self.g:
+                raise TraceError("mixing values from two different traces")
+            return other
+        if isinstance(other, (numbers.Real, np.bool_)):
+            return Sym(self.g, self.g.const(other))
+        if isinstance(other, np.ndarray):
+            if other.ndim == 0 or other.size == 1 and other.ndim <= 1:
+                return Sym(self.g, self.g.const(other.reshape(-1)[0]))
+            if other.ndim == 1:
+                return Sym(self.g, self.g.cvec(other))
+            raise TraceError("only 1-D arrays can be combined with traced values")
+        if isinstance(other, (list, tuple)):
+            return self._lift(np.asarray(other, dtype=np.float64))
+        return NotImplemented
+
+    def _bcast_len(self, other):
+        la, lb = self.length, other.length
+        if la is None:
+            return lb
+        if lb is None or la == lb:
+            return la
+        if la == 1:
+            return lb
+        if lb == 1:
+            return la
+        raise TraceError("shape mismatch in traced elementwise op: %d vs %d" % (la, lb))
+
+    def _unary(self, op):
+        if op == "pos":
+            return self
+        if op == "square":
+            return self._binary("mul", self)
+        if op == "recip":
+            return Sym(self.g, self.g.const(1.0))._binary("div", self)
+        return Sym(self.g, self.g.add(("un", op, self.id), self.length))
+
+    def _binary(self, op, other, swap=False):
+        other = self._lift(other)
+        if other is NotImplemented:
+            return NotImplemented
+        a, b = (other, self) if swap else (self, other)
+        length = a._bcast_len(b)
+        return Sym(self.g, self.g.add(("bin", op, a.id, b.id), length))
+
+    def _compare(self, op, other, swap=False):
+        other = self._lift(other)
+        if other is NotImplemented:
+            return NotImplemented
+        a, b = (other, self) if swap else (self, other)
+        return Sym(self.g, self.g.add(("cmp", op, a.id, b.id), a._bcast_len(b), True))
+
+    # ------------------------------------------------------------------ operators
+    def __neg__(self): return self._unary("neg")
+    def __pos__(self): return self
+    def __abs__(self): return self._unary("abs")
+    def __add__(self, o): return self._binary("add", o)
+    def __radd__(self, o): return self._binary("add", o, swap=True)
+    def __sub__(self, o): return self._binary("sub", o)
+    def __rsub__(self, o): return self._binary("sub", o, swap=True)
+    def __mul__(self, o): return self._binary("mul", o)
+    def __rmul__(self, o): return self._binary("mul", o, swap=True)
+    def __truediv__(self, o): return self._binary("div", o)
+    def __rtruediv__(self, o): return self._binary("div", o, swap=True)
+    def __lt__(self, o): return self._compare("lt", o)
+    def __le__(self, o): return self._compare("le", o)
+    def __gt__(self, o): return self._compare("gt", o)
+    def __ge__(self, o): return self._compare("ge", o)
+    def __and__(self, o): return self._logical("and", o)
+    def __or__(self, o): return self._logical("or", o)
+
+    def _logical(self, op, other):
+        if not (isinstance(other, Sym) and self.g.isbool[self.id] and self.g.isbool[other.id]):
+            raise TraceError("& and | are only traced between comparison results")
+        return Sym(self.g, self.g.add(("logic", op, self.id, other.id),
+                                      self._bcast_len(other), True))
+
+    def __pow__(self, e):
+        # NumPy's scalar-exponent fast paths (numpy/_core/src/multiarray/number.c fast_scalar_power):
+        # 2 -> square (x*x), 0.5 -> sqrt, 1 -> +x, -1 -> reciprocal.  Other exponents call libm
+        # pow(), which has no bit-reproducible device twin here.
+        if isinstance(e, (numbers.Real, np.ndarray)) and np.ndim(e) == 0:
+            e = float(e)
+            if e == 2.0:
+                return self._binary("mul", self)
+            if e == 1.0:
+                return self
+            if e == 0.5:
+                return self._unary("sqrt")
+            if e == -1.0:
+                return self._unary("recip")
+            if e == 0.0:
+                return _ones_like(self)
+        raise TraceError("x ** %r is not traceable (supported exponents: 2, 1, 0.5, -1, 0)" % (e,))
+
+    # ------------------------------------------------------------------ indexing
+    def __getitem__(self, key):
+        n = self.length
+        if isinstance(key, (numbers.Integral, np.integer)):
+            return Sym(self.g, self.g.add(("idx", self.id, _norm_index(key, n)), None))
+        if isinstance(key, slice):
+            if n is None:
+                raise TraceError("slicing a traced scalar")
+            start, stop, step = key.indices(n)
+            if step != 1:
+                raise TraceError("only unit-step slices are traceable")
+            ln = max(0, stop - start)
+            if start == 0 and ln == n:
+                return self
+            return Sym(self.g, self.g.add(("slice", self.id, start, ln), ln))
+        raise TraceError("unsupported index %r on a traced vector" % (key,))
+
+    def __setitem__(self, key, value):
+        # in-place boolean-mask assignment: x[mask] = scalar  ->  x = where(mask, scalar, x)
+        if isinstance(key, Sym) and self.g.isbool[key.id]:
+            v = self._lift(value)
+            if v is NotImplemented or v.length not in (None, 1):
+                raise TraceError("masked assignment needs a scalar right-hand side")
+            if key.length not in (None, 1, self.length):
+                raise TraceError("mask length mismatch")
+            self.id = self.g.add(("where", key.id, v.id, self.id), self.length)
+            return
+        raise TraceError("only boolean-mask assignment (x[x < a] = a) is traceable")
+
+    # ------------------------------------------------------------------ NumPy protocol
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method != "__call__" or kwargs.get("out") is not None:
+            raise TraceError("ufunc method %s.%s is not traceable" % (ufunc.__name__, method))
+        if ufunc in _UNARY:
+            return inputs[0]._unary(_UNARY[ufunc])
+        if ufunc is np.deg2rad or ufunc is np.radians:
+            return inputs[0]._binary("mul", _DEG2RAD)
+        if ufunc is np.rad2deg or ufunc is np.degrees:
+            return inputs[0]._binary("mul", _RAD2DEG)
+        if ufunc is np.power:
+            if isinstance(inputs[0], Sym):
+                return inputs[0].__pow__(inputs[1])
+            raise TraceError("const ** traced is not traceable")
+        table = _BINARY if ufunc in _BINARY else _COMPARE if ufunc in _COMPARE else \
+            _LOGICAL if ufunc in _LOGICAL else None
+        if table is None:
+            raise TraceError("NumPy ufunc %s is not traceable" % ufunc.__name__)
+        a, b = inputs
+        if isinstance(a, Sym):
+            me, other, swap = a, b, False
+        else:
+            me, other, swap = b, a, True
+        if table is _BINARY:
+            out = me._binary(table[ufunc], other, swap)
+        elif table is _COMPARE:
+            out = me._compare(table[ufunc], other, swap)
+        else:
+            out = me._logical(table[ufunc], other)
+        if out is NotImplemented:
+            raise TraceError("unsupported operand for %s" % ufunc.__name__)
+        return out
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func in (np.hstack, np.concatenate):
+            return cat(list(args[0]))
+        if func is np.append:
+            return cat([args[0], args[1]])
+        if func is np.where and len(args) == 3:
+            return where(*args)
+        if func is np.clip:
+            x, lo, hi = args[0], args[1], args[2]
+            return np.minimum(np.maximum(x, lo), hi)
+        if func is np.sum and len(args) == 1 and not kwargs:
+            raise TraceError("np.sum uses pairwise summation, which has no traced twin; use "
+                             "prob.running_cost for integrals")
+        if func in (np.shape,):
+            return args[0].shape
+        if func in (np.size,):
+            return args[0].size
+        if func in (np.ndim,):
+            return args[0].ndim
+        if func is np.copy:
+            return args[0].copy()
+        raise TraceError("NumPy function %s is not traceable" % getattr(func, "__name__", func))
+
+
+def _ones_like(s):
+    if s.length is None:
+        return Sym(s.g, s.g.const(1.0))
+    return Sym(s.g, s.g.cvec(np.ones(s.length)))
+
+
+def is_sym(x):
+    return isinstance(x, Sym)
+
+
+def _find_graph(items):
+    for it in items:
+        if isinstance(it, Sym):
+            return it.g
+    return None
+
+
+def cat(items):
+    """``np.hstack`` that also understands traced values (scalars count as one element)."""
+    g = _find_graph(items)
+    if g is None:
+        return np.hstack([np.atleast_1d(np.asarray(i, dtype=np.float64)) for i in items]) \
+            if len(items) else np.zeros(0)
+    ids, total = [], 0
+    probe = Sym(g, g.const(0.0))
+    for it in items:
+        if isinstance(it, np.ndarray) and it.size == 0:
+            continue
+        if isinstance(it, (list, tuple)):
+            it = np.asarray(it, dtype=np.float64)
+            if it.size == 0:
+                continue
+        s = probe._lift(it) if not isinstance(it, Sym) else it
+        if s is NotImplemented:
+            raise TraceError("cannot concatenate %r with traced values" % (type(it),))
+        if isinstance(it, np.ndarray) and it.ndim == 1 and it.size == 1:
+            # keep a length-1 *vector* (not a broadcastable scalar) for layout purposes
+            pass
+        n = 1 if s.length is None else s.length
+        if n == 0:
+            continue
+        ids.append(s.id)
+        total += n
+    if len(ids) == 1 and g.length[ids[0]] is not None:
+        return Sym(g, ids[0])
+    return Sym(g, g.add(("cat", tuple(ids)), total))
+
+
+def where(cond, a, b):
+    g = _find_graph([cond, a, b])
+    if g is None:
+        return np.where(cond, a, b)
+    probe = Sym(g, g.const(0.0))
+    c, a, b = (probe._lift(v) for v in (cond, a, b))
+    if not g.isbool[c.id]:
+        raise TraceError("np.where condition must be a traced comparison")
+    length = c._bcast_len(a)
+    length2 = a._bcast_len(b)
+    length = length if length2 is None else (length2 if length is None else max(length, length2))
+    return Sym(g, g.add(("where", c.id, a.id, b.id), length))
+
+
+def matvec(phase, operand):
+    """Collocation derivative ``D[phase] @ operand`` as a single traced node."""
+    return Sym(operand.g, operand.g.add(("mv", int(phase), operand.id), operand.length))
+
+
+def seqsum(vec):
+    """Python's builtin ``sum``: left-to-right, starting from int 0 (reference
+    ``OpenGoddard/optimize.py:708``)."""
+    return Sym(vec.g, vec.g.add(("seqsum", vec.id), None))
+
+
+def new_decision_vector(n):
+    g = Graph()
+    return Sym(g, g.add(("p", 0, int(n)), int(n)))

@@ -59,9 +59,7 @@ def lib():
         import torch  # noqa: F401  (side effect: its bundled HIP runtime gets loaded first)
     except Exception:
         pass
-    path = _build.CORE_LIB
-    if not os.path.exists(path):
-        path = _build.build_core()
+    path = _build.build_core()          # no-op when the in-tree library matches its sources
     handle = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)

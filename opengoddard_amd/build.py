@@ -14,6 +14,7 @@ SURVEY.md section 7.4 item 2); fused multiply-adds only happen where the code as
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -47,39 +48,58 @@ def _run(cmd):
     return proc.stdout
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
-        return False
-    t = os.path.getmtime(target)
-    return all(os.path.getmtime(s) <= t for s in sources)
+def _digest_files(paths, extra=""):
+    """Content hash of the sources an artefact is built from (mtimes do not survive the
+    snapshot copy to the GPU box, content does)."""
+    hsh = hashlib.sha256(extra.encode())
+    for path in paths:
+        with open(path, "rb") as fh:
+            hsh.update(fh.read())
+    hsh.update(" ".join(HIP_FLAGS).encode())
+    return hsh.hexdigest()[:16]
 
 
-def _csrc_files():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
-            if f.endswith((".h", ".hip"))] + [os.path.join(HERE, "..", "include", "ogpsx.h")]
+def _core_sources():
+    return [os.path.join(CSRC, f) for f in ("ogpsx_core.hip", "og_lgl.h", "og_math.h", "ogk.h")] + \
+        [os.path.join(HERE, "..", "include", "ogpsx.h")]
+
+
+def _kernel_sources():
+    return [os.path.join(CSRC, f) for f in ("ogk_kernels.hip", "ogk.h", "og_math.h")]
 
 
 def build_core(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    if not force and _newer(CORE_LIB, _csrc_files()):
-        return CORE_LIB
+    stamp_path = CORE_LIB + ".stamp"
+    want = _digest_files(_core_sources())
+    if not force and os.path.exists(CORE_LIB) and os.path.exists(stamp_path):
+        with open(stamp_path) as fh:
+            if fh.read().strip() == want:
+                return CORE_LIB
     tmp = CORE_LIB + ".tmp%d" % os.getpid()
     _run([hipcc()] + HIP_FLAGS + [os.path.join(CSRC, "ogpsx_core.hip"), "-o", tmp, "-ldl"])
     os.replace(tmp, CORE_LIB)
+    with open(stamp_path, "w") as fh:
+        fh.write(want)
     return CORE_LIB
+
+
+def module_digest(header_source):
+    """Key of a callback module: generated header + kernel sources + flags."""
+    return _digest_files(_kernel_sources(), extra=header_source)
 
 
 def module_path(digest):
     return os.path.join(JITDIR, "libogk_%s.so" % digest)
 
 
-def build_module(header_source, digest, force=False):
+def build_module(header_source, digest=None, force=False):
     """Compile the sweep kernels against one generated header -> shared object path."""
     os.makedirs(JITDIR, exist_ok=True)
+    digest = module_digest(header_source)
     out = module_path(digest)
     kernels = os.path.join(CSRC, "ogk_kernels.hip")
-    deps = [kernels, os.path.join(CSRC, "ogk.h"), os.path.join(CSRC, "og_math.h")]
-    if not force and _newer(out, deps):
+    if not force and os.path.exists(out):
         return out
     header = os.path.join(JITDIR, "og_gen_%s.h" % digest)
     with tempfile.NamedTemporaryFile("w", dir=JITDIR, suffix=".h", delete=False) as fh:

@@ -1,0 +1,120 @@
+"""HIP engine: the GPU evaluation of one Problem's NLP callbacks behind ``Problem.solve``.
+
+Construction traces the callbacks (``codegen.trace_problem``), emits the device header,
+compiles the sweep kernels against it (``build.build_module``; cached by source hash) and
+creates a handle in ``libogpsx.so`` (``og_problem_create``, include/ogpsx.h).  Afterwards
+
+* :meth:`values` = one ``og_eval``: ``(cost, c_eq, c_ineq)`` at ``p``  - replaces one call each
+  of the reference's ``cost_add`` / ``equality_add`` / ``inequality`` (``optimize.py:670-728``);
+* :meth:`jacobians` = one ``og_fd_sweep`` over all n columns - replaces the 3n+2 Python
+  callback evaluations SciPy's ``approx_derivative`` makes per SLSQP major iteration
+  (``scipy/optimize/_slsqp_py.py:299-313``, ``_numdiff.py:584-625``).
+
+There is deliberately no NumPy fallback: no GPU or no compiled extension => exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native, build, codegen
+
+
+class HipEngine:
+    def __init__(self, prob, obj, device=0, program=None):
+        lib = _native.lib()
+        if _native.device_count() < 1:
+            raise RuntimeError("opengoddard_amd: no HIP device is visible; the MI355X engine has "
+                               "no CPU fallback")
+        self.program = program or codegen.trace_problem(prob, obj)
+        self.header = codegen.emit_header(self.program)
+        self.digest = codegen.program_hash(self.header)
+        self.module_path = build.build_module(self.header, self.digest)
+        P = self.program
+        self.n, self.m, self.m_eq, self.m_ineq = P.n, P.m, P.m_eq, P.m_ineq
+        self.device = int(device)
+
+        self._nodes = (C.c_int32 * len(P.nodes))(*P.nodes)
+        self._D = [np.ascontiguousarray(D, dtype=np.float64) for D in prob.D]
+        dp = C.POINTER(C.c_double)
+        self._Dptr = (dp * len(self._D))(*[d.ctypes.data_as(dp) for d in self._D])
+        self._cvec = np.ascontiguousarray(P.cvec, dtype=np.float64)
+        desc = _native.OgDesc(
+            abi_version=_native.OG_ABI_VERSION, device=self.device, n=P.n, m_eq=P.m_eq,
+            m_ineq=P.m_ineq, n_phase=len(P.nodes), nodes=self._nodes, D=self._Dptr,
+            cvec=self._cvec.ctypes.data_as(dp) if self._cvec.size else None,
+            n_cvec=int(self._cvec.size), module_path=self.module_path.encode())
+        self._lib = lib
+        self._handle = C.c_void_p()
+        _native.check(lib.og_problem_create(C.byref(desc), C.byref(self._handle)),
+                      "og_problem_create")
+        self._val_key = self._val = None
+        self._jac_key = self._jac = None
+        self.n_values = self.n_sweeps = 0
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.og_problem_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ raw calls
+    def eval_stacked(self, x):
+        """F(x) = [cost | c_eq | c_ineq] (host in, host out)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.n,)
+        F = np.empty(self.m)
+        _native.check(self._lib.og_eval(self._handle, _native.dptr(x), _native.dptr(F)), "og_eval")
+        return F
+
+    def sweep_stacked(self, x, h, col_lo=0, col_hi=None):
+        """(F0, JT) with JT[(j - col_lo), r] = dF_r/dx_j for the columns in [col_lo, col_hi)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        col_hi = self.n if col_hi is None else int(col_hi)
+        F0 = np.empty(self.m)
+        JT = np.empty((col_hi - col_lo, self.m))
+        _native.check(self._lib.og_fd_sweep(self._handle, _native.dptr(x), _native.dptr(h),
+                                            int(col_lo), col_hi, _native.dptr(JT),
+                                            _native.dptr(F0)), "og_fd_sweep")
+        return F0, JT
+
+    def eval_dev(self, d_x, d_F, stream=0):
+        _native.check(self._lib.og_eval_dev(self._handle, d_x, d_F, stream), "og_eval_dev")
+
+    def sweep_dev(self, d_x, d_h, col_lo, col_hi, d_JT, d_F0, stream=0):
+        """Asynchronous device-pointer sweep (ints from ``torch.Tensor.data_ptr()``)."""
+        _native.check(self._lib.og_fd_sweep_dev(self._handle, d_x, d_h, int(col_lo), int(col_hi),
+                                                d_JT, d_F0, stream), "og_fd_sweep_dev")
+
+    # ------------------------------------------------------------------ SciPy-facing
+    def _split(self, F):
+        return F[0], F[1:1 + self.m_eq], F[1 + self.m_eq:]
+
+    def values(self, p):
+        key = np.asarray(p, dtype=np.float64).tobytes()
+        if key != self._val_key:
+            self._val = self._split(self.eval_stacked(p))
+            self._val_key = key
+            self.n_values += 1
+        return self._val
+
+    def jacobians(self, p, lb, ub):
+        """((grad, J_eq, J_ineq), h) at ``p``; one sweep serves all three SLSQP requests."""
+        key = np.asarray(p, dtype=np.float64).tobytes()
+        if key != self._jac_key:
+            h = _native.fd_step(p, lb, ub)
+            F0, JT = self.sweep_stacked(p, h)
+            J = JT.T
+            self._jac = ((np.ascontiguousarray(J[0]), J[1:1 + self.m_eq], J[1 + self.m_eq:]), h)
+            self._jac_key = key
+            self._val, self._val_key = self._split(F0), key
+            self.n_sweeps += 1
+        return self._jac

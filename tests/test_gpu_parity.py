@@ -1,0 +1,160 @@
+"""GPU parity tests (``-m gpu``): the HIP sweep, called through the C ABI, against
+
+1. the CPU twin (``oracle/twin.cpp``) - same arithmetic order, so the bar is **bit-exact**
+   (values, Jacobian entries, zero pattern), at the reference's golden evaluation points;
+2. the reference's own goldens (``tests/golden/cfg_*.npz``, made by the reference engine +
+   SciPy 1.15.3) - residuals within 1e-9 relative to the row's term magnitude, Jacobian within
+   the forward-difference noise bound of SURVEY.md section 8(c):
+   ``1e-9*|J| + 64*eps*rowscale/|h|`` (the reference's own Jacobian moves by this much when its
+   BLAS merely sums in a different order).
+"""
+import numpy as np
+import pytest
+
+from conftest import fd_noise_bound, inject_reference_lgl
+from opengoddard_amd import _native, problems
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ("brachistochrone", "goddard", "polar_tsto_shipped", "low_thrust_shipped")
+ALL = problems.NAMES
+
+
+def _engine_and_twin(name, lgl=None):
+    from opengoddard_amd.engine import HipEngine
+    from oracle import twin
+    prob, obj = problems.build(name)
+    if lgl is not None:
+        inject_reference_lgl(prob, lgl)
+    eng = HipEngine(prob, obj)
+    tw = twin.Twin(prob, obj, program=eng.program, header=eng.header)
+    return prob, obj, eng, tw
+
+
+def row_scales(eng, prob, x, F):
+    """Magnitude of the terms summed in each row (defect rows: sum_l |D_kl| |x~_l|)."""
+    scale = np.maximum(1.0, np.abs(F))
+    P = eng.program
+    for g in P.groups:
+        if g.kind != "defect":
+            continue
+        D = np.abs(prob.D[g.phase])
+        for (row, _), slot in zip(g.outputs, g.mv_slots):
+            leaf = P.mv[slot].leaf_base
+            xs = np.abs(x[leaf:leaf + g.length])
+            scale[row:row + g.length] = np.maximum(scale[row:row + g.length], D.dot(xs))
+    return scale
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_bit_exact_against_cpu_twin(name, golden):
+    G = golden("cfg_" + name)
+    prob, obj, eng, tw = _engine_and_twin(name)
+    from oracle import np_path
+    lb, ub = np_path.bounds_arrays(prob)
+    for k in range(G["x"].shape[0]):
+        x = G["x"][k]
+        F_gpu = eng.eval_stacked(x)
+        assert np.array_equal(F_gpu, tw.values(x)), "F differs at point %d" % k
+        h = _native.fd_step(x, lb, ub)
+        assert np.array_equal(h, G["h"][k]), "FD step rule differs from SciPy's at point %d" % k
+        cols = np.arange(eng.n) if eng.n <= 800 else G["cols"]
+        F0, JT = eng.sweep_stacked(x, h)
+        assert np.array_equal(F0, F_gpu)
+        F0c, JTc = tw.sweep(x, h, cols)
+        assert np.array_equal(JT[cols], JTc), "Jacobian differs from the CPU twin at point %d" % k
+        assert np.isfinite(JT).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_against_reference_goldens(name, golden, lgl_golden):
+    G = golden("cfg_" + name)
+    prob, obj, eng, tw = _engine_and_twin(name, lgl_golden)
+    cols = G["cols"]
+    for k in range(G["x"].shape[0]):
+        x, Fg, h, JTg = G["x"][k], G["F"][k], G["h"][k], G["JT"][k]
+        F0, JT = eng.sweep_stacked(x, h)
+        scale = row_scales(eng, prob, x, Fg)
+        assert np.all(np.abs(F0 - Fg) <= 1e-9 * scale), \
+            "residual off by %.3g" % np.max(np.abs(F0 - Fg) / scale)
+        # all-elementwise rows without transcendentals round identically on GPU and in NumPy
+        bound = fd_noise_bound(JTg, scale, h[cols])
+        err = np.abs(JT[cols] - JTg)
+        assert np.all(err <= bound), "Jacobian outside the FD noise bound: worst ratio %.3g" % \
+            np.max(err / np.maximum(bound, 1e-300))
+    eng.close()
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_column_sharding_is_bitwise_invariant(name, golden):
+    """sharding FD columns must not change a single bit."""
+    G = golden("cfg_" + name)
+    prob, obj, eng, tw = _engine_and_twin(name)
+    x, h = G["x"][1], G["h"][1]
+    _, full = eng.sweep_stacked(x, h)
+    for parts in (2, 3, 8):
+        edges = np.linspace(0, eng.n, parts + 1).astype(int)
+        pieces = [eng.sweep_stacked(x, h, lo, hi)[1] for lo, hi in zip(edges[:-1], edges[1:])]
+        assert np.array_equal(np.vstack(pieces), full)
+    eng.close()
+
+
+def test_sweep_is_deterministic(golden):
+    G = golden("cfg_polar_tsto")
+    prob, obj, eng, tw = _engine_and_twin("polar_tsto")
+    x, h = G["x"][0], G["h"][0]
+    a = eng.sweep_stacked(x, h)[1]
+    b = eng.sweep_stacked(x, h)[1]
+    assert np.array_equal(a, b)
+    eng.close()
+
+
+def test_device_pointer_entry_points_match_host_entry_points(golden):
+    import torch
+    G = golden("cfg_goddard")
+    prob, obj, eng, tw = _engine_and_twin("goddard")
+    x, h = G["x"][0], G["h"][0]
+    F0, JT = eng.sweep_stacked(x, h)
+    dev = torch.device("cuda", 0)
+    d_x = torch.from_numpy(x).to(dev)
+    d_h = torch.from_numpy(h).to(dev)
+    d_F = torch.empty(eng.m, dtype=torch.float64, device=dev)
+    d_JT = torch.empty((eng.n, eng.m), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), 0, eng.n, d_JT.data_ptr(), d_F.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_JT.cpu().numpy(), JT)
+    assert np.array_equal(d_F.cpu().numpy(), F0)
+    eng.close()
+
+
+def test_lgl_kernel_matches_host_bitwise():
+    import ctypes as C
+    import torch
+    lib = _native.lib()
+    dev = torch.device("cuda", 0)
+    for n in (3, 4, 5, 20, 50, 80, 128, 200):
+        tau, w, D = _native.lgl(n)
+        d_tau = torch.empty(n, dtype=torch.float64, device=dev)
+        d_w = torch.empty(n, dtype=torch.float64, device=dev)
+        d_D = torch.empty((n, n), dtype=torch.float64, device=dev)
+        _native.check(lib.og_lgl_dev(n, C.c_void_p(d_tau.data_ptr()), C.c_void_p(d_w.data_ptr()),
+                                     C.c_void_p(d_D.data_ptr()), None), "og_lgl_dev")
+        assert np.array_equal(d_tau.cpu().numpy(), tau)
+        assert np.array_equal(d_w.cpu().numpy(), w)
+        assert np.array_equal(d_D.cpu().numpy(), D)
+
+
+def test_hardware_probe():
+    """MFMA f64 = k-ordered fma chain; f64 div/sqrt/og_math bit-identical host vs device."""
+    import os
+    import subprocess
+    probe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                         "tools", "_build", "gpu_probe")
+    if not os.path.exists(probe):
+        pytest.skip("probe binary not built (run __graft_entry__.build())")
+    out = subprocess.run([probe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: full forward-difference Jacobian sweeps of the NLP callbacks.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One *step* = one SLSQP major iteration's worth of callback work at a fixed point x0 that is
+already resident in HBM: F(x0) plus the n forward-difference columns of
+[cost | c_eq | c_ineq], written as the transposed Jacobian (n x m, float64) into HBM.  The
+reference spends 3n+2 Python callback evaluations on this, so
+``value`` = (3n+2) * K / elapsed  [NLP-callback evals/s], BASELINE.json's metric.
+
+Workload: BASELINE.json's target configuration, the 2-phase / 6-state / 3-control /
+80-node-per-phase polar ascent (``polar_tsto``, C3, n = 1442).  With N > 1 ranks the columns are
+split in contiguous blocks (strong scaling - total work is fixed) and reassembled by one
+RCCL all-gather per step; timing is barrier + synchronize on both
+sides, max over ranks.
+
+Extra objects on the JSON line: ``roofline`` (dominant kernel ``ogk_sweep<true>`` against the
+HBM roofline, algorithmic bytes 8*[(n+1)n + m n + sum N_i^2] per launch, duration from HIP
+events on the launch stream) and ``cpu_baseline`` (the NumPy restatement of the reference path,
+``oracle/np_path.py``, timed on this host for ~10 s; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(name, seconds=10.0):
+    """Reference-style serial NumPy sweep (oracle as the *checker-side* baseline, never the
+    measured product)."""
+    import numpy as np
+    from opengoddard_amd import problems
+    from oracle import np_path
+    prob, obj = problems.build(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    x0 = np.clip(prob.p, lb, ub)
+    n = x0.size
+    np_path.stacked_values(prob, obj, x0)                       # warm
+    evals, sweeps, t0 = 0, 0, time.perf_counter()
+    while True:
+        np_path.sweep(prob, obj, x0)                            # n+1 stacked evaluations
+        sweeps += 1
+        evals += 3 * (n + 1)
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"value": evals / dt, "unit": "callback evals/s", "cores": 1, "kind": "port",
+            "sample": "%d full FD sweeps of %s (n=%d, 3(n+1) callback evaluations each) with the "
+                      "NumPy restatement of the reference path, %.1f s" % (sweeps, name, n, dt),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="polar_tsto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from opengoddard_amd import _native, problems, sharding
+    from opengoddard_amd.engine import HipEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with "
+                         "torch.distributed.run)" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible - the engine has no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    prob, obj = problems.build(a.workload)
+    eng = HipEngine(prob, obj, device=local_rank)
+    n, m = eng.n, eng.m
+    lb = np.array([-np.inf if b[0] is None else b[0] for b in prob.bounds])
+    ub = np.array([np.inf if b[1] is None else b[1] for b in prob.bounds])
+    x0 = np.clip(prob.p, lb, ub)
+    h = _native.fd_step(x0, lb, ub)
+    d_x = torch.from_numpy(x0).to(dev)
+    d_h = torch.from_numpy(h).to(dev)
+    d_F0 = torch.empty(m, dtype=torch.float64, device=dev)
+    lo, hi = sharding.column_range(n, rank, world)
+    rows = sharding.block_rows(n, world)
+    d_local = torch.zeros((rows, m), dtype=torch.float64, device=dev)
+    d_full = torch.empty(sharding.gathered_shape(n, m, world), dtype=torch.float64, device=dev) \
+        if world > 1 else d_local
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.eval_dev(d_x.data_ptr(), d_F0.data_ptr(), stream)
+        eng.columns_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, d_local.data_ptr(),
+                        d_F0.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_full, d_local)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-only duration of the dominant kernel, HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(a.steps)]
+    eng.eval_dev(d_x.data_ptr(), d_F0.data_ptr(), stream)
+    for e0, e1 in ev:
+        e0.record()
+        eng.columns_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, d_local.data_ptr(),
+                        d_F0.data_ptr(), stream)
+        e1.record()
+    torch.cuda.synchronize()
+    kern_ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
+    kern_ms_mean = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+    ncols = hi - lo
+    sumN2 = sum(int(v) ** 2 for v in prob.nodes)
+    alg_bytes = 8.0 * ((ncols + 1) * n + m * ncols + sumN2)
+    achieved = alg_bytes / (kern_ms_mean * 1e-3) / 1e9
+
+    result = {
+        "metric": "NLP-callback evals/sec (cost+constr+FD-Jacobian)",
+        "value": (3 * n + 2) * a.steps / elapsed,
+        "unit": "callback evals/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: %d phases, %s states, %s controls, %s LGL nodes" % (
+            a.workload, len(prob.nodes), prob.number_of_states, prob.number_of_controls, prob.nodes),
+            "n": n, "m_eq": eng.m_eq, "m_ineq": eng.m_ineq,
+            "evals_per_step": 3 * n + 2,
+            "parallelism": "fd-columns x%d%s" % (world, " + RCCL all-gather" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "kernel": "ogk_sweep<true>", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms_mean": kern_ms_mean, "kernel_ms_median": kern_ms},
+    }
+    if world == 1 and rank == 0 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
+        result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,13 @@ int og_fd_sweep_dev(og_handle h, const double* d_x, const double* d_hstep,
                     int32_t col_lo, int32_t col_hi, double* d_JT, double* d_F0,
                     void* hip_stream);
 
+/* Columns only: like og_fd_sweep_dev but d_F0 is an *input* that must already hold F(x)
+ * (from og_eval_dev at the same x).  One kernel launch; this is the unit bench.py times for the
+ * roofline figure. */
+int og_fd_columns_dev(og_handle h, const double* d_x, const double* d_hstep,
+                      int32_t col_lo, int32_t col_hi, double* d_JT, const double* d_F0,
+                      void* hip_stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 const char* og_last_error(void);
 int og_device_count(void);     /* HIP devices visible to the library (0 without a GPU) */

@@ -42,6 +42,8 @@ SIGNATURES = {
     "og_eval_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_fd_sweep_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_fd_columns_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_last_error": (C.c_char_p, []),
     "og_device_count": (C.c_int, []),
 }

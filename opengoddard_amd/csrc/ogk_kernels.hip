@@ -14,7 +14,8 @@
 // ((n+1) x n doubles in the reference's formulation) is never materialised: every read of the
 // decision vector goes through XCol, which returns x0[i] except at i == j.
 //
-// Kernel 1, ogk_defect: one workgroup per (phase, 16-node output tile, 64 FD columns);
+// One kernel, ogk_sweep, with two kinds of workgroup.
+// Collocation workgroups (defect_body): one per (phase, 16-node output tile, 64 FD columns);
 //   each of its 4 wavefronts owns 16 columns and all states of the phase.
 //   - the D-matrix panel for the node tile is staged in LDS in MFMA operand order (ogk.h),
 //     shared by the 4 waves and by all states;
@@ -26,7 +27,7 @@
 //   - the epilogue evaluates the phase's traced dynamics at each (column, node) the lane
 //     holds, forms defect = Y - (tf-t0)/2 * f, and writes the difference quotient straight
 //     into the transposed Jacobian (row-major n x m, SciPy's J_transposed).
-// Kernel 2, ogk_rows: cost, user equality / inequality rows and knot rows; one thread per
+// Row workgroups (rows_body): cost, user equality / inequality rows and knot rows; one thread per
 //   (row item, 8 columns), consecutive lanes = consecutive rows => coalesced J_T stores.
 //
 // Mode 0 (SWEEP = false) is the same code with no perturbation; it writes F(x0), which mode 1
@@ -64,10 +65,10 @@ __device__ __forceinline__ int defect_block_to_group(int bx, int* nt_out) {
 }
 
 template <bool SWEEP>
-__global__ __launch_bounds__(256) void ogk_defect(const ogk_args a) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, const int by,
+                                            double* lds) {
     int nt;
-    const int g = defect_block_to_group((int)blockIdx.x, &nt);
+    const int g = defect_block_to_group(bx, &nt);
     if (g < 0) return;
     const int N = OgGen::G_LEN(g);
     const int KS = (N + 3) >> 2;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void ogk_defect(const ogk_args a) {
 
     const int wave = tid >> 6, lane = tid & 63;
     if (!SWEEP && wave != 0) return;
-    const int c0 = SWEEP ? a.col_lo + ((int)blockIdx.y * 4 + wave) * 16 : 0;
+    const int c0 = SWEEP ? a.col_lo + (by * 4 + wave) * 16 : 0;
     if (SWEEP && c0 >= a.col_hi) return;
 
     // ---- the column this lane feeds into the A operand, and the one operand entry it changes
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(256) void ogk_defect(const ogk_args a) {
 }
 
 template <bool SWEEP>
-__global__ __launch_bounds__(256) void ogk_rows(const ogk_args a) {
-    const int ri = (int)blockIdx.x * 256 + (int)threadIdx.x;
+__device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const int by) {
+    const int ri = bx * 256 + (int)threadIdx.x;
     if (ri >= OgGen::N_ROW_ITEMS) return;
     int g = 0;
     for (; g < OgGen::N_GROUPS; ++g) {
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void ogk_rows(const ogk_args a) {
             if (o < nout) a.f0[OgGen::G_ROW(g, o) + k] = out[o];
         return;
     }
-    const int j0 = a.col_lo + (int)blockIdx.y * ROWS_COLS_PER_THREAD;
+    const int j0 = a.col_lo + by * ROWS_COLS_PER_THREAD;
     for (int c = 0; c < ROWS_COLS_PER_THREAD; ++c) {
         const int j = j0 + c;
         if (j >= a.col_hi) break;
@@ -206,6 +207,21 @@ __global__ __launch_bounds__(256) void ogk_rows(const ogk_args a) {
             const int row = OgGen::G_ROW(g, o) + k;
             jrow[row] = (out[o] - a.f0[row]) / dx;
         }
+    }
+}
+
+// One launch for the whole stacked function: workgroups [0, ndef*ytiles) run the collocation
+// path (heavier, scheduled first), the rest run the row path.
+template <bool SWEEP>
+__global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int ndef,
+                                                 const int defect_total, const int row_blocks) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int id = (int)blockIdx.x;
+    if (id < defect_total) {
+        defect_body<SWEEP>(a, id % ndef, id / ndef, lds);
+    } else {
+        const int rid = id - defect_total;
+        rows_body<SWEEP>(a, rid % row_blocks, rid / row_blocks);
     }
 }
 
@@ -250,20 +266,18 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     const size_t lds = defect_lds_bytes();
     const int row_blocks = (OgGen::N_ROW_ITEMS + 255) / 256;
     if (mode == 0) {
-        if (ndef > 0)
-            hipLaunchKernelGGL(ogk_defect<false>, dim3(ndef, 1), dim3(256), lds, stream, *args);
-        if (row_blocks > 0)
-            hipLaunchKernelGGL(ogk_rows<false>, dim3(row_blocks, 1), dim3(256), 0, stream, *args);
+        const int total = ndef + row_blocks;
+        if (total > 0)
+            hipLaunchKernelGGL(ogk_sweep<false>, dim3(total), dim3(256), lds, stream, *args, ndef,
+                               ndef, row_blocks);
         return (int)hipGetLastError();
     }
     const int ncols = args->col_hi - args->col_lo;
     if (ncols <= 0) return 0;
-    if (ndef > 0)
-        hipLaunchKernelGGL(ogk_defect<true>, dim3(ndef, (ncols + 63) / 64), dim3(256), lds, stream,
-                           *args);
-    if (row_blocks > 0)
-        hipLaunchKernelGGL(ogk_rows<true>,
-                           dim3(row_blocks, (ncols + ROWS_COLS_PER_THREAD - 1) / ROWS_COLS_PER_THREAD),
-                           dim3(256), 0, stream, *args);
+    const int defect_total = ndef * ((ncols + 63) / 64);
+    const int rows_total = row_blocks * ((ncols + ROWS_COLS_PER_THREAD - 1) / ROWS_COLS_PER_THREAD);
+    if (defect_total + rows_total > 0)
+        hipLaunchKernelGGL(ogk_sweep<true>, dim3(defect_total + rows_total), dim3(256), lds, stream,
+                           *args, ndef, defect_total, row_blocks);
     return (int)hipGetLastError();
 }

@@ -291,6 +291,17 @@ int og_fd_sweep_dev(og_handle p, const double* d_x, const double* d_h, int32_t l
     return 0;
 }
 
+int og_fd_columns_dev(og_handle p, const double* d_x, const double* d_h, int32_t lo, int32_t hi,
+                      double* d_JT, const double* d_F0, void* hip_stream) {
+    if (!p || !d_x || !d_h || !d_JT || !d_F0) return fail(1, "og_fd_columns_dev: null argument");
+    if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_fd_columns_dev: bad column range");
+    ogk_args a;
+    fill_args(p, &a, d_x, d_h, const_cast<double*>(d_F0), d_JT, lo, hi);
+    int rc = p->launch(&a, 1, hip_stream);
+    if (rc) return fail(100 + rc, std::string("og_fd_columns_dev: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
 int og_eval(og_handle p, const double* x, double* F) {
     if (!p || !x || !F) return fail(1, "og_eval: null argument");
     OG_HIP(hipSetDevice(p->device));

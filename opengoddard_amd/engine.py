@@ -94,6 +94,11 @@ class HipEngine:
         _native.check(self._lib.og_fd_sweep_dev(self._handle, d_x, d_h, int(col_lo), int(col_hi),
                                                 d_JT, d_F0, stream), "og_fd_sweep_dev")
 
+    def columns_dev(self, d_x, d_h, col_lo, col_hi, d_JT, d_F0, stream=0):
+        """The sweep kernel alone (``d_F0`` must already hold F(x) from :meth:`eval_dev`)."""
+        _native.check(self._lib.og_fd_columns_dev(self._handle, d_x, d_h, int(col_lo), int(col_hi),
+                                                  d_JT, d_F0, stream), "og_fd_columns_dev")
+
     # ------------------------------------------------------------------ SciPy-facing
     def _split(self, F):
         return F[0], F[1:1 + self.m_eq], F[1 + self.m_eq:]

@@ -1,0 +1,142 @@
+"""C-ABI surface (no compute without a GPU), solve() host logic with the oracle engine injected,
+and the fail-loudly contract of the product path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+from opengoddard_amd import _native, build, problems
+from opengoddard_amd import optimize as og
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    with open(os.path.join(ROOT, "include", "ogpsx.h")) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    declared = set(re.findall(r"\b(og_[a-z_0-9]+)\s*\(", text))
+    assert declared, "no declarations parsed"
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    raw = C.CDLL(build.build_core())
+    for name in sorted(declared):
+        assert getattr(raw, name) is not None
+    _native.lib()
+
+
+def test_error_reporting_without_compute():
+    lib = _native.lib()
+    assert lib.og_lgl(2, None, None, None) != 0
+    assert b"N must be >= 3" in lib.og_last_error()
+    handle = C.c_void_p()
+    desc = _native.OgDesc(abi_version=999, device=0, n=1, m_eq=0, m_ineq=0, n_phase=1)
+    assert lib.og_problem_create(C.byref(desc), C.byref(handle)) != 0
+    assert b"ABI" in lib.og_last_error()
+    assert not handle.value
+    lib.og_problem_destroy(None)                 # destroying a null handle is a no-op
+    assert lib.og_device_count() >= 0
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a machine without a GPU")
+def test_product_path_fails_loudly_without_gpu():
+    """No silent CPU fallback: solve() must raise when the HIP engine cannot run."""
+    prob, obj = problems.build("brachistochrone")
+    assert og.ENGINE_FACTORY is None
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        prob.solve(obj)
+
+
+@pytest.fixture
+def oracle_engine():
+    from oracle import np_path
+    og.ENGINE_FACTORY = np_path.NumpyEngine
+    yield
+    og.ENGINE_FACTORY = None
+
+
+def test_solve_host_logic_brachistochrone(oracle_engine, capsys):
+    """Restart loop, jac= plumbing, caching and quirk Q13 with the oracle engine injected:
+    converges to the known answer tf = sqrt(pi) (reference: 1.77245410898455)."""
+    prob, obj = problems.build("brachistochrone")
+    calls = []
+    prob.solve(obj, lambda: calls.append(prob.time_final(-1)))
+    out = capsys.readouterr().out
+    assert "---- iteration : 1 ----" in out and "Optimization terminated successfully" in out
+    assert abs(prob.time_final(-1) - 1.7724541) < 2e-6
+    assert abs(prob.time_final(-1) - np.sqrt(np.pi)) < 1e-5
+    assert len(calls) == prob.iterator + 1 and prob.iterator < prob.maxIterator
+    x = prob.states_all_section(0)
+    assert abs(x[0]) < 1e-8 and abs(x[-1] - 1.0) < 1e-8
+
+
+def test_solve_options_and_q13(oracle_engine, capsys):
+    prob, obj = problems.build("goddard")
+    prob.maxIterator = 2
+    prob.solve(obj, maxiter=2, ftol=1e-10)
+    out = capsys.readouterr().out
+    assert out.count("---- iteration") == 2 and "Iteration limit reached" in out
+    assert prob.iterator == 2
+    # exit mode 9: the last callback was a Jacobian request -> p[-1] carries the FD step (Q13)
+    frac = prob.p[-1]
+    assert isinstance(prob.p, np.ndarray) and np.isfinite(frac)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("tag,script", [
+    ("ex01", "01_Brachistochrone_Problem.py"), ("ex04", "04_Goddard_0knot.py"),
+    ("ex05", "05_Goddard_1knot.py"), ("ex08", "08_Rocket_Ascent_Polar_SSTO.py"),
+    ("ex09", "09_Rocket_Ascent_Polar_TSTO.py"), ("ex10", "10_Low_Thrust_Orbit_Transfer.py")])
+def test_shipped_example_scripts_run_unmodified(tag, script, golden, lgl_golden, oracle_engine,
+                                                monkeypatch, tmp_path):
+    """API conformance (build container only): the reference's example script, executed
+    against THIS package's ``OpenGoddard`` import path, must hand SciPy callables whose values
+    and Jacobians equal the goldens captured from the reference itself - bit for bit once the
+    reference's LGL data is injected.  Also checks that the script's callbacks trace."""
+    import runpy
+    import sys
+    from scipy import optimize as sciopt
+    from conftest import inject_reference_lgl
+    from opengoddard_amd import codegen
+    from oracle import np_path, program_eval
+    os.environ["MPLBACKEND"] = "Agg"
+    sys.dont_write_bytecode = True
+    got = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_minimize(fun, x0, args=(), bounds=None, constraints=(), jac=None, **kw):
+        got.update(fun=fun, x0=np.array(x0), args=args, bounds=bounds, constraints=constraints,
+                   jac=jac)
+        raise Stop()
+
+    monkeypatch.setattr(sciopt, "minimize", fake_minimize)
+    monkeypatch.chdir(tmp_path)
+    assert sys.modules.get("OpenGoddard.optimize") is None or \
+        sys.modules["OpenGoddard.optimize"].__file__.startswith(ROOT)
+    with pytest.raises(Stop):
+        runpy.run_path(os.path.join("/root/reference/examples", script), run_name="__conformance__")
+    G = golden(tag)
+    prob, obj = got["args"]
+    assert type(prob).__module__ == "opengoddard_amd.optimize"
+    lb, ub = np_path.bounds_arrays(prob)
+    assert np.array_equal(lb, G["lb"]) and np.array_equal(ub, G["ub"])
+    assert np.max(np.abs(np.clip(got["x0"], lb, ub) - G["x"][0])) <= 1e-13
+    inject_reference_lgl(prob, lgl_golden)
+    prob._engine.m_eq = None
+    m_eq = int(G["m_eq"])
+    for k in range(G["x"].shape[0]):
+        x, Fg = G["x"][k], G["F"][k]
+        vals = [got["fun"](x, *got["args"]), got["constraints"][0]["fun"](x, *got["args"]),
+                got["constraints"][1]["fun"](x, *got["args"])]
+        assert np.array_equal(np.concatenate([np.atleast_1d(v) for v in vals]), Fg)
+    if G["cols"].size == G["x"].shape[1]:                   # full Jacobians stored
+        x = G["x"][0]
+        Jeq = got["constraints"][0]["jac"](x, *got["args"])
+        Jin = got["constraints"][1]["jac"](x, *got["args"])
+        assert np.array_equal(Jeq, G["JT"][0].T[1:1 + m_eq])
+        assert np.array_equal(Jin, G["JT"][0].T[1 + m_eq:])
+    # and the unmodified callbacks are traceable into device code
+    P = codegen.trace_problem(prob, obj)
+    assert np.array_equal(program_eval.evaluate(P, prob, G["x"][1]), G["F"][1])
+    assert "struct OgGen" in codegen.emit_header(P)

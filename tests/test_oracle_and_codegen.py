@@ -1,0 +1,196 @@
+"""The oracle chain on CPU (no GPU needed):
+
+reference goldens  ==bitwise==  NumPy restatement (oracle/np_path.py, reference LGL injected)
+NumPy restatement  ==bitwise==  traced + lowered program (oracle/program_eval.py)
+reference goldens  ~= noise ~=  C++ twin of the generated device code (oracle/twin.cpp)
+
+plus the FD step rule in all three places (SciPy-made goldens, oracle, og_fd_step).
+"""
+import numpy as np
+import pytest
+
+from conftest import fd_noise_bound, inject_reference_lgl
+from opengoddard_amd import _native, codegen, problems
+from opengoddard_amd import trace as tr
+from oracle import np_path, program_eval, twin
+
+ALL = problems.NAMES
+SHIPPED_TWINS = {"ex01": "cfg_brachistochrone", "ex04": "cfg_goddard",
+                 "ex09": "cfg_polar_tsto_shipped", "ex10": "cfg_low_thrust_shipped"}
+
+
+@pytest.mark.parametrize("ex,cfg", sorted(SHIPPED_TWINS.items()))
+def test_reauthored_problems_equal_the_shipped_examples(ex, cfg, golden):
+    """cfg_* (this repo's problem definitions run by the reference engine) and ex_* (the
+    reference's own example scripts) were captured independently; they must be identical."""
+    A, B = golden(ex), golden(cfg)
+    for key in ("x", "F", "h", "JT", "lb", "ub", "cols"):
+        assert np.array_equal(A[key], B[key]), key
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_numpy_oracle_reproduces_reference_bitwise(name, golden, lgl_golden):
+    G = golden("cfg_" + name)
+    prob, obj = problems.build(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    assert np.array_equal(lb, G["lb"]) and np.array_equal(ub, G["ub"])
+    # initial guess: only tau differs (<= 1.2e-16) between og_lgl and the reference
+    assert np.max(np.abs(np.clip(prob.p, lb, ub) - G["x"][0])) <= 1e-13
+    inject_reference_lgl(prob, lgl_golden)
+    ncheck = 12 if prob.number_of_variables > 1000 else 40
+    for k in range(G["x"].shape[0]):
+        x = G["x"][k]
+        assert np.array_equal(np_path.stacked_values(prob, obj, x), G["F"][k])
+        assert np.array_equal(np_path.fd_step(x, lb, ub), G["h"][k])
+        assert np.array_equal(_native.fd_step(x, lb, ub), G["h"][k])
+    cols = [int(c) for c in G["cols"][:ncheck]]
+    _, _, JT = np_path.sweep(prob, obj, G["x"][0], columns=cols)
+    assert np.array_equal(JT, G["JT"][0][:ncheck])
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_traced_program_equals_numpy_oracle_bitwise(name, golden):
+    G = golden("cfg_" + name)
+    prob, obj = problems.build(name)
+    P = codegen.trace_problem(prob, obj)
+    assert (P.n, P.m_eq, P.m_ineq) == (G["x"].shape[1], int(G["m_eq"]), int(G["m_ineq"]))
+    covered = np.zeros(P.m, dtype=int)
+    for row, ln, _, _ in P.pieces:
+        covered[row:row + ln] += 1
+    assert np.all(covered == 1)                                 # every row exactly once
+    for k in range(G["x"].shape[0]):
+        x = G["x"][k]
+        assert np.array_equal(program_eval.evaluate(P, prob, x),
+                              np_path.stacked_values(prob, obj, x))
+    header = codegen.emit_header(P)
+    assert codegen.emit_header(codegen.trace_problem(prob, obj)) == header   # deterministic
+
+
+def _row_scales(P, prob, x, F):
+    scale = np.maximum(1.0, np.abs(F))
+    for g in P.groups:
+        if g.kind != "defect":
+            continue
+        D = np.abs(prob.D[g.phase])
+        for (row, _), slot in zip(g.outputs, g.mv_slots):
+            leaf = P.mv[slot].leaf_base
+            scale[row:row + g.length] = np.maximum(scale[row:row + g.length],
+                                                   D.dot(np.abs(x[leaf:leaf + g.length])))
+    return scale
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_cpu_twin_against_reference_goldens(name, golden, lgl_golden):
+    """Generated device code compiled for the host: residual within 1e-9 of the row's term
+    magnitude, FD Jacobian within the noise bound, structural zeros identical."""
+    G = golden("cfg_" + name)
+    prob, obj = problems.build(name)
+    inject_reference_lgl(prob, lgl_golden)
+    tw = twin.Twin(prob, obj)
+    ncheck = 16 if tw.n > 1000 else 64
+    cols = G["cols"][:ncheck]
+    m_eq = tw.m_eq
+    for k in range(G["x"].shape[0]):
+        x, Fg, h = G["x"][k], G["F"][k], G["h"][k]
+        F = tw.values(x)
+        scale = _row_scales(tw.program, prob, x, Fg)
+        assert np.all(np.abs(F - Fg) <= 1e-9 * scale)
+        if name in ("goddard", "brachistochrone", "polar_tsto_shipped", "polar_tsto",
+                    "low_thrust_shipped", "low_thrust"):
+            # inequality rows of these problems are + - * / sqrt only: identical rounding
+            assert np.array_equal(F[1 + m_eq:], Fg[1 + m_eq:])
+        F0, JT = tw.sweep(x, h, cols)
+        JTg = G["JT"][k][:ncheck]
+        assert np.all(np.abs(JT - JTg) <= fd_noise_bound(JTg, scale, h[cols]))
+        assert np.array_equal(JT == 0.0, JTg == 0.0)
+
+
+def test_fd_step_rule_on_adversarial_bounds():
+    rng = np.random.default_rng(7)
+    n = 400
+    x = rng.standard_normal(n) * 10.0 ** rng.integers(-12, 12, n)
+    lb = np.full(n, -np.inf)
+    ub = np.full(n, np.inf)
+    idx = rng.permutation(n)
+    lb[idx[:80]] = x[idx[:80]]                               # sitting on the lower bound
+    ub[idx[80:160]] = x[idx[80:160]]                         # sitting on the upper bound
+    lb[idx[160:200]] = x[idx[160:200]] - 1e-9                # tighter than the step on both sides
+    ub[idx[160:200]] = x[idx[160:200]] + 5e-9
+    ub[idx[200:240]] = x[idx[200:240]] + 1e-9
+    lb[idx[200:240]] = x[idx[200:240]] - 5e-9
+    x[idx[240:250]] = 0.0
+    x[idx[250:260]] = 1e20                                   # x + h == x: zero-step fallback
+    x[idx[260:270]] = -1e20
+    h1 = np_path.fd_step(x, lb, ub)
+    h2 = _native.fd_step(x, lb, ub)
+    assert np.array_equal(h1, h2)
+    assert np.all((x + h1 >= lb) & (x + h1 <= ub))
+    try:                                                      # SciPy's own, when importable
+        from scipy.optimize._numdiff import _adjust_scheme_to_bounds
+    except Exception:
+        return
+    h0 = np.full(n, np_path.ABS_STEP)
+    sign = (x >= 0).astype(float) * 2 - 1
+    h0 = np.where((x + h0) - x == 0, np_path.ABS_STEP * sign * np.maximum(1.0, np.abs(x)), h0)
+    hs, _ = _adjust_scheme_to_bounds(x, h0, 1, "1-sided", lb, ub)
+    assert np.array_equal(h1, hs)
+    free_lo, free_hi = np.full(n, -np.inf), np.full(n, np.inf)          # the unbounded fast path
+    assert np.array_equal(np_path.fd_step(x, free_lo, free_hi), _native.fd_step(x, free_lo, free_hi))
+
+
+# ------------------------------------------------------------------------------ tracer units
+def _trace_eval(fn, n=12, seed=0):
+    """Run ``fn`` on a Sym vector and on the same NumPy vector; compare through program_eval."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0.5, 2.0, n)
+    p = tr.new_decision_vector(n)
+    sym = fn(p)
+    P = codegen.Program()
+    P.n, P.nodes = n, []
+    low = codegen._Lowerer(p.g, P)
+    out = []
+    ev = program_eval._Eval(P, x, [])
+    for ln, e in low.pieces(sym.id):
+        ln = 1 if ln is None else ln
+        out.append(np.broadcast_to(ev.elem(e, ln, {}), (ln,)))
+    return np.concatenate(out), np.atleast_1d(fn(x))
+
+
+@pytest.mark.parametrize("fn", [
+    lambda p: p[2:7] * 3.0 - p[0],
+    lambda p: np.hstack((p[0:3], p[-1], 2.5, p[5:7] / p[7:9])),
+    lambda p: np.sqrt(p[0:4] ** 2 + p[4:8] ** 2) / np.exp(-p[8:12]),
+    lambda p: np.sin(p[0:6]) * np.cos(p[6:12]) + np.tan(p[0:6] * 0.1),
+    lambda p: np.concatenate([p[0:3], p[6:9]])[1:5] ** 0.5,
+    lambda p: np.concatenate([p[0:3] * 2, p[6:9] * 3])[-2] - np.log(p[3]),
+    lambda p: np.maximum(p[0:4], 1.2) + np.minimum(p[4:8], 1.1) - abs(-p[8:12]),
+    lambda p: np.where(p[0:5] > 1.0, p[5:10], -p[0:5]),
+    lambda p: (1 / p[0:4] ** 2 + p[4:8] ** -1) * np.deg2rad(30.0),
+    lambda p: np.append(p[0:2] - 1, p[10] * p[11]),
+])
+def test_tracer_matches_numpy_on_small_expressions(fn):
+    got, want = _trace_eval(fn)
+    assert np.array_equal(got, want)
+
+
+def test_tracer_masked_assignment_and_copy_semantics():
+    def fn(p):
+        h = p[0:6] - 1.0
+        h[h < 0.0] = 0.25                     # in place on a temporary (reference ex. 09:36)
+        return h * 2.0
+    got, want = _trace_eval(fn)
+    assert np.array_equal(got, want)
+
+
+def test_tracer_rejects_untraceable_callbacks():
+    p = tr.new_decision_vector(8)
+    with pytest.raises(tr.TraceError):
+        bool(p[0] > 1.0)                       # Python control flow on a decision variable
+    with pytest.raises(tr.TraceError):
+        p[0:4] ** 3.0                          # libm pow has no bit-reproducible device twin
+    with pytest.raises(tr.TraceError):
+        np.arctan2(p[0:2], p[2:4])
+    with pytest.raises(tr.TraceError):
+        np.sum(p[0:4])
+    with pytest.raises(tr.TraceError):
+        float(p[0])

@@ -85,9 +85,14 @@ int og_fd_sweep_dev(og_handle h, const double* d_x, const double* d_hstep,
                     int32_t col_lo, int32_t col_hi, double* d_JT, double* d_F0,
                     void* hip_stream);
 
-/* Columns only: like og_fd_sweep_dev but d_F0 is an *input* that must already hold F(x)
- * (from og_eval_dev at the same x).  One kernel launch; this is the unit bench.py times for the
- * roofline figure. */
+/* Columns only: like og_fd_sweep_dev but d_F0 is an *input* that must already hold F(x) from
+ * the most recent og_eval_dev on this handle at the same x (that call also refreshes the
+ * handle's sweep scratch).  One kernel launch; this is the unit bench.py times for the
+ * roofline figure.
+ *
+ * Environment: OGPSX_SWEEP=dense (read when a handle is created) selects the literal dense
+ * sweep - every row re-evaluated for every column - instead of the default structured sweep
+ * that only re-evaluates rows reading the perturbed variable.  Results are identical. */
 int og_fd_columns_dev(og_handle h, const double* d_x, const double* d_hstep,
                       int32_t col_lo, int32_t col_hi, double* d_JT, const double* d_F0,
                       void* hip_stream);

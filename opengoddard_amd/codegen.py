@@ -57,6 +57,8 @@ class Group:
         self.phase = phase
         self.outputs = []             # [(row_start, eid)]
         self.mv_slots = []            # slot ids feeding y[] (defect groups)
+        self.tails = []               # defect groups: output s = Y_s - tails[s]
+        self.deps = []                # [(kind, base, count)] decision-vector dependencies
 
 
 class Program:
@@ -391,6 +393,66 @@ def _make_groups(P):
             if len(grp.mv_slots) > 16:
                 raise _tr.TraceError("more than 16 states per phase are not supported")
     P.groups = order
+    for grp in order:
+        if grp.kind == "defect":
+            _split_defect_outputs(P, grp)
+        grp.deps = _group_dependencies(P, grp)
+
+
+def _split_defect_outputs(P, grp):
+    """Defect rows must have the shape  Y_s[k] - T_s[k]  with T_s free of collocation products
+    (that is what ``Problem._assemble_equality`` produces); the structured sweep re-evaluates
+    T only where it depends on the perturbed variable."""
+    eg = P.eg
+    if len(grp.outputs) != len(grp.mv_slots):
+        raise _tr.TraceError("defect group: one collocation product per state expected")
+    for s, (_, e) in enumerate(grp.outputs):
+        node = eg.nodes[e]
+        ok = node[0] == "bin" and node[1] == "sub"
+        if ok:
+            y = eg.nodes[node[2]]
+            ok = y[0] == "Y" and y[1] == grp.mv_slots[s] and y[2] == 0 and y[3] == 1 and \
+                not _leaves(eg, node[3], ("Y",))
+        if not ok:
+            raise _tr.TraceError("defect row is not of the form  D x - (tf-t0)/2 f")
+        grp.tails.append(node[3])
+
+
+def _group_dependencies(P, grp):
+    """Which decision variables an element k of the group reads.
+    kind 1: p[base + k]            (one column per element, ``count`` = group length)
+    kind 0: p[base]                (one column, every element)
+    kind 2: p[base .. base+count)  read inside a sum  (each column, every element)"""
+    eg = P.eg
+    roots = grp.tails if grp.kind == "defect" else [e for _, e in grp.outputs]
+    deps = set()
+    stack, seen = [(r, None) for r in roots], set()
+    while stack:
+        e, span = stack.pop()
+        if (e, span) in seen:
+            continue
+        seen.add((e, span))
+        node = eg.nodes[e]
+        tag = node[0]
+        if tag == "P":
+            if node[2] == 0:
+                deps.add((0, node[1], 1))
+            elif span is None:
+                deps.add((1, node[1], grp.length))
+            else:
+                deps.add((2, node[1], span))
+        elif tag == "un":
+            stack.append((node[2], span))
+        elif tag in ("bin", "cmp", "logic"):
+            stack.append((node[2], span))
+            stack.append((node[3], span))
+        elif tag == "where":
+            for c in node[1:]:
+                stack.append((c, span))
+        elif tag == "sum":
+            for ln, body in node[1]:
+                stack.append((body, ln))
+    return sorted(deps)
 
 
 # ------------------------------------------------------------------------------ C++ emission
@@ -526,14 +588,32 @@ class _Emitter:
             names[e] = name
 
     def group_function(self, gi, grp):
+        if grp.kind == "defect":
+            # T_s = (tf-t0)/2 * f_s at node k; the defect is  y[s] - T_s
+            lines = ["    template <class X> OG_HD static void tail%d(const int k, const X& x, "
+                     "const double* cv, double* T) {" % gi,
+                     "        (void)k; (void)cv;"]
+            names = {}
+            self._emit_sums(grp.tails, lines, names, 8)
+            self._emit_expr(grp.tails, "k", lines, names, 8, {})
+            for s, e in enumerate(grp.tails):
+                lines.append("        T[%d] = %s;" % (s, names[e]))
+            lines += ["    }",
+                      "    template <class X> OG_HD static void group%d(const int k, const X& x, "
+                      "const double* y, const double* cv, double* out) {" % gi,
+                      "        double T[%d];" % len(grp.tails),
+                      "        tail%d(k, x, cv, T);" % gi]
+            for s in range(len(grp.tails)):
+                lines.append("        out[%d] = y[%d] - T[%d];" % (s, s, s))
+            lines.append("    }")
+            return lines
         lines = ["    template <class X> OG_HD static void group%d(const int k, const X& x, "
                  "const double* y, const double* cv, double* out) {" % gi,
                  "        (void)k; (void)y; (void)cv;"]
         names = {}
         roots = [e for _, e in grp.outputs]
-        ymap = {s: i for i, s in enumerate(grp.mv_slots)}
         self._emit_sums(roots, lines, names, 8)
-        self._emit_expr(roots, "k", lines, names, 8, ymap)
+        self._emit_expr(roots, "k", lines, names, 8, {})
         for o, (_, e) in enumerate(grp.outputs):
             lines.append("        out[%d] = %s;" % (o, names[e]))
         lines.append("    }")
@@ -608,12 +688,41 @@ def emit_header(P):
         if g.kind == "rows":
             at += g.length
     L.append(_int_table("G_ITEM0", starts))
+    # dependency table (group-major) and per-group ranges into it
+    dep_g, dep_kind, dep_base, dep_cnt, g_dep0, g_ndep = [], [], [], [], [], []
+    for gi, g in enumerate(P.groups):
+        g_dep0.append(len(dep_g))
+        g_ndep.append(len(g.deps))
+        for kind, base, cnt in g.deps:
+            dep_g.append(gi), dep_kind.append(kind), dep_base.append(base), dep_cnt.append(cnt)
+    L.append("    static constexpr int N_DEP = %d;" % len(dep_g))
+    L += [_int_table("DEP_G", dep_g), _int_table("DEP_KIND", dep_kind),
+          _int_table("DEP_BASE", dep_base), _int_table("DEP_CNT", dep_cnt),
+          _int_table("G_DEP0", g_dep0), _int_table("G_NDEP", g_ndep)]
+    # collocation slots: owning group, offset of their base product in the y0 scratch
+    slot_group = [0] * len(P.mv)
+    for gi, g in enumerate(P.groups):
+        for sl in g.mv_slots:
+            slot_group[sl] = gi
+    y0_off, at = [], 0
+    for sl in P.mv:
+        y0_off.append(at)
+        at += sl.length
+    L += [_int_table("MV_GROUP", slot_group), _int_table("MV_Y0", y0_off),
+          "    static constexpr int N_Y0 = %d;" % max(at, 1)]
     L.append("")
     for gi, g in enumerate(P.groups):
         L += em.group_function(gi, g)
         L.append("")
     L += em.operand_function()
     L.append("")
+    L.append("    template <class X> OG_HD static void defect_tail(const int g, const int k, "
+             "const X& x, const double* cv, double* T) {")
+    L.append("        switch (g) {")
+    for gi, g in enumerate(P.groups):
+        if g.kind == "defect":
+            L.append("        case %d: tail%d(k, x, cv, T); break;" % (gi, gi))
+    L += ["        default: break;", "        }", "    }", ""]
     L.append("    template <class X> OG_HD static void group_eval(const int g, const int k, "
              "const X& x, const double* y, const double* cv, double* out) {")
     L.append("        switch (g) {")

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define OGK_ABI 2
+#define OGK_ABI 3
 #define OGK_MAX_PHASE 32
 
 // MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
@@ -28,6 +28,7 @@ typedef struct ogk_info {
     int32_t abi;
     int32_t n, m, m_eq, m_ineq;
     int32_t n_phase, n_mv, n_groups, n_cvec;
+    int32_t n_y0;           // doubles of scratch for the unperturbed collocation products
     int32_t phase_nodes[OGK_MAX_PHASE];
 } ogk_info;
 
@@ -36,7 +37,10 @@ typedef struct ogk_args {
     const double* h;        // [n] signed FD steps (device; unused for a plain evaluation)
     const double* dfrag;    // packed D fragments of all phases (device)
     const double* cvec;     // constant table (device, may be NULL when n_cvec == 0)
-    double* f0;             // [m] F(x0): written by mode 0, read by mode 1
+    double* f0;             // [m] F(x0): written by mode 0, read by modes 1 and 2
+    double* y0;             // [n_y0] base collocation products   (written by mode 0)
+    double* t0;             // [m] base dynamics terms of defect rows (written by mode 0)
+    double* z;              // [m] F0 - F0: 0, or NaN for non-finite rows (written by mode 0)
     double* jt;             // [(col_hi-col_lo) * m] transposed Jacobian rows (mode 1)
     int32_t col_lo, col_hi; // FD columns handled by this launch
     int64_t dfrag_off[OGK_MAX_PHASE];
@@ -47,7 +51,8 @@ extern "C" {
 #endif
 // exported by every callback module
 int ogk_get_info(ogk_info* out);
-// mode 0: evaluate F(x0) into f0.  mode 1: FD sweep over [col_lo, col_hi) into jt (needs f0).
+// mode 0: evaluate F(x0) into f0 (+ scratch y0/t0/z).  mode 1: structured FD sweep over
+// [col_lo, col_hi) into jt (needs mode 0's outputs at the same x0).  mode 2: dense FD sweep.
 // Only enqueues kernels on `stream`; returns a hipError_t value (0 = success).
 int ogk_launch(const ogk_args* args, int mode, void* stream);
 #ifdef __cplusplus

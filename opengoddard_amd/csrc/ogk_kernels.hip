@@ -2,8 +2,8 @@
 //
 // Compiled once per problem as  hipcc --offload-arch=gfx950 -ffp-contract=off -DOG_GEN_HEADER=...
 // The generated header only supplies pointwise device functions (OgGen::group_eval,
-// OgGen::mv_operand) and small index tables; everything about parallel decomposition, LDS,
-// MFMA and memory traffic is in this file.
+// OgGen::defect_tail, OgGen::mv_operand) and small index tables; everything about parallel
+// decomposition, LDS, MFMA and memory traffic is in this file.
 //
 // What the kernels replace:
 //   a7  solve.equality_add     OpenGoddard/optimize.py:670-698   collocation defects + user rows
@@ -14,25 +14,28 @@
 // ((n+1) x n doubles in the reference's formulation) is never materialised: every read of the
 // decision vector goes through XCol, which returns x0[i] except at i == j.
 //
-// One kernel, ogk_sweep, with two kinds of workgroup.
-// Collocation workgroups (defect_body): one per (phase, 16-node output tile, 64 FD columns);
-//   each of its 4 wavefronts owns 16 columns and all states of the phase.
-//   - the D-matrix panel for the node tile is staged in LDS in MFMA operand order (ogk.h),
-//     shared by the 4 waves and by all states;
-//   - the unperturbed collocation operands x~_s = (p_s*u)/u are computed once per workgroup
-//     into LDS; a column changes at most one element of one state, patched in registers;
-//   - Y[s][c][k] = sum_l x~_s,c[l] * D[k][l] runs on v_mfma_f64_16x16x4_f64 (A = state
-//     vectors of 16 columns, B = D^T panel), a k-ordered fma chain per output, identical to
-//     the oracle's loop;
-//   - the epilogue evaluates the phase's traced dynamics at each (column, node) the lane
-//     holds, forms defect = Y - (tf-t0)/2 * f, and writes the difference quotient straight
-//     into the transposed Jacobian (row-major n x m, SciPy's J_transposed).
-// Row workgroups (rows_body): cost, user equality / inequality rows and knot rows; one thread per
-//   (row item, 8 columns), consecutive lanes = consecutive rows => coalesced J_T stores.
+// Three launch modes (ogk_launch):
+//   0  ogk_dense<false>  F(x0) -> f0, plus scratch the sweep reuses: the unperturbed collocation
+//                        products y0, the dynamics terms t0 = (tf-t0)/2 f, and z = F0 - F0
+//                        (0, or NaN where a row is not finite: what dense FD would produce).
+//   1  ogk_sweep         structured forward-difference sweep (default).  Dense FD evaluates
+//                        every row for every column although a row changes only when it reads
+//                        the perturbed variable; because base and perturbed values come from
+//                        the same device functions, every other difference quotient is exactly
+//                        (F0-F0)/dx.  This kernel therefore
+//                          - lets one workgroup own one J_T row (= FD column j): it streams z
+//                            into the row, then re-evaluates only the (group, element) items
+//                            whose traced leaves include p[j] (tables DEP_*), and
+//                          - runs the collocation product for the N perturbed vectors of each
+//                            state slice on v_mfma_f64_16x16x4_f64 (A = 16 perturbed state
+//                            vectors, B = D^T panel staged in LDS in operand order), writing
+//                            the dense N x N block d(defect_s)/d(state_s) directly.
+//                        The result is identical to mode 2 (tests compare them and the CPU twin).
+//   2  ogk_dense<true>   the literal dense sweep: all rows for all columns (validation, and the
+//                        shape SURVEY.md section 7.2 describes).
 //
-// Mode 0 (SWEEP = false) is the same code with no perturbation; it writes F(x0), which mode 1
-// subtracts.  Using one code path for base and perturbed values keeps structural zeros of the
-// Jacobian exactly 0.0.
+// The MFMA accumulation is a k-ordered fma chain per output (verified on hardware by
+// tools/gpu_probe.hip), identical to oracle/twin.cpp's loop.
 #include <hip/hip_runtime.h>
 #include "ogk.h"
 #include OG_GEN_HEADER
@@ -52,6 +55,7 @@ struct XCol {
 };
 
 constexpr int ROWS_COLS_PER_THREAD = 8;
+constexpr int MAX_ITEMS = OgGen::N_DEP > 0 ? OgGen::N_DEP : 1;
 
 __device__ __forceinline__ int defect_block_to_group(int bx, int* nt_out) {
     for (int g = 0; g < OgGen::N_GROUPS; ++g) {
@@ -64,6 +68,9 @@ __device__ __forceinline__ int defect_block_to_group(int bx, int* nt_out) {
     return -1;
 }
 
+// ------------------------------------------------------------------------------------------
+// Collocation workgroup of modes 0 and 2: (phase, 16-node tile, 64 FD columns), all states.
+// ------------------------------------------------------------------------------------------
 template <bool SWEEP>
 __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, const int by,
                                             double* lds) {
@@ -76,7 +83,6 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
     const int phase = OgGen::G_PHASE(g);
     const int mv0 = OgGen::G_MV0(g);
     const int nmv = OgGen::G_NMV(g);
-    const int nout = OgGen::G_NOUT(g);
     const int tid = (int)threadIdx.x;
 
     // ---- stage the D panel (MFMA B-operand order) and the base operands in LDS
@@ -132,12 +138,12 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
         }
     }
 
-    // ---- epilogue: dynamics + defect + difference quotient.  C/D layout of the f64 MFMA:
-    //      column (node) = lane & 15, row (FD column) = (lane >> 4) + 4 * reg.
+    // ---- epilogue.  C/D layout of the f64 MFMA: column (node) = lane & 15,
+    //      row (FD column) = (lane >> 4) + 4 * reg.
     const int k = nt * 16 + (lane & 15);
     if (k >= N) return;
     double y[OgGen::MAX_NMV];
-    double out[OgGen::MAX_OUT];
+    double T[OgGen::MAX_NMV];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int c = lk + 4 * reg;
@@ -155,20 +161,25 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
 #pragma unroll
         for (int s = 0; s < OgGen::MAX_NMV; ++s) y[s] = acc[s][reg];
         const XCol xa{a.x0, j, xj};
-        OgGen::group_eval(g, k, xa, y, a.cvec, out);
+        OgGen::defect_tail(g, k, xa, a.cvec, T);
 #pragma unroll
-        for (int o = 0; o < OgGen::MAX_OUT; ++o) {     // static index: keeps out[] in registers
-            if (o >= nout) break;
-            const int row = OgGen::G_ROW(g, o) + k;
+        for (int s = 0; s < OgGen::MAX_NMV; ++s) {     // static index: keeps y/T in registers
+            if (s >= nmv) break;
+            const int row = OgGen::G_ROW(g, s) + k;
+            const double val = y[s] - T[s];
             if (SWEEP) {
-                a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (out[o] - a.f0[row]) / dx;
+                a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - a.f0[row]) / dx;
             } else {
-                a.f0[row] = out[o];
+                a.f0[row] = val;
+                a.z[row] = val - val;
+                a.t0[row] = T[s];
+                a.y0[OgGen::MV_Y0(mv0 + s) + k] = y[s];
             }
         }
     }
 }
 
+// Row workgroup of modes 0 and 2: one thread per (row item, 8 columns).
 template <bool SWEEP>
 __device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const int by) {
     const int ri = bx * 256 + (int)threadIdx.x;
@@ -188,7 +199,11 @@ __device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const
         OgGen::group_eval(g, k, base, nullptr, a.cvec, out);
 #pragma unroll
         for (int o = 0; o < OgGen::MAX_OUT; ++o)
-            if (o < nout) a.f0[OgGen::G_ROW(g, o) + k] = out[o];
+            if (o < nout) {
+                const int row = OgGen::G_ROW(g, o) + k;
+                a.f0[row] = out[o];
+                a.z[row] = out[o] - out[o];
+            }
         return;
     }
     const int j0 = a.col_lo + by * ROWS_COLS_PER_THREAD;
@@ -210,10 +225,8 @@ __device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const
     }
 }
 
-// One launch for the whole stacked function: workgroups [0, ndef*ytiles) run the collocation
-// path (heavier, scheduled first), the rest run the row path.
 template <bool SWEEP>
-__global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int ndef,
+__global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int ndef,
                                                  const int defect_total, const int row_blocks) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
@@ -222,6 +235,189 @@ __global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int nde
     } else {
         const int rid = id - defect_total;
         rows_body<SWEEP>(a, rid % row_blocks, rid / row_blocks);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mode 1, part A: one workgroup owns FD column j = one row of J_T.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void column_body(const ogk_args& a, const int j, int* lds_i) {
+    const int tid = (int)threadIdx.x;
+    int* item_g = lds_i;
+    int* item_k0 = lds_i + MAX_ITEMS;
+    int* item_off = lds_i + 2 * MAX_ITEMS;       // MAX_ITEMS + 1 entries
+    int* counter = lds_i + 3 * MAX_ITEMS + 1;
+    if (tid == 0) *counter = 0;
+
+    // rows of this J_T row that the MFMA tiles own (j inside a collocated state slice)
+    int own_lo = 0, own_hi = 0;
+    for (int s = 0; s < OgGen::N_MV; ++s) {
+        const int leaf = OgGen::MV_LEAF(s), len = OgGen::MV_LEN(s);
+        if (j >= leaf && j < leaf + len) {
+            const int g = OgGen::MV_GROUP(s);
+            own_lo = OgGen::G_ROW(g, s - OgGen::G_MV0(g));
+            own_hi = own_lo + len;
+        }
+    }
+    __syncthreads();
+
+    // ---- stream z (0, or NaN for non-finite rows) into the row, skipping the owned block
+    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+    for (int r = tid; r < OgGen::M; r += 256)
+        if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
+
+    // ---- which (group, element range) items read p[j]?
+    for (int d = tid; d < OgGen::N_DEP; d += 256) {
+        const int kind = OgGen::DEP_KIND(d), base = OgGen::DEP_BASE(d), cnt = OgGen::DEP_CNT(d);
+        if (j < base || j >= base + cnt) continue;
+        const int slot = atomicAdd(counter, 1);
+        item_g[slot] = OgGen::DEP_G(d);
+        item_k0[slot] = (kind == 1) ? (j - base) : -1;      // -1: every element of the group
+    }
+    __syncthreads();
+    const int nitems = *counter;
+    if (nitems == 0) return;
+    if (tid == 0) {
+        int at = 0;
+        for (int i = 0; i < nitems; ++i) {
+            item_off[i] = at;
+            at += (item_k0[i] >= 0) ? 1 : OgGen::G_LEN(item_g[i]);
+        }
+        item_off[nitems] = at;
+    }
+    __syncthreads();      // also orders the z stores above before the item stores below
+    const int nelem = item_off[nitems];
+
+    const double xb = a.x0[j];
+    const double xj = xb + a.h[j];
+    const double dx = xj - xb;
+    const XCol xa{a.x0, j, xj};
+    double y[OgGen::MAX_NMV];
+    double out[OgGen::MAX_OUT];
+    for (int e = tid; e < nelem; e += 256) {
+        int it = 0;
+        while (e >= item_off[it + 1]) ++it;
+        const int g = item_g[it];
+        const int k = (item_k0[it] >= 0) ? item_k0[it] : (e - item_off[it]);
+        const int nout = OgGen::G_NOUT(g);
+        if (OgGen::G_KIND(g) == 1) {
+            const int mv0 = OgGen::G_MV0(g);
+#pragma unroll
+            for (int s = 0; s < OgGen::MAX_NMV; ++s)
+                y[s] = (s < OgGen::G_NMV(g)) ? a.y0[OgGen::MV_Y0(mv0 + s) + k] : 0.0;
+        }
+        OgGen::group_eval(g, k, xa, y, a.cvec, out);
+#pragma unroll
+        for (int o = 0; o < OgGen::MAX_OUT; ++o) {
+            if (o >= nout) break;
+            const int row = OgGen::G_ROW(g, o) + k;
+            if (row >= own_lo && row < own_hi) continue;        // written by the MFMA tiles
+            jrow[row] = (out[o] - a.f0[row]) / dx;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mode 1, part B: d(defect_s)/d(state_s) for one collocation slot: (64 columns of the slice)
+// x (16-node tile) per workgroup, one 16-column MFMA tile per wavefront.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tile_block_to_slot(int bx, int* mt4_out, int* nt_out) {
+    for (int s = 0; s < OgGen::N_MV; ++s) {
+        const int t16 = (OgGen::MV_LEN(s) + 15) >> 4;
+        const int per = ((t16 + 3) >> 2) * t16;
+        if (bx < per) { *mt4_out = bx / t16; *nt_out = bx % t16; return s; }
+        bx -= per;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, double* lds) {
+    int mt4 = 0, nt = 0;
+    const int slot = tile_block_to_slot(bx, &mt4, &nt);
+    if (slot < 0) return;
+    const int N = OgGen::MV_LEN(slot);
+    const int KS = (N + 3) >> 2;
+    const int g = OgGen::MV_GROUP(slot);
+    const int s_local = slot - OgGen::G_MV0(g);
+    const int leaf = OgGen::MV_LEAF(slot);
+    const int row0 = OgGen::G_ROW(g, s_local);
+    const int tid = (int)threadIdx.x;
+
+    double* dpanel = lds;
+    double* xt = lds + KS * 64;
+    const double* src = a.dfrag + a.dfrag_off[OgGen::MV_PHASE(slot)] + (long)nt * KS * 64;
+    for (int i = tid; i < KS * 64; i += 256) dpanel[i] = src[i];
+    const XCol base{a.x0, -1, 0.0};
+    for (int l = tid; l < KS * 4; l += 256)
+        xt[l] = (l < N) ? OgGen::mv_operand(slot, l, base, a.cvec) : 0.0;
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l0 = (mt4 * 4 + wave) * 16;             // first slice offset of this wave's tile
+    if (l0 >= N) return;
+    const int jlo = leaf + l0;
+    if (jlo >= a.col_hi || jlo + 16 <= a.col_lo) return;   // tile outside this rank's columns
+
+    // A operand: row (lane & 15) is the state vector with its own element perturbed
+    const int la = l0 + (lane & 15);
+    double hit_v = 0.0;
+    if (la < N) {
+        const int ja = leaf + la;
+        const XCol xa{a.x0, ja, a.x0[ja] + a.h[ja]};
+        hit_v = OgGen::mv_operand(slot, la, xa, a.cvec);
+    }
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    const int lk = lane >> 4;
+    for (int ks = 0; ks < KS; ++ks) {
+        const int l = ks * 4 + lk;
+        double av = xt[l];
+        if (l == la) av = hit_v;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, dpanel[ks * 64 + lane], acc, 0, 0, 0);
+    }
+
+    const int k = nt * 16 + (lane & 15);
+    if (k >= N) return;
+    const int row = row0 + k;
+    const double t_base = a.t0[row];
+    const double f_base = a.f0[row];
+    const int dep0 = OgGen::G_DEP0(g), ndep = OgGen::G_NDEP(g);
+    double T[OgGen::MAX_NMV];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int lc = l0 + lk + 4 * reg;
+        const int j = leaf + lc;
+        if (lc >= N || j < a.col_lo || j >= a.col_hi) continue;
+        const double xb = a.x0[j];
+        const double xj = xb + a.h[j];
+        const double dx = xj - xb;
+        // does the dynamics term of node k read p[j]?  (normally only on the diagonal k == lc)
+        bool reads = false;
+        for (int d = dep0; d < dep0 + ndep; ++d) {
+            const int kind = OgGen::DEP_KIND(d), base_d = OgGen::DEP_BASE(d);
+            reads = reads || (kind == 1 ? (base_d + k == j)
+                                        : (j >= base_d && j < base_d + OgGen::DEP_CNT(d)));
+        }
+        double t = t_base;
+        if (reads) {
+            const XCol xa{a.x0, j, xj};
+            OgGen::defect_tail(g, k, xa, a.cvec, T);
+#pragma unroll
+            for (int s = 0; s < OgGen::MAX_NMV; ++s)
+                if (s == s_local) t = T[s];
+        }
+        const double val = acc[reg] - t;
+        a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - f_base) / dx;
+    }
+}
+
+__global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int ncols) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int id = (int)blockIdx.x;
+    if (id < ncols) {
+        // highest columns first: the phase-final-time columns carry the most items
+        column_body(a, a.col_hi - 1 - id, reinterpret_cast<int*>(lds));
+    } else {
+        tile_body(a, id - ncols, lds);
     }
 }
 
@@ -243,6 +439,25 @@ size_t defect_lds_bytes() {
     return worst;
 }
 
+int tile_blocks() {
+    int nb = 0;
+    for (int s = 0; s < OgGen::N_MV; ++s) {
+        const int t16 = (OgGen::MV_LEN(s) + 15) >> 4;
+        nb += ((t16 + 3) >> 2) * t16;
+    }
+    return nb;
+}
+
+size_t sweep_lds_bytes() {
+    size_t worst = (3 * (size_t)MAX_ITEMS + 2) * sizeof(int);
+    for (int s = 0; s < OgGen::N_MV; ++s) {
+        const int KS = (OgGen::MV_LEN(s) + 3) >> 2;
+        const size_t need = ((size_t)KS * 64 + (size_t)KS * 4) * sizeof(double);
+        worst = need > worst ? need : worst;
+    }
+    return worst;
+}
+
 }  // namespace
 
 extern "C" int ogk_get_info(ogk_info* out) {
@@ -255,6 +470,7 @@ extern "C" int ogk_get_info(ogk_info* out) {
     out->n_mv = OgGen::N_MV;
     out->n_groups = OgGen::N_GROUPS;
     out->n_cvec = OgGen::N_CVEC;
+    out->n_y0 = OgGen::N_Y0;
     for (int i = 0; i < OGK_MAX_PHASE; ++i)
         out->phase_nodes[i] = i < OgGen::N_PHASE ? OgGen::PHASE_NODES(i) : 0;
     return 0;
@@ -263,21 +479,25 @@ extern "C" int ogk_get_info(ogk_info* out) {
 extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int ndef = defect_blocks();
-    const size_t lds = defect_lds_bytes();
     const int row_blocks = (OgGen::N_ROW_ITEMS + 255) / 256;
     if (mode == 0) {
         const int total = ndef + row_blocks;
         if (total > 0)
-            hipLaunchKernelGGL(ogk_sweep<false>, dim3(total), dim3(256), lds, stream, *args, ndef,
-                               ndef, row_blocks);
+            hipLaunchKernelGGL(ogk_dense<false>, dim3(total), dim3(256), defect_lds_bytes(), stream,
+                               *args, ndef, ndef, row_blocks);
         return (int)hipGetLastError();
     }
     const int ncols = args->col_hi - args->col_lo;
     if (ncols <= 0) return 0;
+    if (mode == 1) {
+        hipLaunchKernelGGL(ogk_sweep, dim3(ncols + tile_blocks()), dim3(256), sweep_lds_bytes(),
+                           stream, *args, ncols);
+        return (int)hipGetLastError();
+    }
     const int defect_total = ndef * ((ncols + 63) / 64);
     const int rows_total = row_blocks * ((ncols + ROWS_COLS_PER_THREAD - 1) / ROWS_COLS_PER_THREAD);
     if (defect_total + rows_total > 0)
-        hipLaunchKernelGGL(ogk_sweep<true>, dim3(defect_total + rows_total), dim3(256), lds, stream,
-                           *args, ndef, defect_total, row_blocks);
+        hipLaunchKernelGGL(ogk_dense<true>, dim3(defect_total + rows_total), dim3(256),
+                           defect_lds_bytes(), stream, *args, ndef, defect_total, row_blocks);
     return (int)hipGetLastError();
 }

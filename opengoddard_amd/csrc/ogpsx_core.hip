@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -73,6 +74,11 @@ struct og_problem_s {
     double* d_f0 = nullptr;
     double* d_jt = nullptr;
     size_t jt_capacity = 0;
+    // sweep scratch written by every evaluation (ogk.h): base products / dynamics terms / F0-F0
+    double* d_y0 = nullptr;
+    double* d_t0 = nullptr;
+    double* d_z = nullptr;
+    int sweep_mode = 1;                 // 1 structured (default), 2 dense (OGPSX_SWEEP=dense)
     hipStream_t stream = nullptr;
 };
 
@@ -85,6 +91,9 @@ void fill_args(const og_problem_s* p, ogk_args* a, const double* x, const double
     a->dfrag = p->d_dfrag;
     a->cvec = p->d_cvec;
     a->f0 = f0;
+    a->y0 = p->d_y0;
+    a->t0 = p->d_t0;
+    a->z = p->d_z;
     a->jt = jt;
     a->col_lo = lo;
     a->col_hi = hi;
@@ -238,6 +247,11 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMalloc(&p->d_x, sizeof(double) * (size_t)p->n);
     if (e == hipSuccess) e = hipMalloc(&p->d_h, sizeof(double) * (size_t)p->n);
     if (e == hipSuccess) e = hipMalloc(&p->d_f0, sizeof(double) * (size_t)p->m);
+    if (e == hipSuccess) e = hipMalloc(&p->d_y0, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
+    if (e == hipSuccess) e = hipMalloc(&p->d_t0, sizeof(double) * (size_t)p->m);
+    if (e == hipSuccess) e = hipMalloc(&p->d_z, sizeof(double) * (size_t)p->m);
+    const char* mode_env = getenv("OGPSX_SWEEP");
+    if (mode_env && std::string(mode_env) == "dense") p->sweep_mode = 2;
     if (e == hipSuccess) e = hipStreamCreate(&p->stream);
     if (e != hipSuccess) {
         og_problem_destroy(p);
@@ -257,6 +271,9 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_h);
     hipFree(p->d_f0);
     hipFree(p->d_jt);
+    hipFree(p->d_y0);
+    hipFree(p->d_t0);
+    hipFree(p->d_z);
     if (p->module) dlclose(p->module);
     delete p;
 }
@@ -286,7 +303,7 @@ int og_fd_sweep_dev(og_handle p, const double* d_x, const double* d_h, int32_t l
     ogk_args a;
     fill_args(p, &a, d_x, d_h, d_F0, d_JT, lo, hi);
     int rc = p->launch(&a, 0, hip_stream);          // F(x0) first: the sweep subtracts it
-    if (!rc) rc = p->launch(&a, 1, hip_stream);
+    if (!rc) rc = p->launch(&a, p->sweep_mode, hip_stream);
     if (rc) return fail(100 + rc, std::string("og_fd_sweep_dev: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
@@ -297,7 +314,7 @@ int og_fd_columns_dev(og_handle p, const double* d_x, const double* d_h, int32_t
     if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_fd_columns_dev: bad column range");
     ogk_args a;
     fill_args(p, &a, d_x, d_h, const_cast<double*>(d_F0), d_JT, lo, hi);
-    int rc = p->launch(&a, 1, hip_stream);
+    int rc = p->launch(&a, p->sweep_mode, hip_stream);
     if (rc) return fail(100 + rc, std::string("og_fd_columns_dev: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }

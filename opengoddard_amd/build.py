@@ -27,7 +27,7 @@ JITDIR = os.path.join(LIBDIR, "jit")
 CORE_LIB = os.path.join(LIBDIR, "libogpsx.so")
 ARCH = "gfx950"
 HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-             "-Wno-unused-value"]
+             "-Wno-unused-value"] + os.environ.get("OG_EXTRA_HIPFLAGS", "").split()
 
 
 class BuildError(RuntimeError):

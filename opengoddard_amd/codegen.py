@@ -25,7 +25,9 @@ import numpy as np
 
 from . import trace as _tr
 
-MAX_GROUP_OUTPUTS = 8
+import os
+
+MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "8"))
 
 
 # ------------------------------------------------------------------------------ element graph

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define OGK_ABI 3
+#define OGK_ABI 4
 #define OGK_MAX_PHASE 32
 
 // MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
@@ -39,6 +39,7 @@ typedef struct ogk_args {
     const double* cvec;     // constant table (device, may be NULL when n_cvec == 0)
     double* f0;             // [m] F(x0): written by mode 0, read by modes 1 and 2
     double* y0;             // [n_y0] base collocation products   (written by mode 0)
+    double* xop;            // [n_y0] base collocation operands   (written by mode 0)
     double* t0;             // [m] base dynamics terms of defect rows (written by mode 0)
     double* z;              // [m] F0 - F0: 0, or NaN for non-finite rows (written by mode 0)
     double* jt;             // [(col_hi-col_lo) * m] transposed Jacobian rows (mode 1)

@@ -42,6 +42,12 @@
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// Timing experiments only (tools/kstats.sh): -DOGK_EXP=<mask> removes pieces of the kernels so
+// that rocprof durations attribute time to phases.  Results are wrong with any bit set.
+#ifndef OGK_EXP
+#define OGK_EXP 0
+#endif
+
 namespace {
 
 struct XCol {
@@ -85,15 +91,25 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
     const int nmv = OgGen::G_NMV(g);
     const int tid = (int)threadIdx.x;
 
-    // ---- stage the D panel (MFMA B-operand order) and the base operands in LDS
+    // ---- stage the D panel (MFMA B-operand order) and the base operands in LDS.  Operand
+    //      entries are laid out [slot][NP]; each wavefront works on one slot at a time so the
+    //      generated switch in mv_operand never diverges.
     double* dpanel = lds;
     double* xt = lds + KS * 64;
     const double* src = a.dfrag + a.dfrag_off[phase] + (long)nt * KS * 64;
     for (int i = tid; i < KS * 64; i += 256) dpanel[i] = src[i];
     const XCol base{a.x0, -1, 0.0};
-    for (int i = tid; i < nmv * NP; i += 256) {
-        const int s = i / NP, l = i - s * NP;
-        xt[i] = (l < N) ? OgGen::mv_operand(mv0 + s, l, base, a.cvec) : 0.0;
+    {
+        const int wave_ = tid >> 6, lane_ = tid & 63;
+        for (int s = wave_; s < OgGen::MAX_NMV; s += 4)
+            for (int l = lane_; l < NP; l += 64) {
+                double v = 0.0;
+                if (s < nmv && l < N && !(OGK_EXP & 4)) {
+                    v = OgGen::mv_operand(mv0 + s, l, base, a.cvec);
+                    if (!SWEEP && nt == 0) a.xop[OgGen::MV_Y0(mv0 + s) + l] = v;
+                }
+                xt[s * NP + l] = v;
+            }
     }
     __syncthreads();
 
@@ -101,11 +117,55 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
     if (!SWEEP && wave != 0) return;
     const int c0 = SWEEP ? a.col_lo + (by * 4 + wave) * 16 : 0;
     if (SWEEP && c0 >= a.col_hi) return;
+    const int lk = lane >> 4;
+    const int k = nt * 16 + (lane & 15);
+    double y[OgGen::MAX_NMV];
+    double T[OgGen::MAX_NMV];
 
-    // ---- the column this lane feeds into the A operand, and the one operand entry it changes
+    if (!SWEEP) {
+        // ---- single evaluation: the states are the 16 rows of the A operand, so one MFMA chain
+        //      yields every state's collocation product for this node tile.
+        const int srow = lane & 15;
+        v4f64 acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double* xrow = xt + (srow < OgGen::MAX_NMV ? srow : 0) * NP;
+        const bool live = srow < nmv;
+        for (int ks = 0; ks < ((OGK_EXP & 1) ? 0 : KS); ++ks) {
+            const double av = live ? xrow[ks * 4 + lk] : 0.0;
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, dpanel[ks * 64 + lane], acc1, 0, 0, 0);
+        }
+        // C/D layout: node = lane & 15, state = (lane >> 4) + 4 * reg.  Exchange through LDS so
+        // that one lane per node sees all states.
+        // (one wavefront: its LDS stores and loads execute in program order, no barrier needed)
+        double* ybuf = xt + OgGen::MAX_NMV * NP;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) ybuf[(lk + 4 * reg) * 16 + (lane & 15)] = acc1[reg];
+        if (lane >= 16 || k >= N) return;
+#pragma unroll
+        for (int s = 0; s < OgGen::MAX_NMV; ++s) y[s] = ybuf[s * 16 + lane];
+        if (OGK_EXP & 2) {
+#pragma unroll
+            for (int s = 0; s < OgGen::MAX_NMV; ++s) T[s] = 0.0;
+        } else {
+            OgGen::defect_tail(g, k, base, a.cvec, T);
+        }
+#pragma unroll
+        for (int s = 0; s < OgGen::MAX_NMV; ++s) {
+            if (s >= nmv) break;
+            const int row = OgGen::G_ROW(g, s) + k;
+            const double val = y[s] - T[s];
+            a.f0[row] = val;
+            a.z[row] = val - val;
+            a.t0[row] = T[s];
+            a.y0[OgGen::MV_Y0(mv0 + s) + k] = y[s];
+        }
+        return;
+    }
+
+    // ---- dense sweep: the column this lane feeds into the A operand, and the one operand entry
+    //      it changes
     int hit_s = -1, hit_l = -1;
     double hit_v = 0.0;
-    if (SWEEP) {
+    {
         const int ja = c0 + (lane & 15);
         if (ja < a.col_hi) {
             for (int s = 0; s < nmv; ++s) {
@@ -121,60 +181,46 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
     }
 
     // ---- batched D.X on the matrix cores: acc[s] (16 columns x 16 nodes) += A_s (16x4) * B (4x16)
+    //      (branch-free over MAX_NMV: unused slots multiply zeros)
     v4f64 acc[OgGen::MAX_NMV];
 #pragma unroll
     for (int s = 0; s < OgGen::MAX_NMV; ++s) acc[s] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const int lk = lane >> 4;
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < ((OGK_EXP & 1) ? 0 : KS); ++ks) {
         const double b = dpanel[ks * 64 + lane];
         const int l = ks * 4 + lk;
 #pragma unroll
         for (int s = 0; s < OgGen::MAX_NMV; ++s) {
-            if (s < nmv) {
-                double av = xt[s * NP + l];
-                if (s == hit_s && l == hit_l) av = hit_v;
-                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc[s], 0, 0, 0);
-            }
+            double av = xt[s * NP + l];
+            av = (s == hit_s && l == hit_l) ? hit_v : av;
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc[s], 0, 0, 0);
         }
     }
 
     // ---- epilogue.  C/D layout of the f64 MFMA: column (node) = lane & 15,
     //      row (FD column) = (lane >> 4) + 4 * reg.
-    const int k = nt * 16 + (lane & 15);
     if (k >= N) return;
-    double y[OgGen::MAX_NMV];
-    double T[OgGen::MAX_NMV];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        const int c = lk + 4 * reg;
-        int j = -1;
-        double xj = 0.0, dx = 1.0;
-        if (SWEEP) {
-            j = c0 + c;
-            if (j >= a.col_hi) continue;
-            const double xb = a.x0[j];
-            xj = xb + a.h[j];
-            dx = xj - xb;
-        } else if (c != 0) {
-            continue;
-        }
+        const int j = c0 + lk + 4 * reg;
+        if (j >= a.col_hi) continue;
+        const double xb = a.x0[j];
+        const double xj = xb + a.h[j];
+        const double dx = xj - xb;
 #pragma unroll
         for (int s = 0; s < OgGen::MAX_NMV; ++s) y[s] = acc[s][reg];
         const XCol xa{a.x0, j, xj};
-        OgGen::defect_tail(g, k, xa, a.cvec, T);
+        if (OGK_EXP & 2) {
+#pragma unroll
+            for (int s = 0; s < OgGen::MAX_NMV; ++s) T[s] = xj;
+        } else {
+            OgGen::defect_tail(g, k, xa, a.cvec, T);
+        }
 #pragma unroll
         for (int s = 0; s < OgGen::MAX_NMV; ++s) {     // static index: keeps y/T in registers
             if (s >= nmv) break;
             const int row = OgGen::G_ROW(g, s) + k;
             const double val = y[s] - T[s];
-            if (SWEEP) {
-                a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - a.f0[row]) / dx;
-            } else {
-                a.f0[row] = val;
-                a.z[row] = val - val;
-                a.t0[row] = T[s];
-                a.y0[OgGen::MV_Y0(mv0 + s) + k] = y[s];
-            }
+            a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - a.f0[row]) / dx;
         }
     }
 }
@@ -195,6 +241,7 @@ __device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const
     const int nout = OgGen::G_NOUT(g);
     double out[OgGen::MAX_OUT];
     if (!SWEEP) {
+        if (OGK_EXP & 64) return;
         const XCol base{a.x0, -1, 0.0};
         OgGen::group_eval(g, k, base, nullptr, a.cvec, out);
 #pragma unroll
@@ -245,9 +292,7 @@ __device__ __forceinline__ void column_body(const ogk_args& a, const int j, int*
     const int tid = (int)threadIdx.x;
     int* item_g = lds_i;
     int* item_k0 = lds_i + MAX_ITEMS;
-    int* item_off = lds_i + 2 * MAX_ITEMS;       // MAX_ITEMS + 1 entries
-    int* counter = lds_i + 3 * MAX_ITEMS + 1;
-    if (tid == 0) *counter = 0;
+    int* item_off = lds_i + 2 * MAX_ITEMS;       // element count per dependency entry
 
     // rows of this J_T row that the MFMA tiles own (j inside a collocated state slice)
     int own_lo = 0, own_hi = 0;
@@ -259,34 +304,26 @@ __device__ __forceinline__ void column_body(const ogk_args& a, const int j, int*
             own_hi = own_lo + len;
         }
     }
-    __syncthreads();
 
     // ---- stream z (0, or NaN for non-finite rows) into the row, skipping the owned block
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    for (int r = tid; r < OgGen::M; r += 256)
-        if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
+    if (!(OGK_EXP & 16))
+        for (int r = tid; r < OgGen::M; r += 256)
+            if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
 
-    // ---- which (group, element range) items read p[j]?
+    // ---- which (group, element range) items read p[j]?  One dependency entry per thread;
+    //      cnt[d] = number of elements entry d contributes for this column.
     for (int d = tid; d < OgGen::N_DEP; d += 256) {
         const int kind = OgGen::DEP_KIND(d), base = OgGen::DEP_BASE(d), cnt = OgGen::DEP_CNT(d);
-        if (j < base || j >= base + cnt) continue;
-        const int slot = atomicAdd(counter, 1);
-        item_g[slot] = OgGen::DEP_G(d);
-        item_k0[slot] = (kind == 1) ? (j - base) : -1;      // -1: every element of the group
-    }
-    __syncthreads();
-    const int nitems = *counter;
-    if (nitems == 0) return;
-    if (tid == 0) {
-        int at = 0;
-        for (int i = 0; i < nitems; ++i) {
-            item_off[i] = at;
-            at += (item_k0[i] >= 0) ? 1 : OgGen::G_LEN(item_g[i]);
-        }
-        item_off[nitems] = at;
+        const bool hit = j >= base && j < base + cnt;
+        item_g[d] = OgGen::DEP_G(d);
+        item_k0[d] = (kind == 1) ? (j - base) : -1;      // -1: every element of the group
+        item_off[d] = !hit ? 0 : (kind == 1 ? 1 : OgGen::G_LEN(OgGen::DEP_G(d)));
     }
     __syncthreads();      // also orders the z stores above before the item stores below
-    const int nelem = item_off[nitems];
+    int nelem = 0;
+    for (int d = 0; d < OgGen::N_DEP; ++d) nelem += item_off[d];
+    if (nelem == 0) return;
 
     const double xb = a.x0[j];
     const double xj = xb + a.h[j];
@@ -294,11 +331,11 @@ __device__ __forceinline__ void column_body(const ogk_args& a, const int j, int*
     const XCol xa{a.x0, j, xj};
     double y[OgGen::MAX_NMV];
     double out[OgGen::MAX_OUT];
-    for (int e = tid; e < nelem; e += 256) {
-        int it = 0;
-        while (e >= item_off[it + 1]) ++it;
+    for (int e = tid; e < ((OGK_EXP & 8) ? 0 : nelem); e += 256) {
+        int it = 0, before = 0;
+        while (e >= before + item_off[it]) { before += item_off[it]; ++it; }
         const int g = item_g[it];
-        const int k = (item_k0[it] >= 0) ? item_k0[it] : (e - item_off[it]);
+        const int k = (item_k0[it] >= 0) ? item_k0[it] : (e - before);
         const int nout = OgGen::G_NOUT(g);
         if (OgGen::G_KIND(g) == 1) {
             const int mv0 = OgGen::G_MV0(g);
@@ -347,9 +384,8 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     double* xt = lds + KS * 64;
     const double* src = a.dfrag + a.dfrag_off[OgGen::MV_PHASE(slot)] + (long)nt * KS * 64;
     for (int i = tid; i < KS * 64; i += 256) dpanel[i] = src[i];
-    const XCol base{a.x0, -1, 0.0};
-    for (int l = tid; l < KS * 4; l += 256)
-        xt[l] = (l < N) ? OgGen::mv_operand(slot, l, base, a.cvec) : 0.0;
+    const double* xop = a.xop + OgGen::MV_Y0(slot);   // base operands, written by mode 0
+    for (int l = tid; l < KS * 4; l += 256) xt[l] = (l < N) ? xop[l] : 0.0;
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -368,10 +404,22 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     }
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     const int lk = lane >> 4;
-    for (int ks = 0; ks < KS; ++ks) {
+    int ks = 0;
+    for (; ks + 4 <= KS; ks += 4) {          // operands of 4 steps in flight before the MFMAs
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = (ks + u) * 4 + lk;
+            av[u] = (l == la) ? hit_v : xt[l];
+            bv[u] = dpanel[(ks + u) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; ks < KS; ++ks) {
         const int l = ks * 4 + lk;
-        double av = xt[l];
-        if (l == la) av = hit_v;
+        const double av = (l == la) ? hit_v : xt[l];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, dpanel[ks * 64 + lane], acc, 0, 0, 0);
     }
 
@@ -410,14 +458,15 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     }
 }
 
-__global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int ncols) {
+__global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int ntiles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
-    if (id < ncols) {
-        // highest columns first: the phase-final-time columns carry the most items
-        column_body(a, a.col_hi - 1 - id, reinterpret_cast<int*>(lds));
+    if (id < ntiles) {
+        // MFMA tiles have the longest dependent chain: dispatch them first
+        if (!(OGK_EXP & 32)) tile_body(a, id, lds);
     } else {
-        tile_body(a, id - ncols, lds);
+        // then the columns, highest first: the phase-final-time columns carry the most items
+        column_body(a, a.col_hi - 1 - (id - ntiles), reinterpret_cast<int*>(lds));
     }
 }
 
@@ -433,7 +482,7 @@ size_t defect_lds_bytes() {
     for (int g = 0; g < OgGen::N_GROUPS; ++g) {
         if (OgGen::G_KIND(g) != 1) continue;
         const int KS = (OgGen::G_LEN(g) + 3) >> 2;
-        const size_t need = ((size_t)KS * 64 + (size_t)OgGen::G_NMV(g) * KS * 4) * sizeof(double);
+        const size_t need = ((size_t)KS * 64 + (size_t)OgGen::MAX_NMV * KS * 4 + 256) * sizeof(double);
         worst = need > worst ? need : worst;
     }
     return worst;
@@ -490,8 +539,9 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     const int ncols = args->col_hi - args->col_lo;
     if (ncols <= 0) return 0;
     if (mode == 1) {
-        hipLaunchKernelGGL(ogk_sweep, dim3(ncols + tile_blocks()), dim3(256), sweep_lds_bytes(),
-                           stream, *args, ncols);
+        const int ntiles = tile_blocks();
+        hipLaunchKernelGGL(ogk_sweep, dim3(ncols + ntiles), dim3(256), sweep_lds_bytes(), stream,
+                           *args, ntiles);
         return (int)hipGetLastError();
     }
     const int defect_total = ndef * ((ncols + 63) / 64);

@@ -76,6 +76,7 @@ struct og_problem_s {
     size_t jt_capacity = 0;
     // sweep scratch written by every evaluation (ogk.h): base products / dynamics terms / F0-F0
     double* d_y0 = nullptr;
+    double* d_xop = nullptr;
     double* d_t0 = nullptr;
     double* d_z = nullptr;
     int sweep_mode = 1;                 // 1 structured (default), 2 dense (OGPSX_SWEEP=dense)
@@ -92,6 +93,7 @@ void fill_args(const og_problem_s* p, ogk_args* a, const double* x, const double
     a->cvec = p->d_cvec;
     a->f0 = f0;
     a->y0 = p->d_y0;
+    a->xop = p->d_xop;
     a->t0 = p->d_t0;
     a->z = p->d_z;
     a->jt = jt;
@@ -248,6 +250,7 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMalloc(&p->d_h, sizeof(double) * (size_t)p->n);
     if (e == hipSuccess) e = hipMalloc(&p->d_f0, sizeof(double) * (size_t)p->m);
     if (e == hipSuccess) e = hipMalloc(&p->d_y0, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
+    if (e == hipSuccess) e = hipMalloc(&p->d_xop, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_t0, sizeof(double) * (size_t)p->m);
     if (e == hipSuccess) e = hipMalloc(&p->d_z, sizeof(double) * (size_t)p->m);
     const char* mode_env = getenv("OGPSX_SWEEP");
@@ -272,6 +275,7 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_f0);
     hipFree(p->d_jt);
     hipFree(p->d_y0);
+    hipFree(p->d_xop);
     hipFree(p->d_t0);
     hipFree(p->d_z);
     if (p->module) dlclose(p->module);

@@ -67,7 +67,63 @@ __global__ void copy_kernel(const double4* s, double4* d, size_t n) {
     for (; i < n; i += stride) d[i] = s[i];
 }
 
+// MFMA / VALU f64 rate probes: NACC independent accumulator chains per wave, ITER steps.
+template <int NACC>
+__global__ void mfma_rate(double* out, int iters, double a0, double b0) {
+    v4f64 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double a = a0 + threadIdx.x * 1e-9, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NACC>
+__global__ void fma_rate(double* out, int iters, double a0, double b0) {
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = i;
+    double a = a0 + threadIdx.x * 1e-9, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_fma(a, b, acc[i]);
+    }
+    double s = 0.0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void div_rate(double* out, int iters, double a0) {
+    double acc = a0 + threadIdx.x;
+    for (int it = 0; it < iters; ++it) acc = 1.0 + 1.0 / acc;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 static double urand() { return (double)rand() / RAND_MAX; }
+
+template <class F>
+static float time_ms(F launch, int reps = 5) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    launch();
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(e0);
+        launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    return best;
+}
 
 int main() {
     int ndev = 0;
@@ -152,6 +208,33 @@ int main() {
             bad += diff;
         }
         hipFree(dx), hipFree(dy), hipFree(dout);
+    }
+
+    // ---- 2b. f64 MFMA / FMA / division rates (one wave, then the whole chip)
+    {
+        double* dout;
+        CK(hipMalloc(&dout, sizeof(double) * 256 * 1024 * 16));
+        const int iters = 20000;
+        float t1 = time_ms([&] { hipLaunchKernelGGL(mfma_rate<1>, dim3(1), dim3(64), 0, 0, dout, iters, 1.0, 1e-9); });
+        float t4 = time_ms([&] { hipLaunchKernelGGL(mfma_rate<4>, dim3(1), dim3(64), 0, 0, dout, iters, 1.0, 1e-9); });
+        float t8 = time_ms([&] { hipLaunchKernelGGL(mfma_rate<8>, dim3(1), dim3(64), 0, 0, dout, iters, 1.0, 1e-9); });
+        printf("mfma_f64_16x16x4, one wave: dependent chain %.1f ns/MFMA; 4 chains %.1f ns/MFMA; 8 chains %.1f ns/MFMA\n",
+               t1 * 1e6 / iters, t4 * 1e6 / (4.0 * iters), t8 * 1e6 / (8.0 * iters));
+        float tc = time_ms([&] { hipLaunchKernelGGL(mfma_rate<4>, dim3(256 * 4), dim3(256), 0, 0, dout, iters, 1.0, 1e-9); });
+        printf("mfma_f64_16x16x4, 1024 blocks x 4 waves: %.2f TFLOP/s\n",
+               1024.0 * 4 * 4 * iters * 2048.0 / (tc * 1e-3) / 1e12);
+        float f1 = time_ms([&] { hipLaunchKernelGGL(fma_rate<1>, dim3(1), dim3(64), 0, 0, dout, iters * 8, 1.0, 1e-9); });
+        float f8 = time_ms([&] { hipLaunchKernelGGL(fma_rate<8>, dim3(1), dim3(64), 0, 0, dout, iters * 8, 1.0, 1e-9); });
+        printf("v_fma_f64, one wave: dependent chain %.2f ns/FMA; 8 chains %.2f ns/FMA\n",
+               f1 * 1e6 / (iters * 8.0), f8 * 1e6 / (iters * 64.0));
+        float fc = time_ms([&] { hipLaunchKernelGGL(fma_rate<8>, dim3(256 * 8), dim3(256), 0, 0, dout, iters, 1.0, 1e-9); });
+        printf("v_fma_f64, 2048 blocks x 4 waves x 8 chains: %.2f TFLOP/s\n",
+               2048.0 * 256 * 8 * iters * 2.0 / (fc * 1e-3) / 1e12);
+        float d1 = time_ms([&] { hipLaunchKernelGGL(div_rate, dim3(1), dim3(64), 0, 0, dout, iters, 3.0); });
+        printf("f64 add+div dependent chain, one wave: %.1f ns per (add, div)\n", d1 * 1e6 / iters);
+        float tl = time_ms([&] { hipLaunchKernelGGL(fma_rate<1>, dim3(1), dim3(64), 0, 0, dout, 1, 1.0, 1e-9); }, 20);
+        printf("empty-ish kernel, event to event: %.2f us\n", tl * 1e3);
+        hipFree(dout);
     }
 
     // ---- 3. HBM fill / copy bandwidth

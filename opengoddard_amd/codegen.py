@@ -27,6 +27,7 @@ from . import trace as _tr
 
 import os
 
+HEAVY_COLUMN_ELEMENTS = 32       # columns with more dependent elements get a whole workgroup
 MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "8"))
 
 
@@ -592,7 +593,7 @@ class _Emitter:
     def group_function(self, gi, grp):
         if grp.kind == "defect":
             # T_s = (tf-t0)/2 * f_s at node k; the defect is  y[s] - T_s
-            lines = ["    template <class X> OG_HD static void tail%d(const int k, const X& x, "
+            lines = ["    template <class X> OG_HDI static void tail%d(const int k, const X& x, "
                      "const double* cv, double* T) {" % gi,
                      "        (void)k; (void)cv;"]
             names = {}
@@ -601,7 +602,7 @@ class _Emitter:
             for s, e in enumerate(grp.tails):
                 lines.append("        T[%d] = %s;" % (s, names[e]))
             lines += ["    }",
-                      "    template <class X> OG_HD static void group%d(const int k, const X& x, "
+                      "    template <class X> OG_HDI static void group%d(const int k, const X& x, "
                       "const double* y, const double* cv, double* out) {" % gi,
                       "        double T[%d];" % len(grp.tails),
                       "        tail%d(k, x, cv, T);" % gi]
@@ -609,7 +610,7 @@ class _Emitter:
                 lines.append("        out[%d] = y[%d] - T[%d];" % (s, s, s))
             lines.append("    }")
             return lines
-        lines = ["    template <class X> OG_HD static void group%d(const int k, const X& x, "
+        lines = ["    template <class X> OG_HDI static void group%d(const int k, const X& x, "
                  "const double* y, const double* cv, double* out) {" % gi,
                  "        (void)k; (void)y; (void)cv;"]
         names = {}
@@ -710,6 +711,14 @@ def emit_header(P):
     for sl in P.mv:
         y0_off.append(at)
         at += sl.length
+    elems = np.zeros(P.n, dtype=np.int64)
+    for g in P.groups:
+        for kind, base, cnt in g.deps:
+            elems[base:base + cnt] += 1 if kind == 1 else g.length
+    heavy = [int(j) for j in np.nonzero(elems > HEAVY_COLUMN_ELEMENTS)[0]]
+    heavy.sort(key=lambda j: -elems[j])
+    light = [j for j in range(P.n) if elems[j] <= HEAVY_COLUMN_ELEMENTS]
+    L += ["    static constexpr int N_HEAVY = %d;" % len(heavy), _int_table("COL_ORDER", heavy + light)]
     L += [_int_table("MV_GROUP", slot_group), _int_table("MV_Y0", y0_off),
           "    static constexpr int N_Y0 = %d;" % max(at, 1)]
     L.append("")
@@ -718,14 +727,14 @@ def emit_header(P):
         L.append("")
     L += em.operand_function()
     L.append("")
-    L.append("    template <class X> OG_HD static void defect_tail(const int g, const int k, "
+    L.append("    template <class X> OG_HDI static void defect_tail(const int g, const int k, "
              "const X& x, const double* cv, double* T) {")
     L.append("        switch (g) {")
     for gi, g in enumerate(P.groups):
         if g.kind == "defect":
             L.append("        case %d: tail%d(k, x, cv, T); break;" % (gi, gi))
     L += ["        default: break;", "        }", "    }", ""]
-    L.append("    template <class X> OG_HD static void group_eval(const int g, const int k, "
+    L.append("    template <class X> OG_HDI static void group_eval(const int g, const int k, "
              "const X& x, const double* y, const double* cv, double* out) {")
     L.append("        switch (g) {")
     for gi in range(len(P.groups)):

@@ -20,8 +20,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define OG_HD __host__ __device__ inline
+#define OG_HDI __host__ __device__ __forceinline__
 #else
 #define OG_HD inline
+#define OG_HDI inline __attribute__((always_inline))
 #endif
 
 namespace ogm {

@@ -286,13 +286,19 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
 }
 
 // ------------------------------------------------------------------------------------------
-// Mode 1, part A: one workgroup owns FD column j = one row of J_T.
+// Mode 1, part A: a J_T row (= FD column j) is owned by one workgroup (WAVE = false: columns
+// with many dependent elements, e.g. phase final times) or by one wavefront (WAVE = true: all
+// other columns, four per workgroup).  The owner streams z into the row and then re-evaluates
+// the (group, element) items that read p[j].  In the wavefront flavour no workgroup barrier is
+// needed: LDS operations and same-address global stores of one wavefront execute in order.
 // ------------------------------------------------------------------------------------------
+template <bool WAVE>
 __device__ __forceinline__ void column_body(const ogk_args& a, const int j, int* lds_i) {
-    const int tid = (int)threadIdx.x;
+    constexpr int STRIDE = WAVE ? 64 : 256;
+    const int tid = WAVE ? ((int)threadIdx.x & 63) : (int)threadIdx.x;
     int* item_g = lds_i;
     int* item_k0 = lds_i + MAX_ITEMS;
-    int* item_off = lds_i + 2 * MAX_ITEMS;       // element count per dependency entry
+    int* item_cnt = lds_i + 2 * MAX_ITEMS;       // element count per dependency entry
 
     // rows of this J_T row that the MFMA tiles own (j inside a collocated state slice)
     int own_lo = 0, own_hi = 0;
@@ -308,21 +314,22 @@ __device__ __forceinline__ void column_body(const ogk_args& a, const int j, int*
     // ---- stream z (0, or NaN for non-finite rows) into the row, skipping the owned block
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
     if (!(OGK_EXP & 16))
-        for (int r = tid; r < OgGen::M; r += 256)
+        for (int r = tid; r < OgGen::M; r += STRIDE)
             if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
 
     // ---- which (group, element range) items read p[j]?  One dependency entry per thread;
-    //      cnt[d] = number of elements entry d contributes for this column.
-    for (int d = tid; d < OgGen::N_DEP; d += 256) {
+    //      item_cnt[d] = number of elements entry d contributes for this column.
+    for (int d = tid; d < OgGen::N_DEP; d += STRIDE) {
         const int kind = OgGen::DEP_KIND(d), base = OgGen::DEP_BASE(d), cnt = OgGen::DEP_CNT(d);
         const bool hit = j >= base && j < base + cnt;
         item_g[d] = OgGen::DEP_G(d);
         item_k0[d] = (kind == 1) ? (j - base) : -1;      // -1: every element of the group
-        item_off[d] = !hit ? 0 : (kind == 1 ? 1 : OgGen::G_LEN(OgGen::DEP_G(d)));
+        item_cnt[d] = !hit ? 0 : (kind == 1 ? 1 : OgGen::G_LEN(OgGen::DEP_G(d)));
     }
-    __syncthreads();      // also orders the z stores above before the item stores below
+    if (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    else __syncthreads();      // also orders the z stores above before the item stores below
     int nelem = 0;
-    for (int d = 0; d < OgGen::N_DEP; ++d) nelem += item_off[d];
+    for (int d = 0; d < OgGen::N_DEP; ++d) nelem += item_cnt[d];
     if (nelem == 0) return;
 
     const double xb = a.x0[j];
@@ -331,9 +338,9 @@ __device__ __forceinline__ void column_body(const ogk_args& a, const int j, int*
     const XCol xa{a.x0, j, xj};
     double y[OgGen::MAX_NMV];
     double out[OgGen::MAX_OUT];
-    for (int e = tid; e < ((OGK_EXP & 8) ? 0 : nelem); e += 256) {
+    for (int e = tid; e < ((OGK_EXP & 8) ? 0 : nelem); e += STRIDE) {
         int it = 0, before = 0;
-        while (e >= before + item_off[it]) { before += item_off[it]; ++it; }
+        while (e >= before + item_cnt[it]) { before += item_cnt[it]; ++it; }
         const int g = item_g[it];
         const int k = (item_k0[it] >= 0) ? item_k0[it] : (e - before);
         const int nout = OgGen::G_NOUT(g);
@@ -464,9 +471,18 @@ __global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int nti
     if (id < ntiles) {
         // MFMA tiles have the longest dependent chain: dispatch them first
         if (!(OGK_EXP & 32)) tile_body(a, id, lds);
+    } else if (id < ntiles + OgGen::N_HEAVY) {
+        // then the columns with many dependent elements (e.g. phase final times): a workgroup each
+        const int j = OgGen::COL_ORDER(id - ntiles);
+        if (j >= a.col_lo && j < a.col_hi) column_body<false>(a, j, reinterpret_cast<int*>(lds));
     } else {
-        // then the columns, highest first: the phase-final-time columns carry the most items
-        column_body(a, a.col_hi - 1 - (id - ntiles), reinterpret_cast<int*>(lds));
+        // all other columns: one wavefront each, four per workgroup
+        const int wave = (int)threadIdx.x >> 6;
+        const int li = OgGen::N_HEAVY + (id - ntiles - OgGen::N_HEAVY) * 4 + wave;
+        if (li >= OgGen::N_VAR) return;
+        const int j = OgGen::COL_ORDER(li);
+        if (j >= a.col_lo && j < a.col_hi)
+            column_body<true>(a, j, reinterpret_cast<int*>(lds) + wave * 3 * MAX_ITEMS);
     }
 }
 
@@ -498,7 +514,7 @@ int tile_blocks() {
 }
 
 size_t sweep_lds_bytes() {
-    size_t worst = (3 * (size_t)MAX_ITEMS + 2) * sizeof(int);
+    size_t worst = 4 * 3 * (size_t)MAX_ITEMS * sizeof(int);
     for (int s = 0; s < OgGen::N_MV; ++s) {
         const int KS = (OgGen::MV_LEN(s) + 3) >> 2;
         const size_t need = ((size_t)KS * 64 + (size_t)KS * 4) * sizeof(double);
@@ -539,9 +555,12 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     const int ncols = args->col_hi - args->col_lo;
     if (ncols <= 0) return 0;
     if (mode == 1) {
+        // every column has a workgroup/wavefront slot; a rank's launch skips columns outside
+        // [col_lo, col_hi) inside the kernel
         const int ntiles = tile_blocks();
-        hipLaunchKernelGGL(ogk_sweep, dim3(ncols + ntiles), dim3(256), sweep_lds_bytes(), stream,
-                           *args, ntiles);
+        const int light_blocks = (OgGen::N_VAR - OgGen::N_HEAVY + 3) / 4;
+        hipLaunchKernelGGL(ogk_sweep, dim3(ntiles + OgGen::N_HEAVY + light_blocks), dim3(256),
+                           sweep_lds_bytes(), stream, *args, ntiles);
         return (int)hipGetLastError();
     }
     const int defect_total = ndef * ((ncols + 63) / 64);

@@ -711,14 +711,46 @@ def emit_header(P):
     for sl in P.mv:
         y0_off.append(at)
         at += sl.length
-    elems = np.zeros(P.n, dtype=np.int64)
-    for g in P.groups:
+    # per-column work lists of the structured sweep: every (group, element) that reads p[j]
+    col_elems = [set() for _ in range(P.n)]
+    for gi, g in enumerate(P.groups):
         for kind, base, cnt in g.deps:
-            elems[base:base + cnt] += 1 if kind == 1 else g.length
-    heavy = [int(j) for j in np.nonzero(elems > HEAVY_COLUMN_ELEMENTS)[0]]
-    heavy.sort(key=lambda j: -elems[j])
-    light = [j for j in range(P.n) if elems[j] <= HEAVY_COLUMN_ELEMENTS]
-    L += ["    static constexpr int N_HEAVY = %d;" % len(heavy), _int_table("COL_ORDER", heavy + light)]
+            for j in range(base, base + cnt):
+                if kind == 1:
+                    col_elems[j].add((gi, j - base))
+                else:
+                    col_elems[j].update((gi, k) for k in range(g.length))
+    col_ptr, elem_g, elem_k = [0], [], []
+    for j in range(P.n):
+        for gi, k in sorted(col_elems[j]):
+            elem_g.append(gi)
+            elem_k.append(k)
+        col_ptr.append(len(elem_g))
+    counts = np.diff(col_ptr)
+    heavy = [int(j) for j in np.nonzero(counts > HEAVY_COLUMN_ELEMENTS)[0]]
+    heavy.sort(key=lambda j: -counts[j])
+    light = [j for j in range(P.n) if counts[j] <= HEAVY_COLUMN_ELEMENTS]
+    # rows of a J_T row written by the MFMA tiles (j inside a collocated state slice)
+    own_lo, own_hi = [0] * P.n, [0] * P.n
+    mv_diag, mv_generic = [], []
+    for si, sl in enumerate(P.mv):
+        g = P.groups[slot_group[si]]
+        row0 = g.outputs[si - g.mv_slots[0]][0]
+        for j in range(sl.leaf_base, sl.leaf_base + sl.length):
+            own_lo[j], own_hi[j] = row0, row0 + sl.length
+        # how does the dynamics term of this group depend on columns of the slot's own slice?
+        diag = any(kind == 1 and base == sl.leaf_base for kind, base, cnt in g.deps)
+        other = any(not (kind == 1 and base == sl.leaf_base) and
+                    base < sl.leaf_base + sl.length and base + cnt > sl.leaf_base
+                    for kind, base, cnt in g.deps)
+        mv_diag.append(int(diag))
+        mv_generic.append(int(other))
+    L += ["    static constexpr int N_HEAVY = %d;" % len(heavy),
+          "    static constexpr int N_ELEM = %d;" % len(elem_g),
+          _int_table("COL_ORDER", heavy + light), _int_table("COL_PTR", col_ptr),
+          _int_table("ELEM_G", elem_g), _int_table("ELEM_K", elem_k),
+          _int_table("COL_OWN_LO", own_lo), _int_table("COL_OWN_HI", own_hi),
+          _int_table("MV_DIAG", mv_diag), _int_table("MV_GENERIC", mv_generic)]
     L += [_int_table("MV_GROUP", slot_group), _int_table("MV_Y0", y0_off),
           "    static constexpr int N_Y0 = %d;" % max(at, 1)]
     L.append("")

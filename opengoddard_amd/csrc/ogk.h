@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define OGK_ABI 4
+#define OGK_ABI 5
 #define OGK_MAX_PHASE 32
 
 // MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
@@ -42,6 +42,8 @@ typedef struct ogk_args {
     double* xop;            // [n_y0] base collocation operands   (written by mode 0)
     double* t0;             // [m] base dynamics terms of defect rows (written by mode 0)
     double* z;              // [m] F0 - F0: 0, or NaN for non-finite rows (written by mode 0)
+    int* nonfinite;         // number of non-finite rows of F(x0): counted by mode 0, read by mode 1
+    int* nonfinite_next;    // the slot the *next* evaluation counts into (mode 0 zeroes it)
     double* jt;             // [(col_hi-col_lo) * m] transposed Jacobian rows (mode 1)
     int32_t col_lo, col_hi; // FD columns handled by this launch
     int64_t dfrag_off[OGK_MAX_PHASE];

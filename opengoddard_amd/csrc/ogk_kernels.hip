@@ -61,7 +61,6 @@ struct XCol {
 };
 
 constexpr int ROWS_COLS_PER_THREAD = 8;
-constexpr int MAX_ITEMS = OgGen::N_DEP > 0 ? OgGen::N_DEP : 1;
 
 __device__ __forceinline__ int defect_block_to_group(int bx, int* nt_out) {
     for (int g = 0; g < OgGen::N_GROUPS; ++g) {
@@ -153,8 +152,10 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
             if (s >= nmv) break;
             const int row = OgGen::G_ROW(g, s) + k;
             const double val = y[s] - T[s];
+            const double zz = val - val;
             a.f0[row] = val;
-            a.z[row] = val - val;
+            a.z[row] = zz;
+            if (zz != zz) atomicAdd(a.nonfinite, 1);
             a.t0[row] = T[s];
             a.y0[OgGen::MV_Y0(mv0 + s) + k] = y[s];
         }
@@ -248,8 +249,10 @@ __device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const
         for (int o = 0; o < OgGen::MAX_OUT; ++o)
             if (o < nout) {
                 const int row = OgGen::G_ROW(g, o) + k;
+                const double zz = out[o] - out[o];
                 a.f0[row] = out[o];
-                a.z[row] = out[o] - out[o];
+                a.z[row] = zz;
+                if (zz != zz) atomicAdd(a.nonfinite, 1);
             }
         return;
     }
@@ -277,6 +280,9 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
                                                  const int defect_total, const int row_blocks) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
+    // the evaluation after this one counts into the other slot: clear it now (stream order
+    // makes this visible to the next launch)
+    if (!SWEEP && id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
     if (id < defect_total) {
         defect_body<SWEEP>(a, id % ndef, id / ndef, lds);
     } else {
@@ -293,56 +299,39 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
 // needed: LDS operations and same-address global stores of one wavefront execute in order.
 // ------------------------------------------------------------------------------------------
 template <bool WAVE>
-__device__ __forceinline__ void column_body(const ogk_args& a, const int j, int* lds_i) {
+__device__ __forceinline__ void column_body(const ogk_args& a, const int j) {
     constexpr int STRIDE = WAVE ? 64 : 256;
     const int tid = WAVE ? ((int)threadIdx.x & 63) : (int)threadIdx.x;
-    int* item_g = lds_i;
-    int* item_k0 = lds_i + MAX_ITEMS;
-    int* item_cnt = lds_i + 2 * MAX_ITEMS;       // element count per dependency entry
-
-    // rows of this J_T row that the MFMA tiles own (j inside a collocated state slice)
-    int own_lo = 0, own_hi = 0;
-    for (int s = 0; s < OgGen::N_MV; ++s) {
-        const int leaf = OgGen::MV_LEAF(s), len = OgGen::MV_LEN(s);
-        if (j >= leaf && j < leaf + len) {
-            const int g = OgGen::MV_GROUP(s);
-            own_lo = OgGen::G_ROW(g, s - OgGen::G_MV0(g));
-            own_hi = own_lo + len;
-        }
-    }
-
-    // ---- stream z (0, or NaN for non-finite rows) into the row, skipping the owned block
-    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    if (!(OGK_EXP & 16))
-        for (int r = tid; r < OgGen::M; r += STRIDE)
-            if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
-
-    // ---- which (group, element range) items read p[j]?  One dependency entry per thread;
-    //      item_cnt[d] = number of elements entry d contributes for this column.
-    for (int d = tid; d < OgGen::N_DEP; d += STRIDE) {
-        const int kind = OgGen::DEP_KIND(d), base = OgGen::DEP_BASE(d), cnt = OgGen::DEP_CNT(d);
-        const bool hit = j >= base && j < base + cnt;
-        item_g[d] = OgGen::DEP_G(d);
-        item_k0[d] = (kind == 1) ? (j - base) : -1;      // -1: every element of the group
-        item_cnt[d] = !hit ? 0 : (kind == 1 ? 1 : OgGen::G_LEN(OgGen::DEP_G(d)));
-    }
-    if (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    else __syncthreads();      // also orders the z stores above before the item stores below
-    int nelem = 0;
-    for (int d = 0; d < OgGen::N_DEP; ++d) nelem += item_cnt[d];
-    if (nelem == 0) return;
-
+    const int own_lo = OgGen::COL_OWN_LO(j), own_hi = OgGen::COL_OWN_HI(j);   // MFMA-tile rows
+    const int e0 = OgGen::COL_PTR(j), e1 = OgGen::COL_PTR(j + 1);
     const double xb = a.x0[j];
     const double xj = xb + a.h[j];
     const double dx = xj - xb;
+
+    // ---- stream the "no dependency" value into the row, skipping the tile-owned block: 0.0
+    //      when every row of F(x0) is finite (counted by mode 0), else z = F0 - F0 (NaN rows).
+    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+    if (!(OGK_EXP & 16)) {
+        if (*a.nonfinite == 0) {
+            for (int r = tid; r < OgGen::M; r += STRIDE)
+                if (r < own_lo || r >= own_hi) jrow[r] = 0.0;
+        } else {
+            for (int r = tid; r < OgGen::M; r += STRIDE)
+                if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
+        }
+    }
+    if (e0 == e1) return;
+    // order the stores above before the element stores below (same addresses): a wavefront's
+    // stores stay in program order; a workgroup needs the barrier
+    if (!WAVE) __syncthreads();
+
+    // ---- re-evaluate the (group, element) items that read p[j] (lists built by the tracer)
     const XCol xa{a.x0, j, xj};
     double y[OgGen::MAX_NMV];
     double out[OgGen::MAX_OUT];
-    for (int e = tid; e < ((OGK_EXP & 8) ? 0 : nelem); e += STRIDE) {
-        int it = 0, before = 0;
-        while (e >= before + item_cnt[it]) { before += item_cnt[it]; ++it; }
-        const int g = item_g[it];
-        const int k = (item_k0[it] >= 0) ? item_k0[it] : (e - before);
+    for (int e = e0 + tid; e < ((OGK_EXP & 8) ? 0 : e1); e += STRIDE) {
+        const int g = OgGen::ELEM_G(e);
+        const int k = OgGen::ELEM_K(e);
         const int nout = OgGen::G_NOUT(g);
         if (OgGen::G_KIND(g) == 1) {
             const int mv0 = OgGen::G_MV0(g);
@@ -436,6 +425,7 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     const double t_base = a.t0[row];
     const double f_base = a.f0[row];
     const int dep0 = OgGen::G_DEP0(g), ndep = OgGen::G_NDEP(g);
+    const bool diag = OgGen::MV_DIAG(slot) != 0, generic = OgGen::MV_GENERIC(slot) != 0;
     double T[OgGen::MAX_NMV];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -445,13 +435,15 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
         const double xb = a.x0[j];
         const double xj = xb + a.h[j];
         const double dx = xj - xb;
-        // does the dynamics term of node k read p[j]?  (normally only on the diagonal k == lc)
-        bool reads = false;
-        for (int d = dep0; d < dep0 + ndep; ++d) {
-            const int kind = OgGen::DEP_KIND(d), base_d = OgGen::DEP_BASE(d);
-            reads = reads || (kind == 1 ? (base_d + k == j)
-                                        : (j >= base_d && j < base_d + OgGen::DEP_CNT(d)));
-        }
+        // does the dynamics term of node k read p[j]?  Normally only on the diagonal k == lc
+        // (the state appears in its phase's dynamics); anything else takes the table scan.
+        bool reads = diag && k == lc;
+        if (generic)
+            for (int d = dep0; d < dep0 + ndep; ++d) {
+                const int kind = OgGen::DEP_KIND(d), base_d = OgGen::DEP_BASE(d);
+                reads = reads || (kind == 1 ? (base_d + k == j)
+                                            : (j >= base_d && j < base_d + OgGen::DEP_CNT(d)));
+            }
         double t = t_base;
         if (reads) {
             const XCol xa{a.x0, j, xj};
@@ -474,15 +466,14 @@ __global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int nti
     } else if (id < ntiles + OgGen::N_HEAVY) {
         // then the columns with many dependent elements (e.g. phase final times): a workgroup each
         const int j = OgGen::COL_ORDER(id - ntiles);
-        if (j >= a.col_lo && j < a.col_hi) column_body<false>(a, j, reinterpret_cast<int*>(lds));
+        if (j >= a.col_lo && j < a.col_hi) column_body<false>(a, j);
     } else {
         // all other columns: one wavefront each, four per workgroup
         const int wave = (int)threadIdx.x >> 6;
         const int li = OgGen::N_HEAVY + (id - ntiles - OgGen::N_HEAVY) * 4 + wave;
         if (li >= OgGen::N_VAR) return;
         const int j = OgGen::COL_ORDER(li);
-        if (j >= a.col_lo && j < a.col_hi)
-            column_body<true>(a, j, reinterpret_cast<int*>(lds) + wave * 3 * MAX_ITEMS);
+        if (j >= a.col_lo && j < a.col_hi) column_body<true>(a, j);
     }
 }
 
@@ -514,7 +505,7 @@ int tile_blocks() {
 }
 
 size_t sweep_lds_bytes() {
-    size_t worst = 4 * 3 * (size_t)MAX_ITEMS * sizeof(int);
+    size_t worst = 0;
     for (int s = 0; s < OgGen::N_MV; ++s) {
         const int KS = (OgGen::MV_LEN(s) + 3) >> 2;
         const size_t need = ((size_t)KS * 64 + (size_t)KS * 4) * sizeof(double);

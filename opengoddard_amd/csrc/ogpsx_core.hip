@@ -79,6 +79,8 @@ struct og_problem_s {
     double* d_xop = nullptr;
     double* d_t0 = nullptr;
     double* d_z = nullptr;
+    int* d_flags = nullptr;             // two non-finite-row counters used alternately
+    int flag_slot = 0;
     int sweep_mode = 1;                 // 1 structured (default), 2 dense (OGPSX_SWEEP=dense)
     hipStream_t stream = nullptr;
 };
@@ -96,6 +98,8 @@ void fill_args(const og_problem_s* p, ogk_args* a, const double* x, const double
     a->xop = p->d_xop;
     a->t0 = p->d_t0;
     a->z = p->d_z;
+    a->nonfinite = p->d_flags + p->flag_slot;
+    a->nonfinite_next = p->d_flags + (p->flag_slot ^ 1);
     a->jt = jt;
     a->col_lo = lo;
     a->col_hi = hi;
@@ -253,6 +257,8 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMalloc(&p->d_xop, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_t0, sizeof(double) * (size_t)p->m);
     if (e == hipSuccess) e = hipMalloc(&p->d_z, sizeof(double) * (size_t)p->m);
+    if (e == hipSuccess) e = hipMalloc(&p->d_flags, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 2 * sizeof(int));
     const char* mode_env = getenv("OGPSX_SWEEP");
     if (mode_env && std::string(mode_env) == "dense") p->sweep_mode = 2;
     if (e == hipSuccess) e = hipStreamCreate(&p->stream);
@@ -278,6 +284,7 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_xop);
     hipFree(p->d_t0);
     hipFree(p->d_z);
+    hipFree(p->d_flags);
     if (p->module) dlclose(p->module);
     delete p;
 }
@@ -294,6 +301,7 @@ int og_problem_dims(og_handle p, int32_t* n, int32_t* m, int32_t* m_eq, int32_t*
 int og_eval_dev(og_handle p, const double* d_x, double* d_F, void* hip_stream) {
     if (!p || !d_x || !d_F) return fail(1, "og_eval_dev: null argument");
     ogk_args a;
+    p->flag_slot ^= 1;                      // this evaluation counts non-finite rows into a fresh slot
     fill_args(p, &a, d_x, nullptr, d_F, nullptr, 0, 0);
     int rc = p->launch(&a, 0, hip_stream);
     if (rc) return fail(100 + rc, std::string("og_eval_dev: ") + hipGetErrorString((hipError_t)rc));
@@ -305,6 +313,7 @@ int og_fd_sweep_dev(og_handle p, const double* d_x, const double* d_h, int32_t l
     if (!p || !d_x || !d_h || !d_JT || !d_F0) return fail(1, "og_fd_sweep_dev: null argument");
     if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_fd_sweep_dev: bad column range");
     ogk_args a;
+    p->flag_slot ^= 1;
     fill_args(p, &a, d_x, d_h, d_F0, d_JT, lo, hi);
     int rc = p->launch(&a, 0, hip_stream);          // F(x0) first: the sweep subtracts it
     if (!rc) rc = p->launch(&a, p->sweep_mode, hip_stream);

@@ -292,62 +292,98 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
 }
 
 // ------------------------------------------------------------------------------------------
-// Mode 1, part A: a J_T row (= FD column j) is owned by one workgroup (WAVE = false: columns
-// with many dependent elements, e.g. phase final times) or by one wavefront (WAVE = true: all
-// other columns, four per workgroup).  The owner streams z into the row and then re-evaluates
-// the (group, element) items that read p[j].  In the wavefront flavour no workgroup barrier is
-// needed: LDS operations and same-address global stores of one wavefront execute in order.
+// Mode 1, part A: the J_T rows (= FD columns).  The owner of a row streams the "no dependency"
+// value into it and then re-evaluates the (group, element) items that read p[j]; the item
+// lists come from the tracer (COL_PTR / ELEM_G / ELEM_K).  Evaluation is latency-bound (a
+// dependent f64 op costs ~13 ns on gfx950), so the mapping is chosen to keep chains short and
+// wavefronts convergent:
+//   heavy_column_body  a column with many items (phase final times): one workgroup, lanes =
+//                      consecutive items (= consecutive nodes of one group: same code);
+//   light_columns_body 16 neighbouring columns per workgroup: lane = column, wavefront = item
+//                      slot, so the items of one column run concurrently in different
+//                      wavefronts and neighbouring columns (same slice, next node) share code.
 // ------------------------------------------------------------------------------------------
-template <bool WAVE>
-__device__ __forceinline__ void column_body(const ogk_args& a, const int j) {
-    constexpr int STRIDE = WAVE ? 64 : 256;
-    const int tid = WAVE ? ((int)threadIdx.x & 63) : (int)threadIdx.x;
-    const int own_lo = OgGen::COL_OWN_LO(j), own_hi = OgGen::COL_OWN_HI(j);   // MFMA-tile rows
+__device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const int own_lo,
+                                         const int own_hi, const int first, const int stride) {
+    if (OGK_EXP & 16) return;
+    if (*a.nonfinite == 0) {        // every row of F(x0) is finite: (F0-F0)/dx is plain zero
+        for (int r = first; r < OgGen::M; r += stride)
+            if (r < own_lo || r >= own_hi) jrow[r] = 0.0;
+    } else {                        // z carries NaN for the non-finite rows
+        for (int r = first; r < OgGen::M; r += stride)
+            if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
+    }
+}
+
+__device__ __forceinline__ void eval_item(const ogk_args& a, const int e, const XCol& xa,
+                                          const double dx, double* jrow, const int own_lo,
+                                          const int own_hi) {
+    const int g = OgGen::ELEM_G(e);
+    const int k = OgGen::ELEM_K(e);
+    const int nout = OgGen::G_NOUT(g);
+    double y[OgGen::MAX_NMV];
+    double out[OgGen::MAX_OUT];
+    if (OgGen::G_KIND(g) == 1) {
+        const int mv0 = OgGen::G_MV0(g);
+#pragma unroll
+        for (int s = 0; s < OgGen::MAX_NMV; ++s)
+            y[s] = (s < OgGen::G_NMV(g)) ? a.y0[OgGen::MV_Y0(mv0 + s) + k] : 0.0;
+    }
+    OgGen::group_eval(g, k, xa, y, a.cvec, out);
+#pragma unroll
+    for (int o = 0; o < OgGen::MAX_OUT; ++o) {
+        if (o >= nout) break;
+        const int row = OgGen::G_ROW(g, o) + k;
+        if (row >= own_lo && row < own_hi) continue;        // written by the MFMA tiles
+        jrow[row] = (out[o] - a.f0[row]) / dx;
+    }
+}
+
+__device__ __forceinline__ void heavy_column_body(const ogk_args& a, const int j) {
+    const int tid = (int)threadIdx.x;
+    const int own_lo = OgGen::COL_OWN_LO(j), own_hi = OgGen::COL_OWN_HI(j);
     const int e0 = OgGen::COL_PTR(j), e1 = OgGen::COL_PTR(j + 1);
     const double xb = a.x0[j];
     const double xj = xb + a.h[j];
     const double dx = xj - xb;
-
-    // ---- stream the "no dependency" value into the row, skipping the tile-owned block: 0.0
-    //      when every row of F(x0) is finite (counted by mode 0), else z = F0 - F0 (NaN rows).
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    if (!(OGK_EXP & 16)) {
-        if (*a.nonfinite == 0) {
-            for (int r = tid; r < OgGen::M; r += STRIDE)
-                if (r < own_lo || r >= own_hi) jrow[r] = 0.0;
-        } else {
-            for (int r = tid; r < OgGen::M; r += STRIDE)
-                if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
-        }
-    }
-    if (e0 == e1) return;
-    // order the stores above before the element stores below (same addresses): a wavefront's
-    // stores stay in program order; a workgroup needs the barrier
-    if (!WAVE) __syncthreads();
-
-    // ---- re-evaluate the (group, element) items that read p[j] (lists built by the tracer)
+    fill_row(a, jrow, own_lo, own_hi, tid, 256);
+    __syncthreads();                 // fill stores before item stores to the same addresses
     const XCol xa{a.x0, j, xj};
-    double y[OgGen::MAX_NMV];
-    double out[OgGen::MAX_OUT];
-    for (int e = e0 + tid; e < ((OGK_EXP & 8) ? 0 : e1); e += STRIDE) {
-        const int g = OgGen::ELEM_G(e);
-        const int k = OgGen::ELEM_K(e);
-        const int nout = OgGen::G_NOUT(g);
-        if (OgGen::G_KIND(g) == 1) {
-            const int mv0 = OgGen::G_MV0(g);
-#pragma unroll
-            for (int s = 0; s < OgGen::MAX_NMV; ++s)
-                y[s] = (s < OgGen::G_NMV(g)) ? a.y0[OgGen::MV_Y0(mv0 + s) + k] : 0.0;
-        }
-        OgGen::group_eval(g, k, xa, y, a.cvec, out);
-#pragma unroll
-        for (int o = 0; o < OgGen::MAX_OUT; ++o) {
-            if (o >= nout) break;
-            const int row = OgGen::G_ROW(g, o) + k;
-            if (row >= own_lo && row < own_hi) continue;        // written by the MFMA tiles
-            jrow[row] = (out[o] - a.f0[row]) / dx;
-        }
+    for (int e = e0 + tid; e < ((OGK_EXP & 8) ? 0 : e1); e += 256)
+        eval_item(a, e, xa, dx, jrow, own_lo, own_hi);
+}
+
+constexpr int LIGHT_COLS = 16;       // columns per workgroup in light_columns_body
+
+__device__ __forceinline__ void light_columns_body(const ogk_args& a, const int first_li) {
+    const int tid = (int)threadIdx.x;
+    // ---- fill the (up to) 16 rows: each wavefront takes whole rows
+    for (int c = tid >> 6; c < LIGHT_COLS; c += 4) {
+        const int li = first_li + c;
+        if (li >= OgGen::N_VAR) break;
+        const int j = OgGen::COL_ORDER(li);
+        if (j < a.col_lo || j >= a.col_hi) continue;
+        fill_row(a, a.jt + (long)(j - a.col_lo) * OgGen::M, OgGen::COL_OWN_LO(j),
+                 OgGen::COL_OWN_HI(j), tid & 63, 64);
     }
+    __syncthreads();                 // fill stores before item stores to the same addresses
+    // ---- items: lane = column, wavefront = item slot
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = first_li + lane;
+    if (lane >= LIGHT_COLS || li >= OgGen::N_VAR) return;
+    const int j = OgGen::COL_ORDER(li);
+    if (j < a.col_lo || j >= a.col_hi) return;
+    const int e0 = OgGen::COL_PTR(j), e1 = OgGen::COL_PTR(j + 1);
+    if (e0 + wave >= e1) return;
+    const int own_lo = OgGen::COL_OWN_LO(j), own_hi = OgGen::COL_OWN_HI(j);
+    const double xb = a.x0[j];
+    const double xj = xb + a.h[j];
+    const double dx = xj - xb;
+    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+    const XCol xa{a.x0, j, xj};
+    for (int e = e0 + wave; e < ((OGK_EXP & 8) ? 0 : e1); e += 4)
+        eval_item(a, e, xa, dx, jrow, own_lo, own_hi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -379,7 +415,18 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     double* dpanel = lds;
     double* xt = lds + KS * 64;
     const double* src = a.dfrag + a.dfrag_off[OgGen::MV_PHASE(slot)] + (long)nt * KS * 64;
-    for (int i = tid; i < KS * 64; i += 256) dpanel[i] = src[i];
+    {
+        // all loads of the panel in flight before the first LDS store (latency paid once)
+        constexpr int UNR = 8;
+        for (int i0 = tid; i0 < KS * 64; i0 += 256 * UNR) {
+            double v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) v[u] = (i0 + 256 * u < KS * 64) ? src[i0 + 256 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (i0 + 256 * u < KS * 64) dpanel[i0 + 256 * u] = v[u];
+        }
+    }
     const double* xop = a.xop + OgGen::MV_Y0(slot);   // base operands, written by mode 0
     for (int l = tid; l < KS * 4; l += 256) xt[l] = (l < N) ? xop[l] : 0.0;
     __syncthreads();
@@ -466,14 +513,10 @@ __global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int nti
     } else if (id < ntiles + OgGen::N_HEAVY) {
         // then the columns with many dependent elements (e.g. phase final times): a workgroup each
         const int j = OgGen::COL_ORDER(id - ntiles);
-        if (j >= a.col_lo && j < a.col_hi) column_body<false>(a, j);
+        if (j >= a.col_lo && j < a.col_hi) heavy_column_body(a, j);
     } else {
-        // all other columns: one wavefront each, four per workgroup
-        const int wave = (int)threadIdx.x >> 6;
-        const int li = OgGen::N_HEAVY + (id - ntiles - OgGen::N_HEAVY) * 4 + wave;
-        if (li >= OgGen::N_VAR) return;
-        const int j = OgGen::COL_ORDER(li);
-        if (j >= a.col_lo && j < a.col_hi) column_body<true>(a, j);
+        // all other columns, 16 per workgroup
+        light_columns_body(a, OgGen::N_HEAVY + (id - ntiles - OgGen::N_HEAVY) * LIGHT_COLS);
     }
 }
 
@@ -549,7 +592,7 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         // every column has a workgroup/wavefront slot; a rank's launch skips columns outside
         // [col_lo, col_hi) inside the kernel
         const int ntiles = tile_blocks();
-        const int light_blocks = (OgGen::N_VAR - OgGen::N_HEAVY + 3) / 4;
+        const int light_blocks = (OgGen::N_VAR - OgGen::N_HEAVY + LIGHT_COLS - 1) / LIGHT_COLS;
         hipLaunchKernelGGL(ogk_sweep, dim3(ntiles + OgGen::N_HEAVY + light_blocks), dim3(256),
                            sweep_lds_bytes(), stream, *args, ntiles);
         return (int)hipGetLastError();

@@ -28,7 +28,7 @@ from . import trace as _tr
 import os
 
 HEAVY_COLUMN_ELEMENTS = 32       # columns with more dependent elements get a whole workgroup
-MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "8"))
+MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "1"))
 
 
 # ------------------------------------------------------------------------------ element graph
@@ -62,6 +62,7 @@ class Group:
         self.mv_slots = []            # slot ids feeding y[] (defect groups)
         self.tails = []               # defect groups: output s = Y_s - tails[s]
         self.deps = []                # [(kind, base, count)] decision-vector dependencies
+        self.out_deps = []            # defect groups: the same, per output (per state)
 
 
 class Program:
@@ -400,6 +401,8 @@ def _make_groups(P):
         if grp.kind == "defect":
             _split_defect_outputs(P, grp)
         grp.deps = _group_dependencies(P, grp)
+        if grp.kind == "defect":
+            grp.out_deps = [_group_dependencies(P, grp, [t]) for t in grp.tails]
 
 
 def _split_defect_outputs(P, grp):
@@ -421,13 +424,14 @@ def _split_defect_outputs(P, grp):
         grp.tails.append(node[3])
 
 
-def _group_dependencies(P, grp):
+def _group_dependencies(P, grp, roots=None):
     """Which decision variables an element k of the group reads.
     kind 1: p[base + k]            (one column per element, ``count`` = group length)
     kind 0: p[base]                (one column, every element)
     kind 2: p[base .. base+count)  read inside a sum  (each column, every element)"""
     eg = P.eg
-    roots = grp.tails if grp.kind == "defect" else [e for _, e in grp.outputs]
+    if roots is None:
+        roots = grp.tails if grp.kind == "defect" else [e for _, e in grp.outputs]
     deps = set()
     stack, seen = [(r, None) for r in roots], set()
     while stack:
@@ -601,8 +605,16 @@ class _Emitter:
             self._emit_expr(grp.tails, "k", lines, names, 8, {})
             for s, e in enumerate(grp.tails):
                 lines.append("        T[%d] = %s;" % (s, names[e]))
-            lines += ["    }",
-                      "    template <class X> OG_HDI static void group%d(const int k, const X& x, "
+            lines.append("    }")
+            for si, e in enumerate(grp.tails):       # one state's term alone: a short chain
+                lines += ["    template <class X> OG_HDI static double tail%d_%d(const int k, "
+                          "const X& x, const double* cv) {" % (gi, si),
+                          "        (void)k; (void)cv;"]
+                nm = {}
+                self._emit_sums([e], lines, nm, 8)
+                self._emit_expr([e], "k", lines, nm, 8, {})
+                lines += ["        return %s;" % nm[e], "    }"]
+            lines += ["    template <class X> OG_HDI static void group%d(const int k, const X& x, "
                       "const double* y, const double* cv, double* out) {" % gi,
                       "        double T[%d];" % len(grp.tails),
                       "        tail%d(k, x, cv, T);" % gi]
@@ -610,6 +622,8 @@ class _Emitter:
                 lines.append("        out[%d] = y[%d] - T[%d];" % (s, s, s))
             lines.append("    }")
             return lines
+        if len(grp.outputs) != 1 and False:
+            pass
         lines = ["    template <class X> OG_HDI static void group%d(const int k, const X& x, "
                  "const double* y, const double* cv, double* out) {" % gi,
                  "        (void)k; (void)y; (void)cv;"]
@@ -711,20 +725,29 @@ def emit_header(P):
     for sl in P.mv:
         y0_off.append(at)
         at += sl.length
-    # per-column work lists of the structured sweep: every (group, element) that reads p[j]
+    # per-column work lists of the structured sweep: every (group, output, element) that reads
+    # p[j].  Entries whose J_T position is written by the MFMA tiles (row of state s, column in
+    # state s's own slice) are left out.
     col_elems = [set() for _ in range(P.n)]
     for gi, g in enumerate(P.groups):
-        for kind, base, cnt in g.deps:
-            for j in range(base, base + cnt):
-                if kind == 1:
-                    col_elems[j].add((gi, j - base))
-                else:
-                    col_elems[j].update((gi, k) for k in range(g.length))
-    col_ptr, elem_g, elem_k = [0], [], []
+        per_output = g.out_deps if g.kind == "defect" else [g.deps] * len(g.outputs)
+        for o, deps in enumerate(per_output):
+            lo = hi = -1
+            if g.kind == "defect":
+                sl = P.mv[g.mv_slots[o]]
+                lo, hi = sl.leaf_base, sl.leaf_base + sl.length
+            for kind, base, cnt in deps:
+                for j in range(base, base + cnt):
+                    if lo <= j < hi:
+                        continue
+                    if kind == 1:
+                        col_elems[j].add((gi, o, j - base))
+                    else:
+                        col_elems[j].update((gi, o, k) for k in range(g.length))
+    col_ptr, elem_g, elem_o, elem_k = [0], [], [], []
     for j in range(P.n):
-        for gi, k in sorted(col_elems[j]):
-            elem_g.append(gi)
-            elem_k.append(k)
+        for gi, o, k in sorted(col_elems[j]):
+            elem_g.append(gi), elem_o.append(o), elem_k.append(k)
         col_ptr.append(len(elem_g))
     counts = np.diff(col_ptr)
     heavy = [int(j) for j in np.nonzero(counts > HEAVY_COLUMN_ELEMENTS)[0]]
@@ -748,7 +771,7 @@ def emit_header(P):
     L += ["    static constexpr int N_HEAVY = %d;" % len(heavy),
           "    static constexpr int N_ELEM = %d;" % len(elem_g),
           _int_table("COL_ORDER", heavy + light), _int_table("COL_PTR", col_ptr),
-          _int_table("ELEM_G", elem_g), _int_table("ELEM_K", elem_k),
+          _int_table("ELEM_G", elem_g), _int_table("ELEM_O", elem_o), _int_table("ELEM_K", elem_k),
           _int_table("COL_OWN_LO", own_lo), _int_table("COL_OWN_HI", own_hi),
           _int_table("MV_DIAG", mv_diag), _int_table("MV_GENERIC", mv_generic)]
     L += [_int_table("MV_GROUP", slot_group), _int_table("MV_Y0", y0_off),
@@ -766,6 +789,35 @@ def emit_header(P):
         if g.kind == "defect":
             L.append("        case %d: tail%d(k, x, cv, T); break;" % (gi, gi))
     L += ["        default: break;", "        }", "    }", ""]
+    # one J_T entry's worth of work: value of output o of group g at element k, and its row
+    L.append("    template <class X> OG_HDI static double item_value(const int g, const int o, "
+             "const int k, const X& x, const double* y0, const double* cv, int* row) {")
+    L.append("        (void)o; (void)y0;")
+    L.append("        switch (g) {")
+    for gi, g in enumerate(P.groups):
+        L.append("        case %d: {" % gi)
+        if g.kind == "defect":
+            L.append("            switch (o) {")
+            for si in range(len(g.tails)):
+                L.append("            case %d: *row = %d + k; return y0[%d + k] - tail%d_%d(k, x, cv);"
+                         % (si, g.outputs[si][0], y0_off[g.mv_slots[si]], gi, si))
+            L += ["            default: break;", "            }", "            break;"]
+        else:
+            L += ["            double out[%d];" % len(g.outputs),
+                  "            group%d(k, x, nullptr, cv, out);" % gi,
+                  "            *row = %d + k; return out[0];" % g.outputs[0][0]]
+            if len(g.outputs) != 1:
+                raise _tr.TraceError("row groups must have one output (OG_MAX_GROUP_OUTPUTS=1)")
+        L.append("        }")
+    L += ["        default: break;", "        }", "        *row = 0;", "        return 0.0;", "    }", ""]
+    # the dynamics term of one collocation slot (one state) at node k
+    L.append("    template <class X> OG_HDI static double tail_one(const int slot, const int k, "
+             "const X& x, const double* cv) {")
+    L.append("        switch (slot) {")
+    for gi, g in enumerate(P.groups):
+        for si, sl in enumerate(g.mv_slots):
+            L.append("        case %d: return tail%d_%d(k, x, cv);" % (sl, gi, si))
+    L += ["        default: return 0.0;", "        }", "    }", ""]
     L.append("    template <class X> OG_HDI static void group_eval(const int g, const int k, "
              "const X& x, const double* y, const double* cv, double* out) {")
     L.append("        switch (g) {")

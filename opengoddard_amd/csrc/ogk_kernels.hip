@@ -48,7 +48,21 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #define OGK_EXP 0
 #endif
 
+// -DOGK_TRACE=1 (tools/trace_sweep.py): workgroups overwrite the start of one of their J_T rows
+// with shader-clock stamps of their phases; results are garbage, timing is the point.
+#ifndef OGK_TRACE
+#define OGK_TRACE 0
+#endif
+
 namespace {
+
+__device__ __forceinline__ void trace_stamp(double* row, const int slot) {
+#if OGK_TRACE
+    row[slot] = (double)__builtin_amdgcn_s_memtime();
+#else
+    (void)row; (void)slot;
+#endif
+}
 
 struct XCol {
     const double* x0;
@@ -316,28 +330,15 @@ __device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const 
 }
 
 __device__ __forceinline__ void eval_item(const ogk_args& a, const int e, const XCol& xa,
-                                          const double dx, double* jrow, const int own_lo,
-                                          const int own_hi) {
-    const int g = OgGen::ELEM_G(e);
-    const int k = OgGen::ELEM_K(e);
-    const int nout = OgGen::G_NOUT(g);
-    double y[OgGen::MAX_NMV];
-    double out[OgGen::MAX_OUT];
-    if (OgGen::G_KIND(g) == 1) {
-        const int mv0 = OgGen::G_MV0(g);
-#pragma unroll
-        for (int s = 0; s < OgGen::MAX_NMV; ++s)
-            y[s] = (s < OgGen::G_NMV(g)) ? a.y0[OgGen::MV_Y0(mv0 + s) + k] : 0.0;
-    }
-    OgGen::group_eval(g, k, xa, y, a.cvec, out);
-#pragma unroll
-    for (int o = 0; o < OgGen::MAX_OUT; ++o) {
-        if (o >= nout) break;
-        const int row = OgGen::G_ROW(g, o) + k;
-        if (row >= own_lo && row < own_hi) continue;        // written by the MFMA tiles
-        jrow[row] = (out[o] - a.f0[row]) / dx;
-    }
+                                          const double dx, double* jrow) {
+    int row;
+    const double v = OgGen::item_value(OgGen::ELEM_G(e), OgGen::ELEM_O(e), OgGen::ELEM_K(e), xa,
+                                       a.y0, a.cvec, &row);
+    jrow[row] = (v - a.f0[row]) / dx;
 }
+
+constexpr int SWEEP_THREADS = 512;   // ogk_sweep workgroup: 8 wavefronts
+constexpr int SWEEP_WAVES = SWEEP_THREADS / 64;
 
 __device__ __forceinline__ void heavy_column_body(const ogk_args& a, const int j) {
     const int tid = (int)threadIdx.x;
@@ -347,27 +348,36 @@ __device__ __forceinline__ void heavy_column_body(const ogk_args& a, const int j
     const double xj = xb + a.h[j];
     const double dx = xj - xb;
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    fill_row(a, jrow, own_lo, own_hi, tid, 256);
+    fill_row(a, jrow, own_lo, own_hi, tid, SWEEP_THREADS);
     __syncthreads();                 // fill stores before item stores to the same addresses
     const XCol xa{a.x0, j, xj};
-    for (int e = e0 + tid; e < ((OGK_EXP & 8) ? 0 : e1); e += 256)
-        eval_item(a, e, xa, dx, jrow, own_lo, own_hi);
+    for (int e = e0 + tid; e < ((OGK_EXP & 8) ? 0 : e1); e += SWEEP_THREADS)
+        eval_item(a, e, xa, dx, jrow);
 }
 
-constexpr int LIGHT_COLS = 16;       // columns per workgroup in light_columns_body
+constexpr int LIGHT_COLS = 4;        // columns per workgroup in light_columns_body
 
 __device__ __forceinline__ void light_columns_body(const ogk_args& a, const int first_li) {
     const int tid = (int)threadIdx.x;
-    // ---- fill the (up to) 16 rows: each wavefront takes whole rows
-    for (int c = tid >> 6; c < LIGHT_COLS; c += 4) {
+#if OGK_TRACE
+    const long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- fill the rows: SWEEP_WAVES / LIGHT_COLS wavefronts share one row
+    {
+        constexpr int WPR = SWEEP_WAVES / LIGHT_COLS;           // wavefronts per row
+        const int c = (tid >> 6) / WPR, part = (tid >> 6) % WPR;
         const int li = first_li + c;
-        if (li >= OgGen::N_VAR) break;
-        const int j = OgGen::COL_ORDER(li);
-        if (j < a.col_lo || j >= a.col_hi) continue;
-        fill_row(a, a.jt + (long)(j - a.col_lo) * OgGen::M, OgGen::COL_OWN_LO(j),
-                 OgGen::COL_OWN_HI(j), tid & 63, 64);
+        if (li < OgGen::N_VAR) {
+            const int j = OgGen::COL_ORDER(li);
+            if (j >= a.col_lo && j < a.col_hi)
+                fill_row(a, a.jt + (long)(j - a.col_lo) * OgGen::M, OgGen::COL_OWN_LO(j),
+                         OgGen::COL_OWN_HI(j), part * 64 + (tid & 63), 64 * WPR);
+        }
     }
     __syncthreads();                 // fill stores before item stores to the same addresses
+#if OGK_TRACE
+    const long long t_filled = __builtin_amdgcn_s_memtime();
+#endif
     // ---- items: lane = column, wavefront = item slot
     const int lane = tid & 63, wave = tid >> 6;
     const int li = first_li + lane;
@@ -376,14 +386,24 @@ __device__ __forceinline__ void light_columns_body(const ogk_args& a, const int 
     if (j < a.col_lo || j >= a.col_hi) return;
     const int e0 = OgGen::COL_PTR(j), e1 = OgGen::COL_PTR(j + 1);
     if (e0 + wave >= e1) return;
-    const int own_lo = OgGen::COL_OWN_LO(j), own_hi = OgGen::COL_OWN_HI(j);
     const double xb = a.x0[j];
     const double xj = xb + a.h[j];
     const double dx = xj - xb;
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
     const XCol xa{a.x0, j, xj};
-    for (int e = e0 + wave; e < ((OGK_EXP & 8) ? 0 : e1); e += 4)
-        eval_item(a, e, xa, dx, jrow, own_lo, own_hi);
+#if OGK_TRACE
+    const long long t_ready = __builtin_amdgcn_s_memtime();
+#endif
+    for (int e = e0 + wave; e < ((OGK_EXP & 8) ? 0 : e1); e += SWEEP_WAVES)
+        eval_item(a, e, xa, dx, jrow);
+#if OGK_TRACE
+    if (lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        double* t = jrow + 8 * wave;
+        t[0] = 1.0e6 + wave; t[1] = (double)t_begin; t[2] = (double)t_filled; t[3] = (double)t_ready;
+        t[4] = (double)__builtin_amdgcn_s_memtime(); t[5] = (double)(e1 - e0);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -393,7 +413,7 @@ __device__ __forceinline__ void light_columns_body(const ogk_args& a, const int 
 __device__ __forceinline__ int tile_block_to_slot(int bx, int* mt4_out, int* nt_out) {
     for (int s = 0; s < OgGen::N_MV; ++s) {
         const int t16 = (OgGen::MV_LEN(s) + 15) >> 4;
-        const int per = ((t16 + 3) >> 2) * t16;
+        const int per = ((t16 + SWEEP_WAVES - 1) / SWEEP_WAVES) * t16;
         if (bx < per) { *mt4_out = bx / t16; *nt_out = bx % t16; return s; }
         bx -= per;
     }
@@ -401,6 +421,10 @@ __device__ __forceinline__ int tile_block_to_slot(int bx, int* mt4_out, int* nt_
 }
 
 __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, double* lds) {
+#if OGK_TRACE
+    const long long t_begin = __builtin_amdgcn_s_memtime();
+    long long t_staged = 0, t_mfma = 0;
+#endif
     int mt4 = 0, nt = 0;
     const int slot = tile_block_to_slot(bx, &mt4, &nt);
     if (slot < 0) return;
@@ -418,25 +442,29 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     {
         // all loads of the panel in flight before the first LDS store (latency paid once)
         constexpr int UNR = 8;
-        for (int i0 = tid; i0 < KS * 64; i0 += 256 * UNR) {
+        for (int i0 = tid; i0 < KS * 64; i0 += SWEEP_THREADS * UNR) {
             double v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) v[u] = (i0 + 256 * u < KS * 64) ? src[i0 + 256 * u] : 0.0;
+            for (int u = 0; u < UNR; ++u)
+                v[u] = (i0 + SWEEP_THREADS * u < KS * 64) ? src[i0 + SWEEP_THREADS * u] : 0.0;
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                if (i0 + 256 * u < KS * 64) dpanel[i0 + 256 * u] = v[u];
+                if (i0 + SWEEP_THREADS * u < KS * 64) dpanel[i0 + SWEEP_THREADS * u] = v[u];
         }
     }
     const double* xop = a.xop + OgGen::MV_Y0(slot);   // base operands, written by mode 0
-    for (int l = tid; l < KS * 4; l += 256) xt[l] = (l < N) ? xop[l] : 0.0;
+    for (int l = tid; l < KS * 4; l += SWEEP_THREADS) xt[l] = (l < N) ? xop[l] : 0.0;
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
-    const int l0 = (mt4 * 4 + wave) * 16;             // first slice offset of this wave's tile
+    const int l0 = (mt4 * SWEEP_WAVES + wave) * 16;   // first slice offset of this wave's tile
     if (l0 >= N) return;
     const int jlo = leaf + l0;
     if (jlo >= a.col_hi || jlo + 16 <= a.col_lo) return;   // tile outside this rank's columns
 
+#if OGK_TRACE
+    t_staged = __builtin_amdgcn_s_memtime();
+#endif
     // A operand: row (lane & 15) is the state vector with its own element perturbed
     const int la = l0 + (lane & 15);
     double hit_v = 0.0;
@@ -466,6 +494,9 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, dpanel[ks * 64 + lane], acc, 0, 0, 0);
     }
 
+#if OGK_TRACE
+    t_mfma = __builtin_amdgcn_s_memtime();
+#endif
     const int k = nt * 16 + (lane & 15);
     if (k >= N) return;
     const int row = row0 + k;
@@ -473,7 +504,6 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     const double f_base = a.f0[row];
     const int dep0 = OgGen::G_DEP0(g), ndep = OgGen::G_NDEP(g);
     const bool diag = OgGen::MV_DIAG(slot) != 0, generic = OgGen::MV_GENERIC(slot) != 0;
-    double T[OgGen::MAX_NMV];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int lc = l0 + lk + 4 * reg;
@@ -494,17 +524,22 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
         double t = t_base;
         if (reads) {
             const XCol xa{a.x0, j, xj};
-            OgGen::defect_tail(g, k, xa, a.cvec, T);
-#pragma unroll
-            for (int s = 0; s < OgGen::MAX_NMV; ++s)
-                if (s == s_local) t = T[s];
+            t = OgGen::tail_one(slot, k, xa, a.cvec);      // this state's dynamics term only
         }
         const double val = acc[reg] - t;
         a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - f_base) / dx;
     }
+#if OGK_TRACE
+    if (lane == 0 && leaf + l0 >= a.col_lo && leaf + l0 < a.col_hi) {
+        __builtin_amdgcn_s_waitcnt(0);
+        double* t = a.jt + (long)(leaf + l0 - a.col_lo) * OgGen::M + row0 + nt * 16;
+        t[0] = 2.0e6 + wave; t[1] = (double)t_begin; t[2] = (double)t_staged; t[3] = (double)t_mfma;
+        t[4] = (double)__builtin_amdgcn_s_memtime(); t[5] = (double)bx;
+    }
+#endif
 }
 
-__global__ __launch_bounds__(256) void ogk_sweep(const ogk_args a, const int ntiles) {
+__global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a, const int ntiles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
     if (id < ntiles) {
@@ -542,7 +577,7 @@ int tile_blocks() {
     int nb = 0;
     for (int s = 0; s < OgGen::N_MV; ++s) {
         const int t16 = (OgGen::MV_LEN(s) + 15) >> 4;
-        nb += ((t16 + 3) >> 2) * t16;
+        nb += ((t16 + SWEEP_WAVES - 1) / SWEEP_WAVES) * t16;
     }
     return nb;
 }
@@ -593,7 +628,8 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         // [col_lo, col_hi) inside the kernel
         const int ntiles = tile_blocks();
         const int light_blocks = (OgGen::N_VAR - OgGen::N_HEAVY + LIGHT_COLS - 1) / LIGHT_COLS;
-        hipLaunchKernelGGL(ogk_sweep, dim3(ntiles + OgGen::N_HEAVY + light_blocks), dim3(256),
+        hipLaunchKernelGGL(ogk_sweep, dim3(ntiles + OgGen::N_HEAVY + light_blocks),
+                           dim3(SWEEP_THREADS),
                            sweep_lds_bytes(), stream, *args, ntiles);
         return (int)hipGetLastError();
     }

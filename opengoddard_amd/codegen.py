@@ -824,7 +824,51 @@ def emit_header(P):
     for gi in range(len(P.groups)):
         L.append("        case %d: group%d(k, x, y, cv, out); break;" % (gi, gi))
     L += ["        default: break;", "        }", "    }", "};", ""]
+    L += _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, slot_group,
+                        y0_off, mv_diag, mv_generic, g_dep0, g_ndep)
     return "\n".join(L)
+
+
+SWEEP_WAVES = 8          # wavefronts per ogk_sweep workgroup (csrc/ogk_kernels.hip)
+
+
+def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, slot_group, y0_off,
+                   mv_diag, mv_generic, g_dep0, g_ndep):
+    """Wide, aligned device tables so that a workgroup of the structured sweep learns everything
+    about its column / item / MFMA tile from ONE load each (every dependent global load costs
+    a few hundred cycles, and the sweep of a small problem is a chain of them)."""
+    def table(ctype, name, rows):
+        rows = rows or [[0] * (4 if ctype == "int4" else 8)]
+        body = ",\n".join("    {%s}" % ", ".join(str(int(v)) for v in r) for r in rows)
+        return ["static __device__ const %s %s[%d] = {" % (ctype, name, len(rows)), body, "};"]
+    heavy_set = set(heavy)
+    col = [[col_ptr[j], col_ptr[j + 1], own_lo[j], own_hi[j] | ((1 << 30) if j in heavy_set else 0)]
+           for j in range(P.n)]
+    elem = [[g, o, k, 0] for g, o, k in zip(elem_g, elem_o, elem_k)]
+    tiles, slots = [], []
+    for si, sl in enumerate(P.mv):
+        t16 = (sl.length + 15) // 16
+        for mtg in range((t16 + SWEEP_WAVES - 1) // SWEEP_WAVES):
+            for nt in range(t16):
+                tiles.append([si, mtg, nt, 0])
+        gi = slot_group[si]
+        g = P.groups[gi]
+        row0 = g.outputs[si - g.mv_slots[0]][0]
+        slots.append([sl.length, gi, sl.leaf_base, row0, y0_off[si], sl.phase,
+                      mv_diag[si] | (mv_generic[si] << 1), (g_dep0[gi] << 12) | g_ndep[gi]])
+    L = ["#if defined(__HIPCC__)", "struct ogt_int8 { int v[8]; };"]
+    L += table("int4", "OGT_COL", col)
+    L += table("int4", "OGT_ELEM", elem)
+    L += table("int4", "OGT_TILE", tiles)
+    L += table("ogt_int8", "OGT_SLOT", [[r] for r in []] or None) if False else \
+        ["static __device__ const ogt_int8 OGT_SLOT[%d] = {" % max(len(slots), 1),
+         ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (slots or [[0] * 8])),
+         "};"]
+    L += ["static constexpr int OGT_N_TILES = %d;" % len(tiles),
+          "static __device__ const int OGT_HEAVY[%d] = {%s};" % (
+              max(len(heavy), 1), ", ".join(str(j) for j in heavy) or "0"),
+          "#endif", ""]
+    return L
 
 
 def program_hash(source):

@@ -306,21 +306,30 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
 }
 
 // ------------------------------------------------------------------------------------------
-// Mode 1, part A: the J_T rows (= FD columns).  The owner of a row streams the "no dependency"
-// value into it and then re-evaluates the (group, element) items that read p[j]; the item
-// lists come from the tracer (COL_PTR / ELEM_G / ELEM_K).  Evaluation is latency-bound (a
-// dependent f64 op costs ~13 ns on gfx950), so the mapping is chosen to keep chains short and
-// wavefronts convergent:
-//   heavy_column_body  a column with many items (phase final times): one workgroup, lanes =
-//                      consecutive items (= consecutive nodes of one group: same code);
-//   light_columns_body 16 neighbouring columns per workgroup: lane = column, wavefront = item
-//                      slot, so the items of one column run concurrently in different
-//                      wavefronts and neighbouring columns (same slice, next node) share code.
+// Mode 1: the structured sweep.  At the sizes this engine sees (n ~ 10^2..10^4) a sweep is a
+// chain of dependent global loads and dependent f64 operations (~13 ns each on gfx950), so the
+// layout below is about latency: every workgroup learns its job from one wide record
+// (OGT_COL / OGT_ELEM / OGT_TILE / OGT_SLOT, generated by the tracer), issues all its loads up
+// front, and the long arithmetic chains (one traced output each) run in different wavefronts.
+//
+// Part A - J_T rows (= FD columns).  The owner of a row streams the "no dependency" value into
+//   it and then re-evaluates the (group, output, element) items that read p[j].
+//     heavy_column_body   a column with many items (phase final times): one workgroup, lanes =
+//                         consecutive items (consecutive nodes of one output: same code);
+//     light_columns_body  LIGHT_COLS neighbouring columns per workgroup: lane = column,
+//                         wavefront = item slot.
+// Part B - tile_body: d(defect_s)/d(state_s) for one collocation slot on the matrix cores.
 // ------------------------------------------------------------------------------------------
+constexpr int SWEEP_THREADS = 512;   // ogk_sweep workgroup: 8 wavefronts
+constexpr int SWEEP_WAVES = SWEEP_THREADS / 64;
+constexpr int LIGHT_COLS = 4;        // columns per workgroup in light_columns_body
+constexpr int HEAVY_FLAG = 1 << 30;  // in OGT_COL[j].w
+
 __device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const int own_lo,
-                                         const int own_hi, const int first, const int stride) {
+                                         const int own_hi, const int first, const int stride,
+                                         const bool all_finite) {
     if (OGK_EXP & 16) return;
-    if (*a.nonfinite == 0) {        // every row of F(x0) is finite: (F0-F0)/dx is plain zero
+    if (all_finite) {               // every row of F(x0) is finite: (F0-F0)/dx is plain zero
         for (int r = first; r < OgGen::M; r += stride)
             if (r < own_lo || r >= own_hi) jrow[r] = 0.0;
     } else {                        // z carries NaN for the non-finite rows
@@ -329,95 +338,80 @@ __device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const 
     }
 }
 
-__device__ __forceinline__ void eval_item(const ogk_args& a, const int e, const XCol& xa,
+__device__ __forceinline__ void eval_item(const ogk_args& a, const int4 item, const XCol& xa,
                                           const double dx, double* jrow) {
     int row;
-    const double v = OgGen::item_value(OgGen::ELEM_G(e), OgGen::ELEM_O(e), OgGen::ELEM_K(e), xa,
-                                       a.y0, a.cvec, &row);
+    const double v = OgGen::item_value(item.x, item.y, item.z, xa, a.y0, a.cvec, &row);
     jrow[row] = (v - a.f0[row]) / dx;
 }
 
-constexpr int SWEEP_THREADS = 512;   // ogk_sweep workgroup: 8 wavefronts
-constexpr int SWEEP_WAVES = SWEEP_THREADS / 64;
-
 __device__ __forceinline__ void heavy_column_body(const ogk_args& a, const int j) {
     const int tid = (int)threadIdx.x;
-    const int own_lo = OgGen::COL_OWN_LO(j), own_hi = OgGen::COL_OWN_HI(j);
-    const int e0 = OgGen::COL_PTR(j), e1 = OgGen::COL_PTR(j + 1);
+    const int4 col = OGT_COL[j];
+    const int own_lo = col.z, own_hi = col.w & ~HEAVY_FLAG;
     const double xb = a.x0[j];
     const double xj = xb + a.h[j];
     const double dx = xj - xb;
+    const bool all_finite = *a.nonfinite == 0;
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    fill_row(a, jrow, own_lo, own_hi, tid, SWEEP_THREADS);
+    fill_row(a, jrow, own_lo, own_hi, tid, SWEEP_THREADS, all_finite);
     __syncthreads();                 // fill stores before item stores to the same addresses
     const XCol xa{a.x0, j, xj};
-    for (int e = e0 + tid; e < ((OGK_EXP & 8) ? 0 : e1); e += SWEEP_THREADS)
-        eval_item(a, e, xa, dx, jrow);
+    for (int e = col.x + tid; e < ((OGK_EXP & 8) ? 0 : col.y); e += SWEEP_THREADS)
+        eval_item(a, OGT_ELEM[e], xa, dx, jrow);
 }
 
-constexpr int LIGHT_COLS = 4;        // columns per workgroup in light_columns_body
-
-__device__ __forceinline__ void light_columns_body(const ogk_args& a, const int first_li) {
+__device__ __forceinline__ void light_columns_body(const ogk_args& a, const int first_j) {
     const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
 #if OGK_TRACE
     const long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- fill the rows: SWEEP_WAVES / LIGHT_COLS wavefronts share one row
-    {
-        constexpr int WPR = SWEEP_WAVES / LIGHT_COLS;           // wavefronts per row
-        const int c = (tid >> 6) / WPR, part = (tid >> 6) % WPR;
-        const int li = first_li + c;
-        if (li < OgGen::N_VAR) {
-            const int j = OgGen::COL_ORDER(li);
-            if (j >= a.col_lo && j < a.col_hi)
-                fill_row(a, a.jt + (long)(j - a.col_lo) * OgGen::M, OgGen::COL_OWN_LO(j),
-                         OgGen::COL_OWN_HI(j), part * 64 + (tid & 63), 64 * WPR);
-        }
-    }
+    // ---- everything this thread will need, requested before anything is waited for
+    constexpr int WPR = SWEEP_WAVES / LIGHT_COLS;               // wavefronts sharing one row
+    const int jf = first_j + wave / WPR;                        // the row this wavefront fills
+    const int ji = first_j + lane;                              // the column this lane evaluates
+    const bool fill_on = jf < a.col_hi;
+    const bool item_on = lane < LIGHT_COLS && ji < a.col_hi;
+    const int4 colf = OGT_COL[fill_on ? jf : a.col_lo];
+    const int4 coli = OGT_COL[item_on ? ji : a.col_lo];
+    const double xb = a.x0[item_on ? ji : a.col_lo];
+    const double hh = a.h[item_on ? ji : a.col_lo];
+    const bool all_finite = *a.nonfinite == 0;
+    int4 item = make_int4(0, 0, 0, 0);
+    const bool has_item = item_on && !(coli.w & HEAVY_FLAG) && coli.x + wave < coli.y;
+    if (has_item) item = OGT_ELEM[coli.x + wave];
+
+    // ---- fill (heavy columns are filled by their own workgroup)
+    if (fill_on && !(colf.w & HEAVY_FLAG))
+        fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, colf.z, colf.w, (wave % WPR) * 64 + lane,
+                 64 * WPR, all_finite);
     __syncthreads();                 // fill stores before item stores to the same addresses
 #if OGK_TRACE
     const long long t_filled = __builtin_amdgcn_s_memtime();
 #endif
+    if (!has_item) return;
     // ---- items: lane = column, wavefront = item slot
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = first_li + lane;
-    if (lane >= LIGHT_COLS || li >= OgGen::N_VAR) return;
-    const int j = OgGen::COL_ORDER(li);
-    if (j < a.col_lo || j >= a.col_hi) return;
-    const int e0 = OgGen::COL_PTR(j), e1 = OgGen::COL_PTR(j + 1);
-    if (e0 + wave >= e1) return;
-    const double xb = a.x0[j];
-    const double xj = xb + a.h[j];
+    const double xj = xb + hh;
     const double dx = xj - xb;
-    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    const XCol xa{a.x0, j, xj};
+    double* jrow = a.jt + (long)(ji - a.col_lo) * OgGen::M;
+    const XCol xa{a.x0, ji, xj};
 #if OGK_TRACE
     const long long t_ready = __builtin_amdgcn_s_memtime();
 #endif
-    for (int e = e0 + wave; e < ((OGK_EXP & 8) ? 0 : e1); e += SWEEP_WAVES)
-        eval_item(a, e, xa, dx, jrow);
+    if (!(OGK_EXP & 8)) {
+        eval_item(a, item, xa, dx, jrow);
+        for (int e = coli.x + wave + SWEEP_WAVES; e < coli.y; e += SWEEP_WAVES)
+            eval_item(a, OGT_ELEM[e], xa, dx, jrow);
+    }
 #if OGK_TRACE
     if (lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         double* t = jrow + 8 * wave;
         t[0] = 1.0e6 + wave; t[1] = (double)t_begin; t[2] = (double)t_filled; t[3] = (double)t_ready;
-        t[4] = (double)__builtin_amdgcn_s_memtime(); t[5] = (double)(e1 - e0);
+        t[4] = (double)__builtin_amdgcn_s_memtime(); t[5] = (double)(coli.y - coli.x);
     }
 #endif
-}
-
-// ------------------------------------------------------------------------------------------
-// Mode 1, part B: d(defect_s)/d(state_s) for one collocation slot: (64 columns of the slice)
-// x (16-node tile) per workgroup, one 16-column MFMA tile per wavefront.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tile_block_to_slot(int bx, int* mt4_out, int* nt_out) {
-    for (int s = 0; s < OgGen::N_MV; ++s) {
-        const int t16 = (OgGen::MV_LEN(s) + 15) >> 4;
-        const int per = ((t16 + SWEEP_WAVES - 1) / SWEEP_WAVES) * t16;
-        if (bx < per) { *mt4_out = bx / t16; *nt_out = bx % t16; return s; }
-        bx -= per;
-    }
-    return -1;
 }
 
 __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, double* lds) {
@@ -425,56 +419,82 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     const long long t_begin = __builtin_amdgcn_s_memtime();
     long long t_staged = 0, t_mfma = 0;
 #endif
-    int mt4 = 0, nt = 0;
-    const int slot = tile_block_to_slot(bx, &mt4, &nt);
-    if (slot < 0) return;
-    const int N = OgGen::MV_LEN(slot);
+    const int4 tile = OGT_TILE[bx];                    // {slot, tile group, node tile}
+    const int slot = tile.x, nt = tile.z;
+    const ogt_int8 rec = OGT_SLOT[slot];
+    const int N = rec.v[0], g = rec.v[1], leaf = rec.v[2], row0 = rec.v[3], y0off = rec.v[4];
+    const bool diag = rec.v[6] & 1, generic = rec.v[6] & 2;
+    const int dep0 = rec.v[7] >> 12, ndep = rec.v[7] & 0xfff;
     const int KS = (N + 3) >> 2;
-    const int g = OgGen::MV_GROUP(slot);
-    const int s_local = slot - OgGen::G_MV0(g);
-    const int leaf = OgGen::MV_LEAF(slot);
-    const int row0 = OgGen::G_ROW(g, s_local);
     const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
+    const int l0 = (tile.y * SWEEP_WAVES + wave) * 16;  // first slice offset of this wave's tile
+    const int k = nt * 16 + (lane & 15);                // output node of this lane
+    const int la = l0 + (lane & 15);                    // A-operand row of this lane
+    const bool wave_on = l0 < N && leaf + l0 < a.col_hi && leaf + l0 + 16 > a.col_lo;
 
+    // ---- requests first: D panel, base operands, this lane's perturbation, epilogue inputs
     double* dpanel = lds;
     double* xt = lds + KS * 64;
-    const double* src = a.dfrag + a.dfrag_off[OgGen::MV_PHASE(slot)] + (long)nt * KS * 64;
-    {
-        // all loads of the panel in flight before the first LDS store (latency paid once)
-        constexpr int UNR = 8;
-        for (int i0 = tid; i0 < KS * 64; i0 += SWEEP_THREADS * UNR) {
-            double v[UNR];
+    const double* src = a.dfrag + a.dfrag_off[rec.v[5]] + (long)nt * KS * 64;
+    const double* xop = a.xop + y0off;                  // base operands, written by mode 0
+    constexpr int UNR = 4;
+    double pv[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u)
-                v[u] = (i0 + SWEEP_THREADS * u < KS * 64) ? src[i0 + SWEEP_THREADS * u] : 0.0;
+    for (int u = 0; u < UNR; ++u)
+        pv[u] = (tid + SWEEP_THREADS * u < KS * 64) ? src[tid + SWEEP_THREADS * u] : 0.0;
+    const double xo = (tid < KS * 4 && tid < N) ? xop[tid] : 0.0;
+    const bool a_on = wave_on && la < N;
+    const double xa_b = a.x0[a_on ? leaf + la : leaf];
+    const double xa_h = a.h[a_on ? leaf + la : leaf];
+    const bool k_on = wave_on && k < N;
+    const int row = row0 + (k_on ? k : 0);
+    const double t_base = a.t0[row];
+    const double f_base = a.f0[row];
+    double xbv[4], hv[4];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u)
-                if (i0 + SWEEP_THREADS * u < KS * 64) dpanel[i0 + SWEEP_THREADS * u] = v[u];
-        }
+    for (int reg = 0; reg < 4; ++reg) {
+        const int lc = l0 + lk + 4 * reg;
+        const int jj = leaf + ((k_on && lc < N) ? lc : 0);
+        xbv[reg] = a.x0[jj];
+        hv[reg] = a.h[jj];
     }
-    const double* xop = a.xop + OgGen::MV_Y0(slot);   // base operands, written by mode 0
-    for (int l = tid; l < KS * 4; l += SWEEP_THREADS) xt[l] = (l < N) ? xop[l] : 0.0;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+        if (tid + SWEEP_THREADS * u < KS * 64) dpanel[tid + SWEEP_THREADS * u] = pv[u];
+    for (int i = tid + SWEEP_THREADS * UNR; i < KS * 64; i += SWEEP_THREADS) dpanel[i] = src[i];
+    if (tid < KS * 4) xt[tid] = xo;
+    for (int l = tid + SWEEP_THREADS; l < KS * 4; l += SWEEP_THREADS) xt[l] = (l < N) ? xop[l] : 0.0;
     __syncthreads();
-
-    const int wave = tid >> 6, lane = tid & 63;
-    const int l0 = (mt4 * SWEEP_WAVES + wave) * 16;   // first slice offset of this wave's tile
-    if (l0 >= N) return;
-    const int jlo = leaf + l0;
-    if (jlo >= a.col_hi || jlo + 16 <= a.col_lo) return;   // tile outside this rank's columns
-
+    if (!wave_on) return;
 #if OGK_TRACE
     t_staged = __builtin_amdgcn_s_memtime();
 #endif
+
+    // ---- the dynamics term on the diagonal (k == own perturbed node) does not depend on the
+    //      MFMA result: start its chain first so that it overlaps the matrix-core work
+    double t_diag = t_base;
+    bool have_diag = false;
+    {
+        const int lc = k;                                // column whose perturbed node is k
+        const int reg = (lc - l0 - lk) >> 2;
+        have_diag = diag && k_on && lc >= l0 + lk && ((lc - l0 - lk) & 3) == 0 && reg < 4 && lc < N &&
+                    leaf + lc >= a.col_lo && leaf + lc < a.col_hi;
+        if (have_diag) {
+            const int jd = leaf + lc;
+            const double xbd = a.x0[jd];
+            const XCol xd{a.x0, jd, xbd + a.h[jd]};
+            t_diag = OgGen::tail_one(slot, k, xd, a.cvec);
+        }
+    }
+
     // A operand: row (lane & 15) is the state vector with its own element perturbed
-    const int la = l0 + (lane & 15);
     double hit_v = 0.0;
-    if (la < N) {
-        const int ja = leaf + la;
-        const XCol xa{a.x0, ja, a.x0[ja] + a.h[ja]};
+    if (a_on) {
+        const XCol xa{a.x0, leaf + la, xa_b + xa_h};
         hit_v = OgGen::mv_operand(slot, la, xa, a.cvec);
     }
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    const int lk = lane >> 4;
     int ks = 0;
     for (; ks + 4 <= KS; ks += 4) {          // operands of 4 steps in flight before the MFMAs
         double av[4], bv[4];
@@ -493,38 +513,31 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
         const double av = (l == la) ? hit_v : xt[l];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, dpanel[ks * 64 + lane], acc, 0, 0, 0);
     }
-
 #if OGK_TRACE
     t_mfma = __builtin_amdgcn_s_memtime();
 #endif
-    const int k = nt * 16 + (lane & 15);
-    if (k >= N) return;
-    const int row = row0 + k;
-    const double t_base = a.t0[row];
-    const double f_base = a.f0[row];
-    const int dep0 = OgGen::G_DEP0(g), ndep = OgGen::G_NDEP(g);
-    const bool diag = OgGen::MV_DIAG(slot) != 0, generic = OgGen::MV_GENERIC(slot) != 0;
+    if (!k_on) return;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int lc = l0 + lk + 4 * reg;
         const int j = leaf + lc;
         if (lc >= N || j < a.col_lo || j >= a.col_hi) continue;
-        const double xb = a.x0[j];
-        const double xj = xb + a.h[j];
-        const double dx = xj - xb;
-        // does the dynamics term of node k read p[j]?  Normally only on the diagonal k == lc
-        // (the state appears in its phase's dynamics); anything else takes the table scan.
-        bool reads = diag && k == lc;
-        if (generic)
+        const double xj = xbv[reg] + hv[reg];
+        const double dx = xj - xbv[reg];
+        double t = (have_diag && lc == k) ? t_diag : t_base;
+        if (generic) {
+            // rare: the dynamics term of node k reads p[j] through something other than the
+            // state's own sample at k - take the dependency-table scan
+            bool reads = diag && k == lc;
             for (int d = dep0; d < dep0 + ndep; ++d) {
                 const int kind = OgGen::DEP_KIND(d), base_d = OgGen::DEP_BASE(d);
                 reads = reads || (kind == 1 ? (base_d + k == j)
                                             : (j >= base_d && j < base_d + OgGen::DEP_CNT(d)));
             }
-        double t = t_base;
-        if (reads) {
-            const XCol xa{a.x0, j, xj};
-            t = OgGen::tail_one(slot, k, xa, a.cvec);      // this state's dynamics term only
+            if (reads) {
+                const XCol xg{a.x0, j, xj};
+                t = OgGen::tail_one(slot, k, xg, a.cvec);
+            }
         }
         const double val = acc[reg] - t;
         a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - f_base) / dx;
@@ -539,19 +552,19 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
 #endif
 }
 
-__global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a, const int ntiles) {
+__global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
-    if (id < ntiles) {
+    if (id < OGT_N_TILES) {
         // MFMA tiles have the longest dependent chain: dispatch them first
         if (!(OGK_EXP & 32)) tile_body(a, id, lds);
-    } else if (id < ntiles + OgGen::N_HEAVY) {
-        // then the columns with many dependent elements (e.g. phase final times): a workgroup each
-        const int j = OgGen::COL_ORDER(id - ntiles);
+    } else if (id < OGT_N_TILES + OgGen::N_HEAVY) {
+        // then the columns with many dependent items (e.g. phase final times): a workgroup each
+        const int j = OGT_HEAVY[id - OGT_N_TILES];
         if (j >= a.col_lo && j < a.col_hi) heavy_column_body(a, j);
     } else {
-        // all other columns, 16 per workgroup
-        light_columns_body(a, OgGen::N_HEAVY + (id - ntiles - OgGen::N_HEAVY) * LIGHT_COLS);
+        // all columns of this launch, LIGHT_COLS per workgroup
+        light_columns_body(a, a.col_lo + (id - OGT_N_TILES - OgGen::N_HEAVY) * LIGHT_COLS);
     }
 }
 
@@ -571,15 +584,6 @@ size_t defect_lds_bytes() {
         worst = need > worst ? need : worst;
     }
     return worst;
-}
-
-int tile_blocks() {
-    int nb = 0;
-    for (int s = 0; s < OgGen::N_MV; ++s) {
-        const int t16 = (OgGen::MV_LEN(s) + 15) >> 4;
-        nb += ((t16 + SWEEP_WAVES - 1) / SWEEP_WAVES) * t16;
-    }
-    return nb;
 }
 
 size_t sweep_lds_bytes() {
@@ -624,13 +628,9 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     const int ncols = args->col_hi - args->col_lo;
     if (ncols <= 0) return 0;
     if (mode == 1) {
-        // every column has a workgroup/wavefront slot; a rank's launch skips columns outside
-        // [col_lo, col_hi) inside the kernel
-        const int ntiles = tile_blocks();
-        const int light_blocks = (OgGen::N_VAR - OgGen::N_HEAVY + LIGHT_COLS - 1) / LIGHT_COLS;
-        hipLaunchKernelGGL(ogk_sweep, dim3(ntiles + OgGen::N_HEAVY + light_blocks),
-                           dim3(SWEEP_THREADS),
-                           sweep_lds_bytes(), stream, *args, ntiles);
+        const int light_blocks = (ncols + LIGHT_COLS - 1) / LIGHT_COLS;
+        hipLaunchKernelGGL(ogk_sweep, dim3(OGT_N_TILES + OgGen::N_HEAVY + light_blocks),
+                           dim3(SWEEP_THREADS), sweep_lds_bytes(), stream, *args);
         return (int)hipGetLastError();
     }
     const int defect_total = ndef * ((ncols + 63) / 64);

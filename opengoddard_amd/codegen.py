@@ -856,7 +856,14 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
         row0 = g.outputs[si - g.mv_slots[0]][0]
         slots.append([sl.length, gi, sl.leaf_base, row0, y0_off[si], sl.phase,
                       mv_diag[si] | (mv_generic[si] << 1), (g_dep0[gi] << 12) | g_ndep[gi]])
+    rowwaves = []
+    for gi, g in enumerate(P.groups):
+        if g.kind == "rows":
+            for k0 in range(0, g.length, 64):
+                rowwaves.append([gi, k0, 0, 0])
     L = ["#if defined(__HIPCC__)", "struct ogt_int8 { int v[8]; };"]
+    L += table("int4", "OGT_ROWWAVE", rowwaves)
+    L.append("static constexpr int OGT_N_ROWWAVES = %d;" % len(rowwaves))
     L += table("int4", "OGT_COL", col)
     L += table("int4", "OGT_ELEM", elem)
     L += table("int4", "OGT_TILE", tiles)

@@ -15,7 +15,7 @@
 // decision vector goes through XCol, which returns x0[i] except at i == j.
 //
 // Three launch modes (ogk_launch):
-//   0  ogk_dense<false>  F(x0) -> f0, plus scratch the sweep reuses: the unperturbed collocation
+//   0  ogk_eval          F(x0) -> f0, plus scratch the sweep reuses: the unperturbed collocation
 //                        products y0, the dynamics terms t0 = (tf-t0)/2 f, and z = F0 - F0
 //                        (0, or NaN where a row is not finite: what dense FD would produce).
 //   1  ogk_sweep         structured forward-difference sweep (default).  Dense FD evaluates
@@ -31,7 +31,7 @@
 //                            vectors, B = D^T panel staged in LDS in operand order), writing
 //                            the dense N x N block d(defect_s)/d(state_s) directly.
 //                        The result is identical to mode 2 (tests compare them and the CPU twin).
-//   2  ogk_dense<true>   the literal dense sweep: all rows for all columns (validation, and the
+//   2  ogk_dense         the literal dense sweep: all rows for all columns (validation, and the
 //                        shape SURVEY.md section 7.2 describes).
 //
 // The MFMA accumulation is a k-ordered fma chain per output (verified on hardware by
@@ -88,11 +88,11 @@ __device__ __forceinline__ int defect_block_to_group(int bx, int* nt_out) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Collocation workgroup of modes 0 and 2: (phase, 16-node tile, 64 FD columns), all states.
+// Mode 2, dense sweep (validation): collocation workgroup = (phase, 16-node tile, 64 FD
+// columns), all states; row workgroup = one thread per (row item, 8 columns).
 // ------------------------------------------------------------------------------------------
-template <bool SWEEP>
-__device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, const int by,
-                                            double* lds) {
+__device__ __forceinline__ void dense_defect_body(const ogk_args& a, const int bx, const int by,
+                                                  double* lds) {
     int nt;
     const int g = defect_block_to_group(bx, &nt);
     if (g < 0) return;
@@ -104,9 +104,6 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
     const int nmv = OgGen::G_NMV(g);
     const int tid = (int)threadIdx.x;
 
-    // ---- stage the D panel (MFMA B-operand order) and the base operands in LDS.  Operand
-    //      entries are laid out [slot][NP]; each wavefront works on one slot at a time so the
-    //      generated switch in mv_operand never diverges.
     double* dpanel = lds;
     double* xt = lds + KS * 64;
     const double* src = a.dfrag + a.dfrag_off[phase] + (long)nt * KS * 64;
@@ -115,69 +112,18 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
     {
         const int wave_ = tid >> 6, lane_ = tid & 63;
         for (int s = wave_; s < OgGen::MAX_NMV; s += 4)
-            for (int l = lane_; l < NP; l += 64) {
-                double v = 0.0;
-                if (s < nmv && l < N && !(OGK_EXP & 4)) {
-                    v = OgGen::mv_operand(mv0 + s, l, base, a.cvec);
-                    if (!SWEEP && nt == 0) a.xop[OgGen::MV_Y0(mv0 + s) + l] = v;
-                }
-                xt[s * NP + l] = v;
-            }
+            for (int l = lane_; l < NP; l += 64)
+                xt[s * NP + l] = (s < nmv && l < N) ? OgGen::mv_operand(mv0 + s, l, base, a.cvec) : 0.0;
     }
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
-    if (!SWEEP && wave != 0) return;
-    const int c0 = SWEEP ? a.col_lo + (by * 4 + wave) * 16 : 0;
-    if (SWEEP && c0 >= a.col_hi) return;
+    const int c0 = a.col_lo + (by * 4 + wave) * 16;
+    if (c0 >= a.col_hi) return;
     const int lk = lane >> 4;
     const int k = nt * 16 + (lane & 15);
-    double y[OgGen::MAX_NMV];
-    double T[OgGen::MAX_NMV];
 
-    if (!SWEEP) {
-        // ---- single evaluation: the states are the 16 rows of the A operand, so one MFMA chain
-        //      yields every state's collocation product for this node tile.
-        const int srow = lane & 15;
-        v4f64 acc1 = {0.0, 0.0, 0.0, 0.0};
-        const double* xrow = xt + (srow < OgGen::MAX_NMV ? srow : 0) * NP;
-        const bool live = srow < nmv;
-        for (int ks = 0; ks < ((OGK_EXP & 1) ? 0 : KS); ++ks) {
-            const double av = live ? xrow[ks * 4 + lk] : 0.0;
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, dpanel[ks * 64 + lane], acc1, 0, 0, 0);
-        }
-        // C/D layout: node = lane & 15, state = (lane >> 4) + 4 * reg.  Exchange through LDS so
-        // that one lane per node sees all states.
-        // (one wavefront: its LDS stores and loads execute in program order, no barrier needed)
-        double* ybuf = xt + OgGen::MAX_NMV * NP;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) ybuf[(lk + 4 * reg) * 16 + (lane & 15)] = acc1[reg];
-        if (lane >= 16 || k >= N) return;
-#pragma unroll
-        for (int s = 0; s < OgGen::MAX_NMV; ++s) y[s] = ybuf[s * 16 + lane];
-        if (OGK_EXP & 2) {
-#pragma unroll
-            for (int s = 0; s < OgGen::MAX_NMV; ++s) T[s] = 0.0;
-        } else {
-            OgGen::defect_tail(g, k, base, a.cvec, T);
-        }
-#pragma unroll
-        for (int s = 0; s < OgGen::MAX_NMV; ++s) {
-            if (s >= nmv) break;
-            const int row = OgGen::G_ROW(g, s) + k;
-            const double val = y[s] - T[s];
-            const double zz = val - val;
-            a.f0[row] = val;
-            a.z[row] = zz;
-            if (zz != zz) atomicAdd(a.nonfinite, 1);
-            a.t0[row] = T[s];
-            a.y0[OgGen::MV_Y0(mv0 + s) + k] = y[s];
-        }
-        return;
-    }
-
-    // ---- dense sweep: the column this lane feeds into the A operand, and the one operand entry
-    //      it changes
+    // the column this lane feeds into the A operand, and the one operand entry it changes
     int hit_s = -1, hit_l = -1;
     double hit_v = 0.0;
     {
@@ -195,12 +141,12 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
         }
     }
 
-    // ---- batched D.X on the matrix cores: acc[s] (16 columns x 16 nodes) += A_s (16x4) * B (4x16)
-    //      (branch-free over MAX_NMV: unused slots multiply zeros)
+    // batched D.X on the matrix cores: acc[s] (16 columns x 16 nodes) += A_s (16x4) * B (4x16)
+    // (branch-free over MAX_NMV: unused slots multiply zeros)
     v4f64 acc[OgGen::MAX_NMV];
 #pragma unroll
     for (int s = 0; s < OgGen::MAX_NMV; ++s) acc[s] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    for (int ks = 0; ks < ((OGK_EXP & 1) ? 0 : KS); ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         const double b = dpanel[ks * 64 + lane];
         const int l = ks * 4 + lk;
 #pragma unroll
@@ -211,9 +157,11 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
         }
     }
 
-    // ---- epilogue.  C/D layout of the f64 MFMA: column (node) = lane & 15,
-    //      row (FD column) = (lane >> 4) + 4 * reg.
+    // epilogue.  C/D layout of the f64 MFMA: column (node) = lane & 15,
+    // row (FD column) = (lane >> 4) + 4 * reg.
     if (k >= N) return;
+    double y[OgGen::MAX_NMV];
+    double T[OgGen::MAX_NMV];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int j = c0 + lk + 4 * reg;
@@ -224,12 +172,7 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
 #pragma unroll
         for (int s = 0; s < OgGen::MAX_NMV; ++s) y[s] = acc[s][reg];
         const XCol xa{a.x0, j, xj};
-        if (OGK_EXP & 2) {
-#pragma unroll
-            for (int s = 0; s < OgGen::MAX_NMV; ++s) T[s] = xj;
-        } else {
-            OgGen::defect_tail(g, k, xa, a.cvec, T);
-        }
+        OgGen::defect_tail(g, k, xa, a.cvec, T);
 #pragma unroll
         for (int s = 0; s < OgGen::MAX_NMV; ++s) {     // static index: keeps y/T in registers
             if (s >= nmv) break;
@@ -240,9 +183,7 @@ __device__ __forceinline__ void defect_body(const ogk_args& a, const int bx, con
     }
 }
 
-// Row workgroup of modes 0 and 2: one thread per (row item, 8 columns).
-template <bool SWEEP>
-__device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const int by) {
+__device__ __forceinline__ void dense_rows_body(const ogk_args& a, const int bx, const int by) {
     const int ri = bx * 256 + (int)threadIdx.x;
     if (ri >= OgGen::N_ROW_ITEMS) return;
     int g = 0;
@@ -255,21 +196,6 @@ __device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const
     const int k = ri - OgGen::G_ITEM0(g);
     const int nout = OgGen::G_NOUT(g);
     double out[OgGen::MAX_OUT];
-    if (!SWEEP) {
-        if (OGK_EXP & 64) return;
-        const XCol base{a.x0, -1, 0.0};
-        OgGen::group_eval(g, k, base, nullptr, a.cvec, out);
-#pragma unroll
-        for (int o = 0; o < OgGen::MAX_OUT; ++o)
-            if (o < nout) {
-                const int row = OgGen::G_ROW(g, o) + k;
-                const double zz = out[o] - out[o];
-                a.f0[row] = out[o];
-                a.z[row] = zz;
-                if (zz != zz) atomicAdd(a.nonfinite, 1);
-            }
-        return;
-    }
     const int j0 = a.col_lo + by * ROWS_COLS_PER_THREAD;
     for (int c = 0; c < ROWS_COLS_PER_THREAD; ++c) {
         const int j = j0 + c;
@@ -289,20 +215,132 @@ __device__ __forceinline__ void rows_body(const ogk_args& a, const int bx, const
     }
 }
 
-template <bool SWEEP>
 __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int ndef,
                                                  const int defect_total, const int row_blocks) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
-    // the evaluation after this one counts into the other slot: clear it now (stream order
-    // makes this visible to the next launch)
-    if (!SWEEP && id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
     if (id < defect_total) {
-        defect_body<SWEEP>(a, id % ndef, id / ndef, lds);
+        dense_defect_body(a, id % ndef, id / ndef, lds);
     } else {
         const int rid = id - defect_total;
-        rows_body<SWEEP>(a, rid % row_blocks, rid / row_blocks);
+        dense_rows_body(a, rid % row_blocks, rid / row_blocks);
     }
+}
+
+constexpr int SWEEP_THREADS = 512;   // ogk_sweep / ogk_eval workgroup: 8 wavefronts
+constexpr int SWEEP_WAVES = SWEEP_THREADS / 64;
+
+// ------------------------------------------------------------------------------------------
+// Mode 0: F(x0) and the scratch the structured sweep reuses.  Collocation workgroup = (phase,
+// 16-node tile): the states are the 16 rows of the A operand, so ONE MFMA chain yields every
+// state's collocation product for the tile; afterwards each wavefront evaluates one state's
+// dynamics term (a short dependent chain each, run concurrently).  Row workgroups: one
+// wavefront per 64 elements of one traced output.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void publish_row(const ogk_args& a, const int row, const double val) {
+    const double zz = val - val;
+    a.f0[row] = val;
+    a.z[row] = zz;
+    if (zz != zz) atomicAdd(a.nonfinite, 1);
+}
+
+__device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx, double* lds) {
+    int nt;
+    const int g = defect_block_to_group(bx, &nt);
+    if (g < 0) return;
+    const int N = OgGen::G_LEN(g);
+    const int KS = (N + 3) >> 2;
+    const int NP = KS * 4;
+    const int mv0 = OgGen::G_MV0(g);
+    const int nmv = OgGen::G_NMV(g);
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
+
+    double* dpanel = lds;
+    double* xt = lds + KS * 64;
+    double* ybuf = xt + OgGen::MAX_NMV * NP;            // [state][16 nodes]
+    const double* src = a.dfrag + a.dfrag_off[OgGen::G_PHASE(g)] + (long)nt * KS * 64;
+    constexpr int UNR = 4;
+    double pv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+        pv[u] = (tid + SWEEP_THREADS * u < KS * 64) ? src[tid + SWEEP_THREADS * u] : 0.0;
+    // operands: one collocation slot per wavefront at a time (no divergence in mv_operand)
+    const XCol base{a.x0, -1, 0.0};
+    for (int s = wave; s < OgGen::MAX_NMV; s += SWEEP_WAVES)
+        for (int l = lane; l < NP; l += 64) {
+            double v = 0.0;
+            if (s < nmv && l < N) {
+                v = OgGen::mv_operand(mv0 + s, l, base, a.cvec);
+                if (nt == 0) a.xop[OgGen::MV_Y0(mv0 + s) + l] = v;
+            }
+            xt[s * NP + l] = v;
+        }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+        if (tid + SWEEP_THREADS * u < KS * 64) dpanel[tid + SWEEP_THREADS * u] = pv[u];
+    for (int i = tid + SWEEP_THREADS * UNR; i < KS * 64; i += SWEEP_THREADS) dpanel[i] = src[i];
+    __syncthreads();
+
+    if (wave == 0) {
+        const int srow = lane & 15;
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* xrow = xt + (srow < OgGen::MAX_NMV ? srow : 0) * NP;
+        const bool live = srow < nmv;
+        int ks = 0;
+        for (; ks + 4 <= KS; ks += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                av[u] = live ? xrow[(ks + u) * 4 + lk] : 0.0;
+                bv[u] = dpanel[(ks + u) * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+        for (; ks < KS; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(live ? xrow[ks * 4 + lk] : 0.0,
+                                                       dpanel[ks * 64 + lane], acc, 0, 0, 0);
+        // C/D layout: node = lane & 15, state = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) ybuf[(lk + 4 * reg) * 16 + (lane & 15)] = acc[reg];
+    }
+    __syncthreads();
+
+    // one state per wavefront: its dynamics term at the tile's 16 nodes
+    const int k = nt * 16 + lane;
+    if (lane >= 16 || k >= N) return;
+    for (int s = wave; s < nmv; s += SWEEP_WAVES) {
+        const double y = ybuf[s * 16 + lane];
+        const double T = OgGen::tail_one(mv0 + s, k, base, a.cvec);
+        const int row = OgGen::G_ROW(g, s) + k;
+        publish_row(a, row, y - T);
+        a.t0[row] = T;
+        a.y0[OgGen::MV_Y0(mv0 + s) + k] = y;
+    }
+}
+
+__device__ __forceinline__ void eval_rows_body(const ogk_args& a, const int bx) {
+    const int w = bx * SWEEP_WAVES + ((int)threadIdx.x >> 6);
+    if (w >= OGT_N_ROWWAVES) return;
+    const int4 rw = OGT_ROWWAVE[w];                       // {group, first element}
+    const int k = rw.y + ((int)threadIdx.x & 63);
+    if (k >= OgGen::G_LEN(rw.x)) return;
+    const XCol base{a.x0, -1, 0.0};
+    int row;
+    const double v = OgGen::item_value(rw.x, 0, k, base, a.y0, a.cvec, &row);
+    publish_row(a, row, v);
+}
+
+__global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, const int ndef) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int id = (int)blockIdx.x;
+    // the evaluation after this one counts into the other slot: clear it now (stream order
+    // makes this visible to the next launch)
+    if (id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
+    if (id < ndef) eval_defect_body(a, id, lds);
+    else eval_rows_body(a, id - ndef);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -320,8 +358,6 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
 //                         wavefront = item slot.
 // Part B - tile_body: d(defect_s)/d(state_s) for one collocation slot on the matrix cores.
 // ------------------------------------------------------------------------------------------
-constexpr int SWEEP_THREADS = 512;   // ogk_sweep workgroup: 8 wavefronts
-constexpr int SWEEP_WAVES = SWEEP_THREADS / 64;
 constexpr int LIGHT_COLS = 4;        // columns per workgroup in light_columns_body
 constexpr int HEAVY_FLAG = 1 << 30;  // in OGT_COL[j].w
 
@@ -329,9 +365,23 @@ __device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const 
                                          const int own_hi, const int first, const int stride,
                                          const bool all_finite) {
     if (OGK_EXP & 16) return;
-    if (all_finite) {               // every row of F(x0) is finite: (F0-F0)/dx is plain zero
-        for (int r = first; r < OgGen::M; r += stride)
-            if (r < own_lo || r >= own_hi) jrow[r] = 0.0;
+    if (all_finite) {
+        // every row of F(x0) is finite: (F0-F0)/dx is plain zero.  16-byte stores on the aligned
+        // pairs that lie wholly outside the tile-owned block, 8-byte stores for the rest.
+        const int a0 = (int)((reinterpret_cast<unsigned long long>(jrow) >> 3) & 1);
+        const double2 zero2 = make_double2(0.0, 0.0);
+        for (int q = first; a0 + 2 * q < OgGen::M; q += stride) {
+            const int r = a0 + 2 * q;
+            const bool in0 = r >= own_lo && r < own_hi;
+            const bool in1 = r + 1 >= own_lo && r + 1 < own_hi;
+            if (r + 1 < OgGen::M && !in0 && !in1) {
+                *reinterpret_cast<double2*>(jrow + r) = zero2;
+            } else {
+                if (!in0) jrow[r] = 0.0;
+                if (r + 1 < OgGen::M && !in1) jrow[r + 1] = 0.0;
+            }
+        }
+        if (a0 && first == 0 && !(0 >= own_lo && 0 < own_hi)) jrow[0] = 0.0;
     } else {                        // z carries NaN for the non-finite rows
         for (int r = first; r < OgGen::M; r += stride)
             if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
@@ -459,20 +509,8 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
         xbv[reg] = a.x0[jj];
         hv[reg] = a.h[jj];
     }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-        if (tid + SWEEP_THREADS * u < KS * 64) dpanel[tid + SWEEP_THREADS * u] = pv[u];
-    for (int i = tid + SWEEP_THREADS * UNR; i < KS * 64; i += SWEEP_THREADS) dpanel[i] = src[i];
-    if (tid < KS * 4) xt[tid] = xo;
-    for (int l = tid + SWEEP_THREADS; l < KS * 4; l += SWEEP_THREADS) xt[l] = (l < N) ? xop[l] : 0.0;
-    __syncthreads();
-    if (!wave_on) return;
-#if OGK_TRACE
-    t_staged = __builtin_amdgcn_s_memtime();
-#endif
-
-    // ---- the dynamics term on the diagonal (k == own perturbed node) does not depend on the
-    //      MFMA result: start its chain first so that it overlaps the matrix-core work
+    // ---- the dynamics term on the diagonal (k == own perturbed node) depends neither on the
+    //      staged data nor on the MFMA result: run its chain while the panel loads are in flight
     double t_diag = t_base;
     bool have_diag = false;
     {
@@ -487,6 +525,18 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
             t_diag = OgGen::tail_one(slot, k, xd, a.cvec);
         }
     }
+
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+        if (tid + SWEEP_THREADS * u < KS * 64) dpanel[tid + SWEEP_THREADS * u] = pv[u];
+    for (int i = tid + SWEEP_THREADS * UNR; i < KS * 64; i += SWEEP_THREADS) dpanel[i] = src[i];
+    if (tid < KS * 4) xt[tid] = xo;
+    for (int l = tid + SWEEP_THREADS; l < KS * 4; l += SWEEP_THREADS) xt[l] = (l < N) ? xop[l] : 0.0;
+    __syncthreads();
+    if (!wave_on) return;
+#if OGK_TRACE
+    t_staged = __builtin_amdgcn_s_memtime();
+#endif
 
     // A operand: row (lane & 15) is the state vector with its own element perturbed
     double hit_v = 0.0;
@@ -619,10 +669,10 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     const int ndef = defect_blocks();
     const int row_blocks = (OgGen::N_ROW_ITEMS + 255) / 256;
     if (mode == 0) {
-        const int total = ndef + row_blocks;
-        if (total > 0)
-            hipLaunchKernelGGL(ogk_dense<false>, dim3(total), dim3(256), defect_lds_bytes(), stream,
-                               *args, ndef, ndef, row_blocks);
+        const int eval_row_blocks = (OGT_N_ROWWAVES + SWEEP_WAVES - 1) / SWEEP_WAVES;
+        if (ndef + eval_row_blocks > 0)
+            hipLaunchKernelGGL(ogk_eval, dim3(ndef + eval_row_blocks), dim3(SWEEP_THREADS),
+                               defect_lds_bytes(), stream, *args, ndef);
         return (int)hipGetLastError();
     }
     const int ncols = args->col_hi - args->col_lo;
@@ -636,7 +686,7 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     const int defect_total = ndef * ((ncols + 63) / 64);
     const int rows_total = row_blocks * ((ncols + ROWS_COLS_PER_THREAD - 1) / ROWS_COLS_PER_THREAD);
     if (defect_total + rows_total > 0)
-        hipLaunchKernelGGL(ogk_dense<true>, dim3(defect_total + rows_total), dim3(256),
+        hipLaunchKernelGGL(ogk_dense, dim3(defect_total + rows_total), dim3(256),
                            defect_lds_bytes(), stream, *args, ndef, defect_total, row_blocks);
     return (int)hipGetLastError();
 }

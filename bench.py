@@ -15,7 +15,7 @@ split in contiguous blocks (strong scaling - total work is fixed) and reassemble
 RCCL all-gather per step; timing is barrier + synchronize on both
 sides, max over ranks.
 
-Extra objects on the JSON line: ``roofline`` (dominant kernel ``ogk_sweep<true>`` against the
+Extra objects on the JSON line: ``roofline`` (dominant kernel ``ogk_sweep`` against the
 HBM roofline, algorithmic bytes 8*[(n+1)n + m n + sum N_i^2] per launch, duration from HIP
 events on the launch stream) and ``cpu_baseline`` (the NumPy restatement of the reference path,
 ``oracle/np_path.py``, timed on this host for ~10 s; rank 0, N = 1 only).
@@ -172,9 +172,10 @@ def main():
             "n": n, "m_eq": eng.m_eq, "m_ineq": eng.m_ineq,
             "evals_per_step": 3 * n + 2,
             "parallelism": "fd-columns x%d%s" % (world, " + RCCL all-gather" if world > 1 else "")},
-        "roofline": {"bound": "hbm", "kernel": "ogk_sweep<true>", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "ogk_sweep", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                     "bytes_actually_written_per_launch": 8.0 * m * ncols,
                      "kernel_ms_mean": kern_ms_mean, "kernel_ms_median": kern_ms,
                      "eval_kernel_ms_mean": eval_ms_mean},
     }

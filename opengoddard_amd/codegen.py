@@ -844,7 +844,7 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     heavy_set = set(heavy)
     col = [[col_ptr[j], col_ptr[j + 1], own_lo[j], own_hi[j] | ((1 << 30) if j in heavy_set else 0)]
            for j in range(P.n)]
-    elem = [[g, o, k, 0] for g, o, k in zip(elem_g, elem_o, elem_k)]
+    elem = [[g, o, k, P.groups[g].outputs[max(o, 0)][0] + k] for g, o, k in zip(elem_g, elem_o, elem_k)]
     tiles, slots = [], []
     for si, sl in enumerate(P.mv):
         t16 = (sl.length + 15) // 16

@@ -361,30 +361,39 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, cons
 constexpr int LIGHT_COLS = 4;        // columns per workgroup in light_columns_body
 constexpr int HEAVY_FLAG = 1 << 30;  // in OGT_COL[j].w
 
-__device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const int own_lo,
-                                         const int own_hi, const int first, const int stride,
-                                         const bool all_finite) {
+// Rows are filled with the "no dependency" value EXCEPT at the positions the items (and the
+// MFMA tiles) write: a per-row bitmap in LDS marks those, so no ordering between the fill stores
+// and the item stores is needed and the fill drains in the background while the wavefronts are
+// already in their (latency-bound) item chains.
+__device__ __forceinline__ bool marked(const unsigned* bits, const int r) {
+    return (bits[r >> 5] >> (r & 31)) & 1u;
+}
+
+__device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const unsigned* bits,
+                                         const int own_lo, const int own_hi, const int first,
+                                         const int stride, const bool all_finite) {
     if (OGK_EXP & 16) return;
     if (all_finite) {
         // every row of F(x0) is finite: (F0-F0)/dx is plain zero.  16-byte stores on the aligned
-        // pairs that lie wholly outside the tile-owned block, 8-byte stores for the rest.
+        // pairs that are wholly free, 8-byte stores for the rest.
         const int a0 = (int)((reinterpret_cast<unsigned long long>(jrow) >> 3) & 1);
         const double2 zero2 = make_double2(0.0, 0.0);
         for (int q = first; a0 + 2 * q < OgGen::M; q += stride) {
             const int r = a0 + 2 * q;
-            const bool in0 = r >= own_lo && r < own_hi;
-            const bool in1 = r + 1 >= own_lo && r + 1 < own_hi;
-            if (r + 1 < OgGen::M && !in0 && !in1) {
+            const bool skip0 = (r >= own_lo && r < own_hi) || marked(bits, r);
+            const bool has1 = r + 1 < OgGen::M;
+            const bool skip1 = !has1 || (r + 1 >= own_lo && r + 1 < own_hi) || marked(bits, r + 1);
+            if (!skip0 && !skip1) {
                 *reinterpret_cast<double2*>(jrow + r) = zero2;
             } else {
-                if (!in0) jrow[r] = 0.0;
-                if (r + 1 < OgGen::M && !in1) jrow[r + 1] = 0.0;
+                if (!skip0) jrow[r] = 0.0;
+                if (!skip1) jrow[r + 1] = 0.0;
             }
         }
-        if (a0 && first == 0 && !(0 >= own_lo && 0 < own_hi)) jrow[0] = 0.0;
+        if (a0 && first == 0 && !(0 >= own_lo && 0 < own_hi) && !marked(bits, 0)) jrow[0] = 0.0;
     } else {                        // z carries NaN for the non-finite rows
         for (int r = first; r < OgGen::M; r += stride)
-            if (r < own_lo || r >= own_hi) jrow[r] = a.z[r];
+            if ((r < own_lo || r >= own_hi) && !marked(bits, r)) jrow[r] = a.z[r];
     }
 }
 
@@ -392,10 +401,12 @@ __device__ __forceinline__ void eval_item(const ogk_args& a, const int4 item, co
                                           const double dx, double* jrow) {
     int row;
     const double v = OgGen::item_value(item.x, item.y, item.z, xa, a.y0, a.cvec, &row);
-    jrow[row] = (v - a.f0[row]) / dx;
+    jrow[row] = (v - a.f0[row]) / dx;         // row == item.w (the position marked in the bitmap)
 }
 
-__device__ __forceinline__ void heavy_column_body(const ogk_args& a, const int j) {
+constexpr int ROW_WORDS = (OgGen::M + 31) / 32;      // bitmap words per J_T row
+
+__device__ __forceinline__ void heavy_column_body(const ogk_args& a, const int j, unsigned* bits) {
     const int tid = (int)threadIdx.x;
     const int4 col = OGT_COL[j];
     const int own_lo = col.z, own_hi = col.w & ~HEAVY_FLAG;
@@ -403,23 +414,32 @@ __device__ __forceinline__ void heavy_column_body(const ogk_args& a, const int j
     const double xj = xb + a.h[j];
     const double dx = xj - xb;
     const bool all_finite = *a.nonfinite == 0;
+    for (int w = tid; w < ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
+    __syncthreads();
+    for (int e = col.x + tid; e < col.y; e += SWEEP_THREADS) {
+        const int r = OGT_ELEM[e].w;
+        atomicOr(&bits[r >> 5], 1u << (r & 31));
+    }
+    __syncthreads();
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    fill_row(a, jrow, own_lo, own_hi, tid, SWEEP_THREADS, all_finite);
-    __syncthreads();                 // fill stores before item stores to the same addresses
+    fill_row(a, jrow, bits, own_lo, own_hi, tid, SWEEP_THREADS, all_finite);
     const XCol xa{a.x0, j, xj};
     for (int e = col.x + tid; e < ((OGK_EXP & 8) ? 0 : col.y); e += SWEEP_THREADS)
         eval_item(a, OGT_ELEM[e], xa, dx, jrow);
 }
 
-__device__ __forceinline__ void light_columns_body(const ogk_args& a, const int first_j) {
+__device__ __forceinline__ void light_columns_body(const ogk_args& a, const int first_j,
+                                                   unsigned* bits) {
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 #if OGK_TRACE
     const long long t_begin = __builtin_amdgcn_s_memtime();
+    const long long t_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // ---- everything this thread will need, requested before anything is waited for
     constexpr int WPR = SWEEP_WAVES / LIGHT_COLS;               // wavefronts sharing one row
-    const int jf = first_j + wave / WPR;                        // the row this wavefront fills
+    const int cf = wave / WPR;                                  // the row this wavefront fills
+    const int jf = first_j + cf;
     const int ji = first_j + lane;                              // the column this lane evaluates
     const bool fill_on = jf < a.col_hi;
     const bool item_on = lane < LIGHT_COLS && ji < a.col_hi;
@@ -429,14 +449,28 @@ __device__ __forceinline__ void light_columns_body(const ogk_args& a, const int 
     const double hh = a.h[item_on ? ji : a.col_lo];
     const bool all_finite = *a.nonfinite == 0;
     int4 item = make_int4(0, 0, 0, 0);
-    const bool has_item = item_on && !(coli.w & HEAVY_FLAG) && coli.x + wave < coli.y;
+    const bool col_live = item_on && !(coli.w & HEAVY_FLAG);
+    const bool has_item = col_live && coli.x + wave < coli.y;
     if (has_item) item = OGT_ELEM[coli.x + wave];
 
-    // ---- fill (heavy columns are filled by their own workgroup)
+    // ---- mark the positions the items will write
+    for (int w = tid; w < LIGHT_COLS * ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
+    __syncthreads();
+    if (has_item) {
+        unsigned* mine = bits + lane * ROW_WORDS;
+        atomicOr(&mine[item.w >> 5], 1u << (item.w & 31));
+        for (int e = coli.x + wave + SWEEP_WAVES; e < coli.y; e += SWEEP_WAVES) {
+            const int r = OGT_ELEM[e].w;
+            atomicOr(&mine[r >> 5], 1u << (r & 31));
+        }
+    }
+    __syncthreads();
+
+    // ---- fill around them (heavy columns are filled by their own workgroup); the stores drain
+    //      while the item chains below run
     if (fill_on && !(colf.w & HEAVY_FLAG))
-        fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, colf.z, colf.w, (wave % WPR) * 64 + lane,
-                 64 * WPR, all_finite);
-    __syncthreads();                 // fill stores before item stores to the same addresses
+        fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + cf * ROW_WORDS, colf.z,
+                 colf.w, (wave % WPR) * 64 + lane, 64 * WPR, all_finite);
 #if OGK_TRACE
     const long long t_filled = __builtin_amdgcn_s_memtime();
 #endif
@@ -460,6 +494,7 @@ __device__ __forceinline__ void light_columns_body(const ogk_args& a, const int 
         double* t = jrow + 8 * wave;
         t[0] = 1.0e6 + wave; t[1] = (double)t_begin; t[2] = (double)t_filled; t[3] = (double)t_ready;
         t[4] = (double)__builtin_amdgcn_s_memtime(); t[5] = (double)(coli.y - coli.x);
+        t[6] = (double)t_real0; t[7] = (double)__builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
@@ -611,10 +646,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a) {
     } else if (id < OGT_N_TILES + OgGen::N_HEAVY) {
         // then the columns with many dependent items (e.g. phase final times): a workgroup each
         const int j = OGT_HEAVY[id - OGT_N_TILES];
-        if (j >= a.col_lo && j < a.col_hi) heavy_column_body(a, j);
+        if (j >= a.col_lo && j < a.col_hi) heavy_column_body(a, j, reinterpret_cast<unsigned*>(lds));
     } else {
         // all columns of this launch, LIGHT_COLS per workgroup
-        light_columns_body(a, a.col_lo + (id - OGT_N_TILES - OgGen::N_HEAVY) * LIGHT_COLS);
+        light_columns_body(a, a.col_lo + (id - OGT_N_TILES - OgGen::N_HEAVY) * LIGHT_COLS,
+                           reinterpret_cast<unsigned*>(lds));
     }
 }
 
@@ -637,7 +673,7 @@ size_t defect_lds_bytes() {
 }
 
 size_t sweep_lds_bytes() {
-    size_t worst = 0;
+    size_t worst = (size_t)LIGHT_COLS * ROW_WORDS * sizeof(unsigned);
     for (int s = 0; s < OgGen::N_MV; ++s) {
         const int KS = (OgGen::MV_LEN(s) + 3) >> 2;
         const size_t need = ((size_t)KS * 64 + (size_t)KS * 4) * sizeof(double);

@@ -20,7 +20,8 @@ flat = JT.ravel()
 for tag, label, names in ((1.0e6, "light", ["fill", "setup", "items"]), (2.0e6, "tile", ["stage", "mfma", "epilogue"])):
     idx = np.nonzero((flat >= tag) & (flat < tag + 4))[0]
     idx = idx[idx + 5 < flat.size]
-    recs = np.array([flat[i:i + 6] for i in idx])
+    idx = idx[idx + 8 < flat.size]
+    recs = np.array([flat[i:i + 8] for i in idx])
     recs = recs[(recs[:, 1] > 1e9) & (recs[:, 4] >= recs[:, 1])] if len(recs) else recs
     if not len(recs):
         print(label, "no records"); continue
@@ -31,6 +32,11 @@ for tag, label, names in ((1.0e6, "light", ["fill", "setup", "items"]), (2.0e6, 
     for i, nm in enumerate(names):
         print("   %-9s mean %8.0f  p50 %8.0f  max %8.0f ticks" % (nm, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
     if label == "light":
+        dt_core = recs[:, 4] - recs[:, 1]
+        dt_real = recs[:, 7] - recs[:, 6]
+        ok = dt_real > 0
+        print("   shader clock during the kernel: %.0f MHz (s_memtime ticks per 100 MHz s_memrealtime tick)" % (
+            100.0 * np.median(dt_core[ok] / dt_real[ok])))
         for w in range(4):
             sel = recs[:, 0] == tag + w
             if sel.any():

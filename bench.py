@@ -58,6 +58,23 @@ def cpu_baseline(name, seconds=10.0):
             "host_cpus": os.cpu_count()}
 
 
+def measured_traffic(workload):
+    """HBM-side bytes per ogk_sweep launch from the committed rocprofv3 --pmc passes
+    (profiles/rNN_traffic.json, made by tools/summarize_profiles.py; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when this workload was not profiled."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            with open(path) as fh:
+                entry = json.load(fh).get(workload, {}).get("ogk_sweep")
+        except (OSError, ValueError):
+            continue
+        if entry and entry.get("hbm_bytes_per_launch"):
+            best = {"bytes": entry["hbm_bytes_per_launch"], "source": os.path.basename(path)}
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +173,7 @@ def main():
     alg_bytes = 8.0 * ((ncols + 1) * n + m * ncols + sumN2)
     achieved = alg_bytes / (kern_ms_mean * 1e-3) / 1e9
 
+    traffic = measured_traffic(a.workload) if world == 1 else None
     result = {
         "metric": "NLP-callback evals/sec (cost+constr+FD-Jacobian)",
         "value": (3 * n + 2) * a.steps / elapsed,
@@ -174,10 +192,13 @@ def main():
             "parallelism": "fd-columns x%d%s" % (world, " + RCCL all-gather" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": "ogk_sweep", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                     "traffic": traffic["bytes"] if traffic else None,
+                     "traffic_source": traffic["source"] if traffic else None,
+                     "algorithmic_bytes_per_launch": alg_bytes,
                      "bytes_actually_written_per_launch": 8.0 * m * ncols,
                      "kernel_ms_mean": kern_ms_mean, "kernel_ms_median": kern_ms,
-                     "eval_kernel_ms_mean": eval_ms_mean},
+                     "eval_kernel_ms_mean": eval_ms_mean,
+                     "frac_of_whole_step": alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
     }
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)

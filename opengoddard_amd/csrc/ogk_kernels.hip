@@ -358,7 +358,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, cons
 //                         wavefront = item slot.
 // Part B - tile_body: d(defect_s)/d(state_s) for one collocation slot on the matrix cores.
 // ------------------------------------------------------------------------------------------
-constexpr int LIGHT_COLS = 4;        // columns per workgroup in light_columns_body
+#ifndef OGK_LIGHT_COLS
+#define OGK_LIGHT_COLS 4
+#endif
+constexpr int LIGHT_COLS = OGK_LIGHT_COLS;   // columns per workgroup in light_columns_body
 constexpr int HEAVY_FLAG = 1 << 30;  // in OGT_COL[j].w
 
 // Rows are filled with the "no dependency" value EXCEPT at the positions the items (and the

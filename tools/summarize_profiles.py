@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/<round>/ktrace_*, pmc_*) into profiles/<round>_*.
+
+    python tools/summarize_profiles.py r01
+
+Writes profiles/<round>_kernel_stats_<workload>.csv (verbatim rocprofv3 --stats table),
+profiles/<round>_traffic.json (per-launch PMC bytes for the engine's kernels) and
+profiles/<round>_summary.md.
+"""
+import csv, glob, json, os, shutil, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", rnd)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+lines = ["# rocprofv3 summary, round %s (MI355X, gfx950)" % rnd, "",
+         "Commands (run from /tmp with TMPDIR=/tmp, see tools/kstats.sh):",
+         "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload W --steps 200 --warmup 20 --no-cpu-baseline`",
+         "`rocprofv3 --pmc FETCH_SIZE -- ...` and `rocprofv3 --pmc WRITE_SIZE -- ...` (separate passes, 50 steps).", ""]
+traffic = {}
+for d in sorted(glob.glob(os.path.join(src, "ktrace_*"))):
+    if not os.path.isdir(d):
+        continue
+    w = os.path.basename(d)[len("ktrace_"):]
+    stats = glob.glob(os.path.join(d, "*kernel_stats.csv"))
+    if not stats:
+        continue
+    shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (rnd, w)))
+    lines += ["## %s" % w, "", "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+    for r in csv.DictReader(open(stats[0])):
+        if "ogk_" in r["Name"]:
+            lines.append("| `%s` | %s | %.2f | %.2f | %.2f |" % (
+                r["Name"].replace("(anonymous namespace)::", ""), r["Calls"], float(r["AverageNs"]) / 1e3,
+                float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+    lines.append("")
+    traffic[w] = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = glob.glob(os.path.join(src, "pmc_%s_%s" % (c, w), "*counter_collection.csv"))
+        if not f:
+            continue
+        per = {}
+        for r in csv.DictReader(open(f[0])):
+            if "ogk_" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+                per.setdefault(k, []).append(float(r["Counter_Value"]))
+        for k, v in per.items():
+            traffic[w].setdefault(k, {})[c + "_KB_mean"] = float(np.mean(v))
+            traffic[w][k]["launches"] = len(v)
+    for k, t in traffic[w].items():
+        fetch = t.get("FETCH_SIZE_KB_mean", 0.0)
+        write = t.get("WRITE_SIZE_KB_mean", 0.0)
+        # MI355X_MICROARCH.md (HBM section): gfx950 FETCH_SIZE counts 64 B per 128-B request ->
+        # double it; WRITE_SIZE taken as is (uncalibrated)
+        t["hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
+        lines.append("PMC `%s`: FETCH_SIZE %.1f KB (x2 per the gfx950 note), WRITE_SIZE %.1f KB per launch "
+                     "-> %.2f MB fabric traffic per launch" % (k, fetch, write, t["hbm_bytes_per_launch"] / 1e6))
+    lines.append("")
+with open(os.path.join(dst, "%s_traffic.json" % rnd), "w") as fh:
+    json.dump(traffic, fh, indent=1)
+with open(os.path.join(dst, "%s_summary.md" % rnd), "w") as fh:
+    fh.write("\n".join(lines) + "\n")
+print("\n".join(lines))

@@ -1,0 +1,193 @@
+"""Edge cases of the API that the BASELINE configurations do not exercise, as small inline
+problems: running cost + quirk Q10 (Bryson-Denham from the reference's smoke script,
+``OpenGoddard/optimize.py:1373-1451``, known answer 7.9985), an empty inequality set (Q14),
+phases with different state counts (knot rows skipped, ``optimize.py:690-691``), smooth knots
+(Q9), a constant cost, constant-array operands and ``np.where``.  CPU: tracer/lowering/twin
+against the NumPy oracle; GPU: the HIP sweep against the twin, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from opengoddard_amd import _native, codegen
+from opengoddard_amd import optimize as og
+from opengoddard_amd.optimize import Condition, Dynamics, Guess, Problem
+from oracle import np_path, program_eval, twin
+
+
+class Params:
+    max_x = 1.0 / 9.0
+    k = 0.7
+
+
+def bryson_denham(nodes=30):
+    def dynamics(prob, obj, section):
+        v = prob.states(1, section)
+        u = prob.controls(0, section)
+        dx = Dynamics(prob, section)
+        dx[0] = v
+        dx[1] = u
+        return dx()
+
+    def equality(prob, obj):
+        x = prob.states_all_section(0)
+        v = prob.states_all_section(1)
+        tf = prob.time_final(-1)
+        rows = Condition()
+        rows.add(x[0] - 0.0)
+        rows.add(v[0] - 1.0)
+        rows.add(x[-1] - 0.0)
+        rows.add(v[-1] + 1.0)
+        rows.add(tf - 1.0)
+        return rows()
+
+    def inequality(prob, obj):
+        x = prob.states_all_section(0)
+        rows = Condition()
+        rows.add(x - 0.0)
+        rows.add(obj.max_x - x)
+        return rows()
+
+    prob = Problem([0, 1.0], [nodes], [2], [1], 10)
+    prob.set_states_all_section(0, Guess.constant(prob.time_all_section, 0.1))
+    prob.dynamics = [dynamics]
+    prob.knot_states_smooth = []
+    prob.cost = lambda prob, obj: 0.0
+    prob.running_cost = lambda prob, obj: 0.5 * prob.controls_all_section(0) ** 2
+    prob.equality = equality
+    prob.inequality = inequality
+    return prob, Params()
+
+
+def ragged_two_phase():
+    """Phase 0: 2 states / 1 control / 7 nodes; phase 1: 3 states / 2 controls / 5 nodes.
+    Different state counts => no built-in knot rows; empty inequality; constant cost."""
+    def dynamics(prob, obj, section):
+        x = prob.states(0, section)
+        v = prob.states(1, section)
+        u = prob.controls(0, section)
+        dx = Dynamics(prob, section)
+        dx[0] = v * np.cos(x)
+        dx[1] = np.where(u > 0.2, u, 0.2 * u) - obj.k * v
+        if section == 1:
+            dx[2] = prob.controls(1, section) * prob.tau[1]       # constant-array operand
+        return dx()
+
+    def equality(prob, obj):
+        rows = Condition()
+        rows.equal(prob.states(0, 0)[0], 0.0)
+        rows.equal(prob.states(0, 1)[0], prob.states(0, 0)[-1])
+        rows.equal(prob.states(1, 1)[0], prob.states(1, 0)[-1], unit=2.0)
+        rows.equal(np.maximum(prob.states(2, 1)[1:3], 0.5), 0.5)
+        return rows()
+
+    prob = Problem([0.0, 1.0, 2.5], [7, 5], [2, 3], [1, 2], 3)
+    prob.set_unit_states(1, 0, 2.0)
+    prob.set_unit_controls(0, 1, 0.5)
+    rng = np.random.default_rng(3)
+    prob.p[:-2] = rng.uniform(0.1, 1.0, prob.number_of_variables - 2)
+    prob.dynamics = [dynamics, dynamics]
+    prob.cost = lambda prob, obj: 1.25
+    prob.equality = equality
+    prob.inequality = lambda prob, obj: Condition()()
+    return prob, Params()
+
+
+def smooth_knots():
+    """Two phases with equal state counts and built-in knot continuity rows (quirk Q9: both
+    sides divided by the first phase's unit)."""
+    def dynamics(prob, obj, section):
+        dx = Dynamics(prob, section)
+        dx[0] = prob.states(1, section)
+        dx[1] = prob.controls(0, section) - np.sin(prob.states(0, section))
+        return dx()
+
+    def equality(prob, obj):
+        rows = Condition()
+        rows.equal(prob.states(0, 0)[0], 0.1)
+        return rows()
+
+    def inequality(prob, obj):
+        rows = Condition()
+        rows.upper_bound(prob.controls_all_section(0), 2.0)
+        rows.lower_bound(prob.time_final(0), 0.2)
+        return rows()
+
+    prob = Problem([0.0, 1.0, 2.0], [6, 9], [2, 2], [1, 1], 3)
+    prob.set_unit_states(0, 0, 3.0)
+    prob.set_unit_states(0, 1, 5.0)
+    rng = np.random.default_rng(5)
+    prob.p[:-2] = rng.uniform(-1.0, 1.0, prob.number_of_variables - 2)
+    prob.dynamics = [dynamics, dynamics]
+    prob.knot_states_smooth = [True]
+    prob.cost = lambda prob, obj: -prob.states(0, 1)[-1]
+    prob.equality = equality
+    prob.inequality = inequality
+    return prob, Params()
+
+
+CASES = {"bryson_denham": bryson_denham, "ragged_two_phase": ragged_two_phase,
+         "smooth_knots": smooth_knots}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_trace_and_twin_match_numpy_oracle(name):
+    prob, obj = CASES[name]()
+    P = codegen.trace_problem(prob, obj)
+    lb, ub = np_path.bounds_arrays(prob)
+    x = np.clip(prob.p, lb, ub)
+    F = np_path.stacked_values(prob, obj, x)
+    assert P.m == F.size
+    assert np.array_equal(program_eval.evaluate(P, prob, x), F)
+    if name == "ragged_two_phase":
+        assert P.m_ineq == 0 and P.m_eq == 5 + 2 * 7 + 3 * 5          # no knot rows
+    if name == "smooth_knots":
+        assert P.m_eq == 1 + 2 * 6 + 2 * 9 + 2                         # + 2 knot rows
+    tw = twin.Twin(prob, obj, program=P)
+    Ft = tw.values(x)
+    assert np.all(np.abs(Ft - F) <= 1e-11 * np.maximum(1.0, np.abs(F)) + 1e-10)
+    h = _native.fd_step(x, lb, ub)
+    F0, JT = tw.sweep(x, h)
+    _, _, JTo = np_path.sweep(prob, obj, x)
+    scale = np.maximum(1.0, np.abs(F)) + 200.0
+    bound = 1e-9 * np.abs(JTo) + 64 * np.finfo(float).eps * scale[None, :] / np.abs(h)[:, None]
+    assert np.all(np.abs(JT - JTo) <= bound)
+
+
+def test_bryson_denham_known_answer_with_oracle_engine(capsys):
+    """The reference converges to 8.0 instead of the analytic 4.0 because the running-cost
+    quadrature omits (tf-t0)/2 (quirk Q10); its smoke script prints 7.998497 for 30 nodes."""
+    og.ENGINE_FACTORY = np_path.NumpyEngine
+    try:
+        prob, obj = bryson_denham(30)
+        prob.solve(obj)
+    finally:
+        og.ENGINE_FACTORY = None
+    capsys.readouterr()
+    cost = float(np_path.cost_add(prob, obj))
+    assert abs(cost - 7.998497) < 5e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_sweep_bit_exact_on_edge_problems(name):
+    from opengoddard_amd.engine import HipEngine
+    prob, obj = CASES[name]()
+    eng = HipEngine(prob, obj)
+    tw = twin.Twin(prob, obj, program=eng.program, header=eng.header)
+    lb, ub = np_path.bounds_arrays(prob)
+    x = np.clip(prob.p, lb, ub)
+    h = _native.fd_step(x, lb, ub)
+    F0, JT = eng.sweep_stacked(x, h)
+    F0c, JTc = tw.sweep(x, h)
+    assert np.array_equal(F0, F0c) and np.array_equal(JT, JTc)
+    assert np.array_equal(eng.eval_stacked(x), F0c)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bryson_denham_solve(capsys):
+    prob, obj = bryson_denham(30)
+    prob.solve(obj)
+    capsys.readouterr()
+    assert abs(float(np_path.cost_add(prob, obj)) - 7.998497) < 5e-4
+    prob._engine.close()

@@ -622,8 +622,6 @@ class _Emitter:
                 lines.append("        out[%d] = y[%d] - T[%d];" % (s, s, s))
             lines.append("    }")
             return lines
-        if len(grp.outputs) != 1 and False:
-            pass
         lines = ["    template <class X> OG_HDI static void group%d(const int k, const X& x, "
                  "const double* y, const double* cv, double* out) {" % gi,
                  "        (void)k; (void)y; (void)cv;"]

@@ -233,10 +233,24 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
         std::vector<double> tmp;
         const double* D = (desc->D && desc->D[i]) ? desc->D[i] : nullptr;
         if (!D) {
-            std::vector<double> tau(N), w(N);
+            // no matrix supplied: build it on the device with the LGL kernels (bit-identical to
+            // og_lgl, tests/test_gpu_parity.py) and bring it back for operand packing
+            double *d_tau = nullptr, *d_w = nullptr, *d_D = nullptr;
             tmp.resize((size_t)N * N);
-            int rc = og_lgl(N, tau.data(), w.data(), tmp.data());
-            if (rc) { og_problem_destroy(p); return rc; }
+            hipError_t le = hipMalloc(&d_tau, sizeof(double) * N);
+            if (le == hipSuccess) le = hipMalloc(&d_w, sizeof(double) * N);
+            if (le == hipSuccess) le = hipMalloc(&d_D, sizeof(double) * (size_t)N * N);
+            int rc = (le == hipSuccess) ? og_lgl_dev(N, d_tau, d_w, d_D, nullptr) : 100 + (int)le;
+            if (!rc && hipMemcpy(tmp.data(), d_D, sizeof(double) * (size_t)N * N,
+                                 hipMemcpyDeviceToHost) != hipSuccess)
+                rc = 101;
+            hipFree(d_tau);
+            hipFree(d_w);
+            hipFree(d_D);
+            if (rc) {
+                og_problem_destroy(p);
+                return fail(rc, "og_problem_create: device LGL construction failed");
+            }
             D = tmp.data();
         }
         ogk_frag_pack(N, D, frag.data() + p->dfrag_off[i]);

@@ -36,9 +36,13 @@ class HipEngine:
         self.device = int(device)
 
         self._nodes = (C.c_int32 * len(P.nodes))(*P.nodes)
+        # a phase whose D is still the library's own LGL matrix is left NULL: the runtime then
+        # builds it with the device LGL kernel; a user-modified D is uploaded as given
         self._D = [np.ascontiguousarray(D, dtype=np.float64) for D in prob.D]
         dp = C.POINTER(C.c_double)
-        self._Dptr = (dp * len(self._D))(*[d.ctypes.data_as(dp) for d in self._D])
+        self._Dptr = (dp * len(self._D))(*[
+            None if (d.shape == (n, n) and np.array_equal(d, _native.lgl(n)[2]))
+            else d.ctypes.data_as(dp) for d, n in zip(self._D, P.nodes)])
         self._cvec = np.ascontiguousarray(P.cvec, dtype=np.float64)
         desc = _native.OgDesc(
             abi_version=_native.OG_ABI_VERSION, device=self.device, n=P.n, m_eq=P.m_eq,

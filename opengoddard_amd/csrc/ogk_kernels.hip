@@ -502,7 +502,12 @@ __device__ __forceinline__ void light_columns_body(const ogk_args& a, const int 
 #endif
 }
 
-__device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, double* lds) {
+// Part B.  One wavefront = one (16 perturbed columns) x (16 nodes) tile of one collocation slot.
+// Every wavefront of the sweep uses its D panel exactly once, so the B operands are read straight
+// from the L2-resident operand image (512 contiguous bytes per step) into registers, a chunk of
+// k-steps ahead of the MFMAs - no LDS round trip and no workgroup barrier on this path (the
+// evaluation and dense kernels, which reuse a panel across wavefronts/states, stage it in LDS).
+__device__ __forceinline__ void tile_body(const ogk_args& a, const int bx) {
 #if OGK_TRACE
     const long long t_begin = __builtin_amdgcn_s_memtime();
     long long t_staged = 0, t_mfma = 0;
@@ -517,25 +522,26 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
     const int l0 = (tile.y * SWEEP_WAVES + wave) * 16;  // first slice offset of this wave's tile
+    if (l0 >= N || leaf + l0 >= a.col_hi || leaf + l0 + 16 <= a.col_lo) return;
     const int k = nt * 16 + (lane & 15);                // output node of this lane
     const int la = l0 + (lane & 15);                    // A-operand row of this lane
-    const bool wave_on = l0 < N && leaf + l0 < a.col_hi && leaf + l0 + 16 > a.col_lo;
+    (void)g;
 
-    // ---- requests first: D panel, base operands, this lane's perturbation, epilogue inputs
-    double* dpanel = lds;
-    double* xt = lds + KS * 64;
-    const double* src = a.dfrag + a.dfrag_off[rec.v[5]] + (long)nt * KS * 64;
+    // ---- requests first: operands of the first chunk, this lane's perturbation, epilogue inputs
+    const double* bsrc = a.dfrag + a.dfrag_off[rec.v[5]] + (long)nt * KS * 64 + lane;
     const double* xop = a.xop + y0off;                  // base operands, written by mode 0
-    constexpr int UNR = 4;
-    double pv[UNR];
+    constexpr int CH = 10;                              // k-steps per chunk
+    double bv[CH], av[CH];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u)
-        pv[u] = (tid + SWEEP_THREADS * u < KS * 64) ? src[tid + SWEEP_THREADS * u] : 0.0;
-    const double xo = (tid < KS * 4 && tid < N) ? xop[tid] : 0.0;
-    const bool a_on = wave_on && la < N;
+    for (int u = 0; u < CH; ++u) {
+        const int l = u * 4 + lk;
+        bv[u] = (u < KS) ? bsrc[u * 64] : 0.0;
+        av[u] = (u < KS && l < N) ? xop[l] : 0.0;
+    }
+    const bool a_on = la < N;
     const double xa_b = a.x0[a_on ? leaf + la : leaf];
     const double xa_h = a.h[a_on ? leaf + la : leaf];
-    const bool k_on = wave_on && k < N;
+    const bool k_on = k < N;
     const int row = row0 + (k_on ? k : 0);
     const double t_base = a.t0[row];
     const double f_base = a.f0[row];
@@ -547,8 +553,9 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
         xbv[reg] = a.x0[jj];
         hv[reg] = a.h[jj];
     }
-    // ---- the dynamics term on the diagonal (k == own perturbed node) depends neither on the
-    //      staged data nor on the MFMA result: run its chain while the panel loads are in flight
+
+    // ---- the dynamics term on the diagonal (k == own perturbed node) needs neither the operands
+    //      nor the MFMA result: its chain runs while the loads above are in flight
     double t_diag = t_base;
     bool have_diag = false;
     {
@@ -563,15 +570,6 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
             t_diag = OgGen::tail_one(slot, k, xd, a.cvec);
         }
     }
-
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-        if (tid + SWEEP_THREADS * u < KS * 64) dpanel[tid + SWEEP_THREADS * u] = pv[u];
-    for (int i = tid + SWEEP_THREADS * UNR; i < KS * 64; i += SWEEP_THREADS) dpanel[i] = src[i];
-    if (tid < KS * 4) xt[tid] = xo;
-    for (int l = tid + SWEEP_THREADS; l < KS * 4; l += SWEEP_THREADS) xt[l] = (l < N) ? xop[l] : 0.0;
-    __syncthreads();
-    if (!wave_on) return;
 #if OGK_TRACE
     t_staged = __builtin_amdgcn_s_memtime();
 #endif
@@ -583,23 +581,26 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx, doubl
         hit_v = OgGen::mv_operand(slot, la, xa, a.cvec);
     }
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    int ks = 0;
-    for (; ks + 4 <= KS; ks += 4) {          // operands of 4 steps in flight before the MFMAs
-        double av[4], bv[4];
+    for (int ks0 = 0; ks0 < KS; ks0 += CH) {
+        // next chunk's operands are requested before this chunk's MFMAs issue
+        double bn[CH], an[CH];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int l = (ks + u) * 4 + lk;
-            av[u] = (l == la) ? hit_v : xt[l];
-            bv[u] = dpanel[(ks + u) * 64 + lane];
+        for (int u = 0; u < CH; ++u) {
+            const int ks = ks0 + CH + u;
+            const int l = ks * 4 + lk;
+            bn[u] = (ks < KS) ? bsrc[ks * 64] : 0.0;
+            an[u] = (ks < KS && l < N) ? xop[l] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-    }
-    for (; ks < KS; ++ks) {
-        const int l = ks * 4 + lk;
-        const double av = (l == la) ? hit_v : xt[l];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, dpanel[ks * 64 + lane], acc, 0, 0, 0);
+        for (int u = 0; u < CH; ++u) {
+            const int ks = ks0 + u;
+            if (ks < KS) {
+                const double aop = (ks * 4 + lk == la) ? hit_v : av[u];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bv[u], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { bv[u] = bn[u]; av[u] = an[u]; }
     }
 #if OGK_TRACE
     t_mfma = __builtin_amdgcn_s_memtime();
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a) {
     const int id = (int)blockIdx.x;
     if (id < OGT_N_TILES) {
         // MFMA tiles have the longest dependent chain: dispatch them first
-        if (!(OGK_EXP & 32)) tile_body(a, id, lds);
+        if (!(OGK_EXP & 32)) tile_body(a, id);
     } else if (id < OGT_N_TILES + OgGen::N_HEAVY) {
         // then the columns with many dependent items (e.g. phase final times): a workgroup each
         const int j = OGT_HEAVY[id - OGT_N_TILES];
@@ -675,15 +676,7 @@ size_t defect_lds_bytes() {
     return worst;
 }
 
-size_t sweep_lds_bytes() {
-    size_t worst = (size_t)LIGHT_COLS * ROW_WORDS * sizeof(unsigned);
-    for (int s = 0; s < OgGen::N_MV; ++s) {
-        const int KS = (OgGen::MV_LEN(s) + 3) >> 2;
-        const size_t need = ((size_t)KS * 64 + (size_t)KS * 4) * sizeof(double);
-        worst = need > worst ? need : worst;
-    }
-    return worst;
-}
+size_t sweep_lds_bytes() { return (size_t)LIGHT_COLS * ROW_WORDS * sizeof(unsigned); }
 
 }  // namespace
 

@@ -77,6 +77,8 @@ class Program:
         self.groups = []
         self.cvec = np.zeros(0)       # flat constant table
         self.cvec_off = []            # table id -> offset into cvec
+        self.tables = []              # linear lookup tables (trace.Graph.tables)
+        self.table_len = []
 
     @property
     def m(self):
@@ -99,6 +101,8 @@ class _Lowerer:
             at += v.shape[0]
         program.cvec_off = off
         program.cvec = np.concatenate(graph.cvecs) if graph.cvecs else np.zeros(0)
+        program.tables = list(graph.tables)
+        program.table_len = [int(graph.cvecs[t[0]].shape[0]) for t in graph.tables]
         self._mv_index = {}
 
     # -- substitution helpers ----------------------------------------------------------------
@@ -112,8 +116,8 @@ class _Lowerer:
             out = leaf_fn(node)
         elif tag in ("C", "sum"):
             out = eid
-        elif tag == "un":
-            out = self.eg.add(("un", node[1], self._map(node[2], leaf_fn, memo)))
+        elif tag in ("un", "interp"):
+            out = self.eg.add((tag, node[1], self._map(node[2], leaf_fn, memo)))
         elif tag in ("bin", "cmp", "logic"):
             out = self.eg.add((tag, node[1], self._map(node[2], leaf_fn, memo),
                                self._map(node[3], leaf_fn, memo)))
@@ -170,8 +174,8 @@ class _Lowerer:
             out = [(None, self.eg.add(("C", node[1])))]
         elif tag == "cvec":
             out = [(length, self.eg.add(("CV", node[1], 0, 1)))]
-        elif tag == "un":
-            out = [(ln, self.eg.add(("un", node[1], e))) for ln, e in self.pieces(node[2])]
+        elif tag in ("un", "interp"):
+            out = [(ln, self.eg.add((tag, node[1], e))) for ln, e in self.pieces(node[2])]
         elif tag in ("bin", "cmp", "logic"):
             out = [(ln, self.eg.add((tag, node[1], a, b)))
                    for ln, (a, b) in self._align([node[2], node[3]], length)]
@@ -290,7 +294,7 @@ def _leaves(eg, eid, tags, seen=None, into_sums=True):
         tag = node[0]
         if tag in tags:
             out.add(node)
-        if tag == "un":
+        if tag in ("un", "interp"):
             stack.append(node[2])
         elif tag in ("bin", "cmp", "logic"):
             stack.extend(node[2:4])
@@ -311,9 +315,10 @@ def trace_problem(prob, obj):
     saved = prob.p
     prob.p = sym_p
     try:
-        cost = prob._assemble_cost(obj)
-        ceq = prob._assemble_equality(obj)
-        cineq = prob.inequality(prob, obj)
+        with _tr.intercept_interp1d():
+            cost = prob._assemble_cost(obj)
+            ceq = prob._assemble_equality(obj)
+            cineq = prob.inequality(prob, obj)
     finally:
         prob.p = saved
 
@@ -448,7 +453,7 @@ def _group_dependencies(P, grp, roots=None):
                 deps.add((1, node[1], grp.length))
             else:
                 deps.add((2, node[1], span))
-        elif tag == "un":
+        elif tag in ("un", "interp"):
             stack.append((node[2], span))
         elif tag in ("bin", "cmp", "logic"):
             stack.append((node[2], span))
@@ -507,7 +512,7 @@ class _Emitter:
                 stack.append((cur, True))
                 node = eg.nodes[cur]
                 tag = node[0]
-                if tag == "un":
+                if tag in ("un", "interp"):
                     stack.append((node[2], False))
                 elif tag in ("bin", "cmp", "logic"):
                     stack.append((node[3], False))
@@ -533,6 +538,11 @@ class _Emitter:
                 rhs = "y[%d]" % ymap[node[1]]
             elif tag == "un":
                 rhs = _UN_C[node[1]] % names[node[2]]
+            elif tag == "interp":
+                ix, iy, mode, lo, hi = self.P.tables[node[1]]
+                rhs = "ogm::interp_linear(cv + %d, cv + %d, %d, %d, %s, %s, %s)" % (
+                    self.P.cvec_off[ix], self.P.cvec_off[iy], self.P.table_len[node[1]], mode,
+                    _cdouble(lo), _cdouble(hi), names[node[2]])
             elif tag == "bin":
                 a, b = names[node[2]], names[node[3]]
                 if node[1] == "max":      # np.maximum: propagate NaN from either side
@@ -569,7 +579,7 @@ class _Emitter:
             tag = node[0]
             if tag == "sum":
                 out.append(e)
-            elif tag == "un":
+            elif tag in ("un", "interp"):
                 stack.append(node[2])
             elif tag in ("bin", "cmp", "logic"):
                 stack.extend(node[2:4])

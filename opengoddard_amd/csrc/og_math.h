@@ -220,4 +220,29 @@ OG_HD double tan_(double x) {
     return (q & 1) ? -(c / s) : (s / c);
 }
 
+// ---------------------------------------------------------------- linear table lookup
+// scipy.interpolate.interp1d(kind="linear") as the reference's example 11 uses it
+// (examples/11_Polar_TSTO_Taiki.py:21-27; SciPy 1.15.3 scipy/interpolate/_interpolate.py
+// _call_linear + _evaluate): i = clip(searchsorted(xg, x, "left"), 1, n-1);
+// y = (y[i]-y[i-1])/(xg[i]-xg[i-1]) * (x - xg[i-1]) + y[i-1]; outside [xg[0], xg[n-1]] the
+// fill values replace it unless extrapolating.  mode 0: fill values; 1: extrapolate;
+// 2: the reference would raise ValueError (bounds_error=True) - a kernel cannot, it returns NaN.
+OG_HD double interp_linear(const double* xg, const double* yg, const int n, const int mode,
+                           const double fill_below, const double fill_above, const double x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {                         // first index with xg[index] >= x
+        const int mid = (lo + hi) >> 1;
+        if (xg[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    const double x_lo = xg[i - 1], x_hi = xg[i], y_lo = yg[i - 1], y_hi = yg[i];
+    const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+    double y = slope * (x - x_lo) + y_lo;
+    if (mode != 1) {
+        if (x < xg[0]) y = (mode == 0) ? fill_below : from_bits(0x7ff8000000000000ULL);
+        if (x > xg[n - 1]) y = (mode == 0) ? fill_above : from_bits(0x7ff8000000000000ULL);
+    }
+    return y;
+}
+
 }  // namespace ogm

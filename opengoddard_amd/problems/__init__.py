@@ -17,6 +17,7 @@ name                      n      what
 ``low_thrust_shipped``    701    C4': 1 phase, 3 states, 4 controls, 100 nodes (reference ex. 10)
 ``low_thrust``           2001    C4: 1 phase, 7 states, 3 controls, 200 nodes
 ``launch4``              6148    C5: 4 knotted phases, 8 states, 4 controls, 128 nodes/phase
+``table_ascent``          281    lookup-table aerodynamics (pattern of reference ex. 11), 40 nodes
 ========================  =====  ==========================================================
 """
 from __future__ import annotations
@@ -31,6 +32,7 @@ _REGISTRY = {
     "low_thrust_shipped": ("low_thrust", {"variant": "3x4", "nodes": [100]}),
     "low_thrust": ("low_thrust", {"variant": "7x3", "nodes": [200]}),
     "launch4": ("launch4", {}),
+    "table_ascent": ("table_ascent", {}),
 }
 
 NAMES = tuple(_REGISTRY)

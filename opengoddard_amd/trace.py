@@ -37,6 +37,7 @@ class Graph:
         self._index = {}
         self.cvecs = []          # constant vectors referenced by ("cvec", i)
         self._cvec_index = {}
+        self.tables = []         # linear lookup tables: (cvec id of x grid, cvec id of y, mode, lo, hi)
 
     def add(self, node, length, isbool=False):
         key = (node, length, isbool)
@@ -409,6 +410,61 @@ def seqsum(vec):
     """Python's builtin ``sum``: left-to-right, starting from int 0 (reference
     ``OpenGoddard/optimize.py:708``)."""
     return Sym(vec.g, vec.g.add(("seqsum", vec.id), None))
+
+
+def interp_linear(xgrid, ygrid, mode, fill_below, fill_above, arg):
+    """Traced ``scipy.interpolate.interp1d(kind="linear")`` call on a traced argument."""
+    g = arg.g
+    xg = np.ascontiguousarray(xgrid, dtype=np.float64)
+    yg = np.ascontiguousarray(ygrid, dtype=np.float64)
+    if xg.ndim != 1 or yg.shape != xg.shape or xg.size < 2:
+        raise TraceError("only 1-D linear interp1d tables are traceable")
+    if np.any(np.diff(xg) <= 0):
+        raise TraceError("interp1d grid must be strictly increasing to be traceable")
+    ix = g.nodes[g.cvec(xg)][1]
+    iy = g.nodes[g.cvec(yg)][1]
+    key = (ix, iy, int(mode), np.float64(fill_below).tobytes(), np.float64(fill_above).tobytes())
+    if key not in g.tables:
+        g.tables.append(key)
+    tid = g.tables.index(key)
+    return Sym(g, g.add(("interp", tid, arg.id), arg.length))
+
+
+class intercept_interp1d:
+    """While tracing, route ``interp1d_object(traced_value)`` to :func:`interp_linear` (the
+    shipped example 11 calls SciPy interpolants inside its callbacks)."""
+
+    def __enter__(self):
+        try:
+            from scipy.interpolate import _polyint
+        except Exception:
+            self._cls = None
+            return self
+        self._cls = _polyint._Interpolator1D
+        self._orig = self._cls.__call__
+        orig = self._orig
+
+        def call(interp, x):
+            if not isinstance(x, Sym):
+                return orig(interp, x)
+            if getattr(interp, "_kind", None) != "linear" or np.ndim(interp.y) != 1:
+                raise TraceError("only linear, 1-D scipy.interpolate.interp1d objects are traceable")
+            if getattr(interp, "_extrapolate", False):
+                mode, lo, hi = 1, 0.0, 0.0
+            elif interp.bounds_error:
+                mode, lo, hi = 2, np.nan, np.nan
+            else:
+                mode = 0
+                lo = float(np.asarray(interp._fill_value_below).reshape(-1)[0])
+                hi = float(np.asarray(interp._fill_value_above).reshape(-1)[0])
+            return interp_linear(interp.x, interp.y, mode, lo, hi, x)
+        self._cls.__call__ = call
+        return self
+
+    def __exit__(self, *exc):
+        if self._cls is not None:
+            self._cls.__call__ = self._orig
+        return False
 
 
 def new_decision_vector(n):

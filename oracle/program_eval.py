@@ -49,6 +49,22 @@ class _Eval:
             out = y[node[2] + node[3] * k] if node[3] else np.float64(y[node[2]])
         elif tag == "un":
             out = _UN[node[1]](self.elem(node[2], length, memo))
+        elif tag == "interp":
+            ix, iy, mode, lo, hi = self.P.tables[node[1]]
+            n = self.P.table_len[node[1]]
+            xg = self.P.cvec[self.P.cvec_off[ix]:self.P.cvec_off[ix] + n]
+            yg = self.P.cvec[self.P.cvec_off[iy]:self.P.cvec_off[iy] + n]
+            xn = np.atleast_1d(np.asarray(self.elem(node[2], length, memo), dtype=float))
+            idx = np.searchsorted(xg, xn).clip(1, n - 1).astype(int)        # SciPy _call_linear
+            slope = (yg[idx] - yg[idx - 1]) / (xg[idx] - xg[idx - 1])
+            out = slope * (xn - xg[idx - 1]) + yg[idx - 1]
+            if mode != 1:
+                flo = np.frombuffer(lo, dtype=np.float64)[0] if mode == 0 else np.nan
+                fhi = np.frombuffer(hi, dtype=np.float64)[0] if mode == 0 else np.nan
+                out[xn < xg[0]] = flo
+                out[xn > xg[-1]] = fhi
+            if np.ndim(self.elem(node[2], length, memo)) == 0:
+                out = np.float64(out[0])
         elif tag == "bin":
             out = _BIN[node[1]](self.elem(node[2], length, memo), self.elem(node[3], length, memo))
         elif tag == "cmp":

@@ -10,7 +10,7 @@ from conftest import GOLDEN
 from opengoddard_amd import _native
 from opengoddard_amd.optimize import Condition, Dynamics, Guess, Problem
 
-LGL_SIZES = (3, 4, 5, 10, 20, 25, 30, 50, 80, 100, 128, 200)
+LGL_SIZES = (3, 4, 5, 10, 20, 25, 30, 40, 50, 80, 100, 128, 200)
 
 
 @pytest.mark.parametrize("n", LGL_SIZES)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Wall-clock to SLSQP convergence, split into callback time and SciPy's SLSQP core
+(second half of BASELINE.json's metric).
+
+    python tools/solve_timing.py goddard [--engine hip|oracle] [--max-restarts N]
+
+``--engine oracle`` runs the same solve with the NumPy restatement of the reference path (CPU) so
+that both columns come from one machine.  Prints one JSON line.
+"""
+import argparse, contextlib, io, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from opengoddard_amd import optimize as og, problems
+
+
+class Timed:
+    def __init__(self, inner):
+        self.inner, self.t_values, self.t_jac, self.n_values, self.n_jac = inner, 0.0, 0.0, 0, 0
+        self._last_v = self._last_j = None
+
+    def values(self, p):
+        t = time.perf_counter(); out = self.inner.values(p); self.t_values += time.perf_counter() - t
+        self.n_values += 1
+        return out
+
+    def jacobians(self, p, lb, ub):
+        t = time.perf_counter(); out = self.inner.jacobians(p, lb, ub); self.t_jac += time.perf_counter() - t
+        self.n_jac += 1
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload")
+    ap.add_argument("--engine", default="hip", choices=["hip", "oracle"])
+    ap.add_argument("--max-restarts", type=int, default=None)
+    ap.add_argument("--ftol", type=float, default=None)
+    a = ap.parse_args()
+    prob, obj = problems.build(a.workload)
+    if a.max_restarts is not None:
+        prob.maxIterator = a.max_restarts
+    holder = {}
+
+    def factory(p, o):
+        if a.engine == "hip":
+            from opengoddard_amd.engine import HipEngine
+            inner = HipEngine(p, o)
+        else:
+            from oracle import np_path
+            inner = np_path.NumpyEngine(p, o)
+        holder["e"] = Timed(inner)
+        return holder["e"]
+
+    og.ENGINE_FACTORY = factory
+    opts = {"ftol": a.ftol} if a.ftol is not None else ({"ftol": 1e-10} if a.workload == "goddard" else {})
+    buf = io.StringIO()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(buf):
+        prob.solve(obj, **opts)
+    wall = time.perf_counter() - t0
+    e = holder["e"]
+    out = buf.getvalue()
+    print(json.dumps({"workload": a.workload, "engine": a.engine, "n": int(prob.number_of_variables),
+                      "wall_s": wall, "t_callbacks_s": e.t_values + e.t_jac,
+                      "t_values_s": e.t_values, "t_jacobians_s": e.t_jac,
+                      "t_slsqp_core_and_python_s": wall - e.t_values - e.t_jac,
+                      "value_calls": e.n_values, "jacobian_calls": e.n_jac,
+                      "restarts": out.count("---- iteration"), "converged": "successfully" in out,
+                      "cost": float(np.atleast_1d(e.inner.values(prob.p)[0])[0])}))
+
+
+if __name__ == "__main__":
+    main()

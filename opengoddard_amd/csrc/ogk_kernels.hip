@@ -23,14 +23,18 @@
 //                        the perturbed variable; because base and perturbed values come from
 //                        the same device functions, every other difference quotient is exactly
 //                        (F0-F0)/dx.  This kernel therefore
-//                          - lets one workgroup own one J_T row (= FD column j): it streams z
-//                            into the row, then re-evaluates only the (group, element) items
-//                            whose traced leaves include p[j] (tables DEP_*), and
+//                          - lets a workgroup own a few J_T rows (= FD columns): it streams
+//                            zeros into them and re-evaluates only the (group, output, element)
+//                            items whose traced leaves include p[j] (tables OGT_COL/OGT_ELEM);
 //                          - runs the collocation product for the N perturbed vectors of each
 //                            state slice on v_mfma_f64_16x16x4_f64 (A = 16 perturbed state
-//                            vectors, B = D^T panel staged in LDS in operand order), writing
-//                            the dense N x N block d(defect_s)/d(state_s) directly.
+//                            vectors, B = the D^T operand image), writing the dense N x N
+//                            block d(defect_s)/d(state_s) directly.
 //                        The result is identical to mode 2 (tests compare them and the CPU twin).
+//
+// D is kept in HBM/L2 in MFMA B-operand order (ogk.h).  Kernels that reuse a panel across
+// wavefronts or states (modes 0 and 2) stage it in LDS; the tiles of mode 1 use each panel once
+// per wavefront and read it straight from L2 (measured: no LDS round trip, no barrier, same speed).
 //   2  ogk_dense         the literal dense sweep: all rows for all columns (validation, and the
 //                        shape SURVEY.md section 7.2 describes).
 //
@@ -42,8 +46,9 @@
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-// Timing experiments only (tools/kstats.sh): -DOGK_EXP=<mask> removes pieces of the kernels so
-// that rocprof durations attribute time to phases.  Results are wrong with any bit set.
+// Timing experiments only (tools/kstats.sh): -DOGK_EXP=<mask> removes pieces of ogk_sweep so that
+// rocprof durations attribute time to phases: 8 = no item evaluation, 16 = no fill, 32 = no MFMA
+// tiles.  Results are wrong with any bit set.
 #ifndef OGK_EXP
 #define OGK_EXP 0
 #endif
@@ -55,14 +60,6 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #endif
 
 namespace {
-
-__device__ __forceinline__ void trace_stamp(double* row, const int slot) {
-#if OGK_TRACE
-    row[slot] = (double)__builtin_amdgcn_s_memtime();
-#else
-    (void)row; (void)slot;
-#endif
-}
 
 struct XCol {
     const double* x0;

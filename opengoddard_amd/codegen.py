@@ -470,8 +470,10 @@ def _group_dependencies(P, grp, roots=None):
 # ------------------------------------------------------------------------------ C++ emission
 _UN_C = {"neg": "-(%s)", "sqrt": "ogm::sqrt_(%s)", "exp": "ogm::exp_(%s)", "log": "ogm::log_(%s)",
          "sin": "ogm::sin_(%s)", "cos": "ogm::cos_(%s)", "tan": "ogm::tan_(%s)",
-         "abs": "ogm::fabs_(%s)"}
-_BIN_C = {"add": "%s + %s", "sub": "%s - %s", "mul": "%s * %s", "div": "%s / %s"}
+         "abs": "ogm::fabs_(%s)", "atan": "ogm::atan_(%s)", "asin": "ogm::asin_(%s)",
+         "acos": "ogm::acos_(%s)"}
+_BIN_C = {"add": "%s + %s", "sub": "%s - %s", "mul": "%s * %s", "div": "%s / %s",
+          "atan2": "ogm::atan2_(%s, %s)"}
 _CMP_C = {"lt": "<", "le": "<=", "gt": ">", "ge": ">=", "eq": "==", "ne": "!="}
 
 

@@ -220,6 +220,165 @@ OG_HD double tan_(double x) {
     return (q & 1) ? -(c / s) : (s / c);
 }
 
+// ---------------------------------------------------------------- atan / atan2 / asin / acos
+OG_HD double atan_(double x) {
+    const double hi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01,
+                          9.82793723247329054082e-01, 1.57079632679489655800e+00};
+    const double lo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17,
+                          1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01,
+                 a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
+                 a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02,
+                 a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
+                 a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02,
+                 a10 = 1.62858201153657823623e-02;
+    if (isnan_(x)) return x;
+    const bool neg = (bits_of(x) >> 63) != 0;
+    const uint32_t ix = hi_word(x) & 0x7fffffffu;
+    if (ix >= 0x44100000u) {                          // |x| >= 2^66 (or inf)
+        const double r = hi[3] + lo[3];
+        return neg ? -r : r;
+    }
+    int id;
+    if (ix < 0x3fdc0000u) {                           // |x| < 0.4375
+        if (ix < 0x3e200000u) return x;               // |x| < 2^-29
+        id = -1;
+    } else {
+        x = fabs_(x);
+        if (ix < 0x3ff30000u) {                       // |x| < 1.1875
+            if (ix < 0x3fe60000u) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); }
+            else                  { id = 1; x = (x - 1.0) / (x + 1.0); }
+        } else if (ix < 0x40038000u) {                // |x| < 2.4375
+            id = 2; x = (x - 1.5) / (1.0 + 1.5 * x);
+        } else {
+            id = 3; x = -1.0 / x;
+        }
+    }
+    const double z = x * x;
+    const double w = z * z;
+    const double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+    const double s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const double r = hi[id] - ((x * (s1 + s2) - lo[id]) - x);
+    return neg ? -r : r;
+}
+
+OG_HD double atan2_(double y, double x) {
+    const double pi = 3.1415926535897931160e+00, pi_lo = 1.2246467991473531772e-16;
+    const double pi_o_2 = 1.5707963267948965580e+00, pi_o_4 = 7.8539816339744827900e-01;
+    if (isnan_(x) || isnan_(y)) return x + y;
+    const uint64_t ux = bits_of(x), uy = bits_of(y);
+    const uint32_t hx = (uint32_t)(ux >> 32), hy = (uint32_t)(uy >> 32);
+    const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    const int m = (int)((hy >> 31) & 1u) | (int)((hx >> 30) & 2u);     // 2*sign(x) + sign(y)
+    if (x == 1.0) return atan_(y);
+    if ((uy << 1) == 0) {                             // y == +-0
+        switch (m) { case 0: case 1: return y; case 2: return pi; default: return -pi; }
+    }
+    if ((ux << 1) == 0) return (hy >> 31) ? -pi_o_2 : pi_o_2;           // x == +-0
+    const bool xinf = (ux << 1) == 0xffe0000000000000ULL, yinf = (uy << 1) == 0xffe0000000000000ULL;
+    if (xinf) {
+        if (yinf) {
+            switch (m) { case 0: return pi_o_4; case 1: return -pi_o_4;
+                         case 2: return 3.0 * pi_o_4; default: return -3.0 * pi_o_4; }
+        }
+        switch (m) { case 0: return 0.0; case 1: return -0.0; case 2: return pi; default: return -pi; }
+    }
+    if (yinf) return (hy >> 31) ? -pi_o_2 : pi_o_2;
+    const int k = ((int)iy - (int)ix) >> 20;
+    double z;
+    int mm = m;
+    if (k > 60) { z = pi_o_2 + 0.5 * pi_lo; mm &= 1; }                  // |y/x| > 2^60
+    else if ((hx >> 31) && k < -60) z = 0.0;                             // 0 > |y|/x > -2^-60
+    else z = atan_(fabs_(y / x));
+    switch (mm) {
+        case 0: return z;
+        case 1: return -z;
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
+OG_HD double asin_poly_p(double t) {
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+                 pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+                 pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05;
+    return t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+}
+
+OG_HD double asin_poly_q(double t) {
+    const double qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+                 qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    return 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+}
+
+OG_HD double asin_(double x) {
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+    const double pio4_hi = 7.85398163397448278999e-01;
+    if (isnan_(x)) return x;
+    const bool neg = (bits_of(x) >> 63) != 0;
+    const uint32_t ix = hi_word(x) & 0x7fffffffu;
+    const double ax = fabs_(x);
+    if (ax >= 1.0) {
+        if (ax == 1.0) return x * pio2_hi + x * pio2_lo;
+        return (x - x) / (x - x);                      // |x| > 1: NaN
+    }
+    if (ix < 0x3fe00000u) {                            // |x| < 0.5
+        if (ix < 0x3e500000u) return x;                // |x| < 2^-26
+        const double t = x * x;
+        return x + x * (asin_poly_p(t) / asin_poly_q(t));
+    }
+    const double w = 1.0 - ax;
+    const double t = w * 0.5;
+    const double p = asin_poly_p(t), q = asin_poly_q(t);
+    const double s = sqrt_(t);
+    double r;
+    if (ix >= 0x3fef3333u) {                           // |x| >= 0.975
+        r = pio2_hi - (2.0 * (s + s * (p / q)) - pio2_lo);
+    } else {
+        const double sh = from_bits(bits_of(s) & 0xffffffff00000000ULL);
+        const double c = (t - sh * sh) / (s + sh);
+        const double rr = p / q;
+        const double pp = 2.0 * s * rr - (pio2_lo - 2.0 * c);
+        const double qq = pio4_hi - 2.0 * sh;
+        r = pio4_hi - (pp - qq);
+    }
+    return neg ? -r : r;
+}
+
+OG_HD double acos_(double x) {
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+    const double pi = 3.14159265358979311600e+00;
+    if (isnan_(x)) return x;
+    const bool neg = (bits_of(x) >> 63) != 0;
+    const uint32_t ix = hi_word(x) & 0x7fffffffu;
+    const double ax = fabs_(x);
+    if (ax >= 1.0) {
+        if (ax == 1.0) return neg ? pi + 2.0 * pio2_lo : 0.0;
+        return (x - x) / (x - x);
+    }
+    if (ix < 0x3fe00000u) {                            // |x| < 0.5
+        if (ix <= 0x3c600000u) return pio2_hi + pio2_lo;      // |x| < 2^-57
+        const double z = x * x;
+        const double r = asin_poly_p(z) / asin_poly_q(z);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (neg) {                                          // x < -0.5
+        const double z = (1.0 + x) * 0.5;
+        const double s = sqrt_(z);
+        const double r = asin_poly_p(z) / asin_poly_q(z);
+        const double w = r * s - pio2_lo;
+        return pi - 2.0 * (s + w);
+    }
+    const double z = (1.0 - x) * 0.5;                   // x > 0.5
+    const double s = sqrt_(z);
+    const double df = from_bits(bits_of(s) & 0xffffffff00000000ULL);
+    const double c = (z - df * df) / (s + df);
+    const double r = asin_poly_p(z) / asin_poly_q(z);
+    const double w = r * s + c;
+    return 2.0 * (df + w);
+}
+
 // ---------------------------------------------------------------- linear table lookup
 // scipy.interpolate.interp1d(kind="linear") as the reference's example 11 uses it
 // (examples/11_Polar_TSTO_Taiki.py:21-27; SciPy 1.15.3 scipy/interpolate/_interpolate.py

@@ -10,7 +10,8 @@ it.  :mod:`opengoddard_amd.codegen` lowers the recorded graph to HIP device func
 
 Supported (this is what the shipped examples use, SURVEY.md section 0 finding 1): ``+ - * /``,
 unary minus, ``**`` with exponent 2 / 0.5 / 1 / -1 (NumPy's fast paths), ``np.sqrt exp log sin
-cos tan abs square deg2rad rad2deg maximum minimum where``, comparisons, integer / negative
+cos tan arctan arcsin arccos arctan2 abs square deg2rad rad2deg maximum minimum where``, linear
+``scipy.interpolate.interp1d`` objects, comparisons, integer / negative
 indexing, unit-step slicing, boolean-mask assignment with a scalar (``h[h < a] = a``,
 reference ``examples/09_Rocket_Ascent_Polar_TSTO.py:36``), ``np.hstack / concatenate / append``.
 Anything else raises :class:`TraceError` - there is no silent CPU fallback.
@@ -73,11 +74,12 @@ def const_value(node):
 _UNARY = {
     np.negative: "neg", np.sqrt: "sqrt", np.exp: "exp", np.log: "log", np.sin: "sin",
     np.cos: "cos", np.tan: "tan", np.absolute: "abs", np.fabs: "abs", np.square: "square",
-    np.positive: "pos", np.reciprocal: "recip",
+    np.positive: "pos", np.reciprocal: "recip", np.arctan: "atan", np.arcsin: "asin",
+    np.arccos: "acos",
 }
 _BINARY = {
     np.add: "add", np.subtract: "sub", np.multiply: "mul", np.true_divide: "div",
-    np.maximum: "max", np.minimum: "min",
+    np.maximum: "max", np.minimum: "min", np.arctan2: "atan2",
 }
 _COMPARE = {
     np.less: "lt", np.less_equal: "le", np.greater: "gt", np.greater_equal: "ge",

@@ -11,9 +11,10 @@ from __future__ import annotations
 import numpy as np
 
 _UN = {"neg": np.negative, "sqrt": np.sqrt, "exp": np.exp, "log": np.log, "sin": np.sin,
-       "cos": np.cos, "tan": np.tan, "abs": np.abs}
+       "cos": np.cos, "tan": np.tan, "abs": np.abs, "atan": np.arctan, "asin": np.arcsin,
+       "acos": np.arccos}
 _BIN = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.true_divide,
-        "max": np.maximum, "min": np.minimum}
+        "max": np.maximum, "min": np.minimum, "atan2": np.arctan2}
 _CMP = {"lt": np.less, "le": np.less_equal, "gt": np.greater, "ge": np.greater_equal,
         "eq": np.equal, "ne": np.not_equal}
 

@@ -18,6 +18,10 @@ void v_log(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i]
 void v_sin(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::sin_(x[i]); }
 void v_cos(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::cos_(x[i]); }
 void v_tan(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::tan_(x[i]); }
+void v_atan(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::atan_(x[i]); }
+void v_asin(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::asin_(x[i]); }
+void v_acos(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::acos_(x[i]); }
+void v_atan2(const double* yy, const double* xx, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = ogm::atan2_(yy[i], xx[i]); }
 }
 """
 
@@ -54,11 +58,46 @@ def ulps(a, b):
     ("v_sin", np.sin, lambda r: r.uniform(-1e5, 1e5, 200000), 1.0),
     ("v_cos", np.cos, lambda r: r.uniform(-1e5, 1e5, 200000), 1.0),
     ("v_tan", np.tan, lambda r: r.uniform(-1.5, 1.5, 200000), 2.0),
+    ("v_atan", np.arctan, lambda r: r.standard_normal(200000) * 10.0 ** r.integers(-10, 10, 200000), 1.0),
+    ("v_asin", np.arcsin, lambda r: r.uniform(-1, 1, 200000), 1.0),
+    ("v_acos", np.arccos, lambda r: r.uniform(-1, 1, 200000), 1.0),
+    ("v_asin", np.arcsin, lambda r: np.sign(r.uniform(-1, 1, 200000)) * (1 - 10.0 ** r.uniform(-12, -1, 200000)), 1.0),
+    ("v_acos", np.arccos, lambda r: np.sign(r.uniform(-1, 1, 200000)) * (1 - 10.0 ** r.uniform(-12, -1, 200000)), 1.0),
 ])
 def test_within_one_ulp_of_numpy(lib, name, ref, sample, tol):
     x = sample(np.random.default_rng(0))
     got, want = call(lib, name, x), ref(x)
     assert np.max(ulps(got, want)) <= tol
+
+
+def test_atan2_within_one_ulp_and_special_values(lib):
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal(300000) * 10.0 ** rng.integers(-8, 8, 300000)
+    x = rng.standard_normal(300000) * 10.0 ** rng.integers(-8, 8, 300000)
+    yy, xx = np.ascontiguousarray(y), np.ascontiguousarray(x)
+    out = np.empty_like(yy)
+    dp = C.POINTER(C.c_double)
+    lib.v_atan2(yy.ctypes.data_as(dp), xx.ctypes.data_as(dp), out.ctypes.data_as(dp), yy.size)
+    assert np.max(ulps(out, np.arctan2(y, x))) <= 1.0
+    inf, nan = np.inf, np.nan
+    ys = np.array([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, inf, -inf, inf, 1.0, -1.0, 1.0, nan, 1.0, 3.0])
+    xs = np.array([1.0, 1.0, -1.0, -1.0, 0.0, 0.0, inf, inf, -inf, inf, -inf, -inf, 1.0, nan, 1.0])
+    out = np.empty_like(ys)
+    lib.v_atan2(ys.ctypes.data_as(dp), xs.ctypes.data_as(dp), out.ctypes.data_as(dp), ys.size)
+    want = np.arctan2(ys, xs)
+    assert np.array_equal(np.isnan(out), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.max(ulps(out[ok][want[ok] != 0], want[ok][want[ok] != 0])) <= 1.0
+    assert np.array_equal(out[ok][want[ok] == 0], want[ok][want[ok] == 0])
+    assert np.array_equal(np.signbit(out[ok]), np.signbit(want[ok]))
+    edge = call(lib, "v_asin", [1.0, -1.0, 0.0, 1.5, 1e-300])
+    assert ulps(edge[:2], np.arcsin([1.0, -1.0])).max() <= 1.0 and edge[2] == 0.0 and np.isnan(edge[3])
+    assert edge[4] == 1e-300
+    edge = call(lib, "v_acos", [1.0, -1.0, 0.0, -1.5])
+    assert edge[0] == 0.0 and ulps(edge[1:3], np.arccos([-1.0, 0.0])).max() <= 1.0 and np.isnan(edge[3])
+    big = call(lib, "v_atan", [inf, -inf, 1e300, -1e300, 0.0, -0.0])
+    assert ulps(big[:4], np.arctan([inf, -inf, 1e300, -1e300])).max() <= 1.0
+    assert big[4] == 0.0 and np.signbit(big[5])
 
 
 def test_special_values(lib):

@@ -167,6 +167,8 @@ def _trace_eval(fn, n=12, seed=0):
     lambda p: np.where(p[0:5] > 1.0, p[5:10], -p[0:5]),
     lambda p: (1 / p[0:4] ** 2 + p[4:8] ** -1) * np.deg2rad(30.0),
     lambda p: np.append(p[0:2] - 1, p[10] * p[11]),
+    lambda p: np.arctan2(p[0:4] - 1.2, p[4:8] - 1.1) + np.arctan(p[8:12]),
+    lambda p: np.arcsin(p[0:6] / 2.5) - np.arccos(p[6:12] / 2.5),
 ])
 def test_tracer_matches_numpy_on_small_expressions(fn):
     got, want = _trace_eval(fn)
@@ -189,7 +191,7 @@ def test_tracer_rejects_untraceable_callbacks():
     with pytest.raises(tr.TraceError):
         p[0:4] ** 3.0                          # libm pow has no bit-reproducible device twin
     with pytest.raises(tr.TraceError):
-        np.arctan2(p[0:2], p[2:4])
+        np.hypot(p[0:2], p[2:4])
     with pytest.raises(tr.TraceError):
         np.sum(p[0:4])
     with pytest.raises(tr.TraceError):

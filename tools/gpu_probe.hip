@@ -53,6 +53,9 @@ __global__ void math_probe(const double* x, const double* y, double* o, int n) {
     o[5 * n + i] = ogm::log_(ogm::fabs_(y[i]));
     o[6 * n + i] = x[i] * y[i] + y[i];            // must NOT be contracted into an fma
     o[7 * n + i] = ogm::tan_(x[i]);
+    o[8 * n + i] = ogm::atan2_(x[i], y[i]);
+    o[9 * n + i] = ogm::asin_(x[i] / 30.0);
+    o[10 * n + i] = ogm::acos_(x[i] / 30.0);
 }
 
 __global__ void fill_kernel(double4* p, size_t n) {
@@ -171,7 +174,7 @@ int main() {
     // ---- 2. scalar math parity host <-> device
     {
         const int n = 1 << 20;
-        std::vector<double> x(n), y(n), o(8 * (size_t)n);
+        std::vector<double> x(n), y(n), o(11 * (size_t)n);
         srand(99);
         for (int i = 0; i < n; ++i) {
             x[i] = (urand() - 0.5) * 60.0;
@@ -181,13 +184,14 @@ int main() {
         double *dx, *dy, *dout;
         CK(hipMalloc(&dx, n * 8));
         CK(hipMalloc(&dy, n * 8));
-        CK(hipMalloc(&dout, 8 * (size_t)n * 8));
+        CK(hipMalloc(&dout, 11 * (size_t)n * 8));
         CK(hipMemcpy(dx, x.data(), n * 8, hipMemcpyHostToDevice));
         CK(hipMemcpy(dy, y.data(), n * 8, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(math_probe, dim3(n / 256), dim3(256), 0, 0, dx, dy, dout, n);
-        CK(hipMemcpy(o.data(), dout, 8 * (size_t)n * 8, hipMemcpyDeviceToHost));
-        const char* names[8] = {"div", "sqrt", "exp", "sin", "cos", "log", "mul+add", "tan"};
-        for (int f = 0; f < 8; ++f) {
+        CK(hipMemcpy(o.data(), dout, 11 * (size_t)n * 8, hipMemcpyDeviceToHost));
+        const char* names[11] = {"div", "sqrt", "exp", "sin", "cos", "log", "mul+add", "tan",
+                                 "atan2", "asin", "acos"};
+        for (int f = 0; f < 11; ++f) {
             int diff = 0;
             for (int i = 0; i < n; ++i) {
                 double h;
@@ -199,7 +203,10 @@ int main() {
                     case 4: h = ogm::cos_(x[i]); break;
                     case 5: h = ogm::log_(ogm::fabs_(y[i])); break;
                     case 6: { volatile double t = x[i] * y[i]; h = t + y[i]; } break;
-                    default: h = ogm::tan_(x[i]); break;
+                    case 7: h = ogm::tan_(x[i]); break;
+                    case 8: h = ogm::atan2_(x[i], y[i]); break;
+                    case 9: h = ogm::asin_(x[i] / 30.0); break;
+                    default: h = ogm::acos_(x[i] / 30.0); break;
                 }
                 const double d = o[(size_t)f * n + i];
                 if (!(d == h) && !(d != d && h != h)) ++diff;

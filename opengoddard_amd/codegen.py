@@ -599,6 +599,9 @@ class _Emitter:
             for ln, body in node[1]:
                 if self._collect_sums([body]):
                     raise _tr.TraceError("nested sums are not supported")
+                # unrolled so that the loads of several terms are in flight; the additions stay in
+                # order (Python's left-to-right sum)
+                lines.append("%s_Pragma(\"unroll 8\")" % pad)
                 lines.append("%sfor (int q = 0; q < %d; ++q) {" % (pad, ln))
                 inner = {}
                 self._emit_expr([body], "q", lines, inner, indent + 4, {})

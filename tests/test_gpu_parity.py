@@ -119,6 +119,47 @@ def test_structured_sweep_equals_dense_sweep(name, golden, monkeypatch):
     assert (JT_s != 0).mean() < 0.2
 
 
+@pytest.mark.parametrize("name", ["polar_tsto", "low_thrust", "launch4"])
+def test_full_size_jacobian_has_the_pseudospectral_structure(name, golden):
+    """Size-independent properties of the equality Jacobian at BASELINE.json's full sizes
+    (SURVEY.md Appendix C): for phase i, state s the block d(defect_s)/d(state_s) is the LGL
+    differentiation matrix D_i off the diagonal (the dynamics term is node-local), blocks
+    between different states of a phase are diagonal, blocks between different phases vanish
+    except through the phase times, and every row of D_i sums to zero."""
+    G = golden("cfg_" + name)
+    prob, obj, eng, tw = _engine_and_twin(name)
+    x, h = G["x"][0], G["h"][0]
+    F0, JT = eng.sweep_stacked(x, h)
+    P = eng.program
+    nphase = len(P.nodes)
+    tf_cols = set(range(eng.n - nphase, eng.n))
+    slots = []
+    for g in P.groups:
+        if g.kind == "defect":
+            for (row, _), sl in zip(g.outputs, g.mv_slots):
+                slots.append((g.phase, row, P.mv[sl].leaf_base, g.length))
+    for phase, row, leaf, N in slots:
+        D = prob.D[phase]
+        block = JT[leaf:leaf + N, row:row + N].T             # [k, l] = d defect(k) / d x(l)
+        off = ~np.eye(N, dtype=bool)
+        scale = np.abs(D).max()
+        assert np.max(np.abs(block[off] - D[off])) <= 2e-6 * scale      # FD of a linear map
+        assert abs(D.sum(axis=1)).max() <= 1e-9 * scale
+        for phase2, row2, leaf2, N2 in slots:
+            other = JT[leaf2:leaf2 + N2, row:row + N].T      # d defect_s(k) / d state_s'(l)
+            if phase2 != phase:
+                assert not other.any()                        # exact structural zeros
+            elif leaf2 != leaf:
+                assert not other[~np.eye(N, dtype=bool)].any()          # node-local coupling
+    # defect rows depend on no variable of another phase except the phase times
+    for phase, row, leaf, N in slots:
+        cols = np.nonzero(JT[:, row:row + N].any(axis=1))[0]
+        lo = 0 if phase == 0 else prob.div[phase - 1][-1]
+        hi = prob.div[phase][-1]
+        assert all((lo <= c < hi) or (c in tf_cols) for c in cols)
+    eng.close()
+
+
 def test_non_finite_rows_propagate_like_dense_fd():
     """A row that is NaN/inf at x0 makes its whole Jacobian row NaN in SciPy's dense FD
     ((NaN - NaN)/dx); the structured sweep must reproduce that, not write zeros."""

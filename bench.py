@@ -125,11 +125,11 @@ def main():
         if collective else d_local
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
+    def step(gather=True):
         eng.eval_dev(d_x.data_ptr(), d_F0.data_ptr(), stream)
         eng.columns_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, d_local.data_ptr(),
                         d_F0.data_ptr(), stream)
-        if collective:
+        if collective and gather:
             dist.all_gather_into_tensor(d_full, d_local)
 
     def fence():
@@ -149,6 +149,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same K steps without the all-gather: how the column-sharded kernels alone scale
+    # (the collective costs more than the sweep it reassembles)
+    elapsed_local = elapsed
+    if collective:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(gather=False)
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_local = float(t.item())
 
     # duration of the dominant kernel from HIP events on the launch stream.  A single
     # event-to-event interval around one launch carries ~2 us of event overhead (an empty kernel
@@ -195,6 +207,8 @@ def main():
         "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
+        "value_without_collective": (3 * n + 2) * a.steps / elapsed_local,
+        "ms_per_step_without_collective": elapsed_local / a.steps * 1e3,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",

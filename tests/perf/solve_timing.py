@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""Wall-clock to SLSQP convergence, split into callback time and SciPy's SLSQP core
+"""Measurement script (lives under tests/ because its CPU leg uses the test-only oracle).
+
+Wall-clock to SLSQP convergence, split into callback time and SciPy's SLSQP core
 (second half of BASELINE.json's metric).
 
-    python tools/solve_timing.py goddard [--engine hip|oracle] [--max-restarts N]
+    python tests/perf/solve_timing.py goddard [--engine hip|oracle] [--max-restarts N]
 
 ``--engine oracle`` runs the same solve with the NumPy restatement of the reference path (CPU) so
 that both columns come from one machine.  Prints one JSON line.
 """
 import argparse, contextlib, io, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from opengoddard_amd import optimize as og, problems
 

@@ -696,8 +696,6 @@ def emit_header(P):
          "    static constexpr int MAX_NMV = %d;" % max([len(g.mv_slots) for g in P.groups] + [1]),
          "    static constexpr int N_ROW_ITEMS = %d;" % n_rowitems,
          _int_table("PHASE_NODES", P.nodes),
-         _int_table("MV_PHASE", [s.phase for s in P.mv]),
-         _int_table("MV_LEN", [s.length for s in P.mv]),
          _int_table("MV_LEAF", [s.leaf_base for s in P.mv]),
          _int_table("G_KIND", [1 if g.kind == "defect" else 0 for g in P.groups]),
          _int_table("G_LEN", [g.length for g in P.groups]),
@@ -725,10 +723,8 @@ def emit_header(P):
         g_ndep.append(len(g.deps))
         for kind, base, cnt in g.deps:
             dep_g.append(gi), dep_kind.append(kind), dep_base.append(base), dep_cnt.append(cnt)
-    L.append("    static constexpr int N_DEP = %d;" % len(dep_g))
-    L += [_int_table("DEP_G", dep_g), _int_table("DEP_KIND", dep_kind),
-          _int_table("DEP_BASE", dep_base), _int_table("DEP_CNT", dep_cnt),
-          _int_table("G_DEP0", g_dep0), _int_table("G_NDEP", g_ndep)]
+    L += [_int_table("DEP_KIND", dep_kind), _int_table("DEP_BASE", dep_base),
+          _int_table("DEP_CNT", dep_cnt)]
     # collocation slots: owning group, offset of their base product in the y0 scratch
     slot_group = [0] * len(P.mv)
     for gi, g in enumerate(P.groups):
@@ -765,7 +761,6 @@ def emit_header(P):
     counts = np.diff(col_ptr)
     heavy = [int(j) for j in np.nonzero(counts > HEAVY_COLUMN_ELEMENTS)[0]]
     heavy.sort(key=lambda j: -counts[j])
-    light = [j for j in range(P.n) if counts[j] <= HEAVY_COLUMN_ELEMENTS]
     # rows of a J_T row written by the MFMA tiles (j inside a collocated state slice)
     own_lo, own_hi = [0] * P.n, [0] * P.n
     mv_diag, mv_generic = [], []
@@ -781,13 +776,8 @@ def emit_header(P):
                     for kind, base, cnt in g.deps)
         mv_diag.append(int(diag))
         mv_generic.append(int(other))
-    L += ["    static constexpr int N_HEAVY = %d;" % len(heavy),
-          "    static constexpr int N_ELEM = %d;" % len(elem_g),
-          _int_table("COL_ORDER", heavy + light), _int_table("COL_PTR", col_ptr),
-          _int_table("ELEM_G", elem_g), _int_table("ELEM_O", elem_o), _int_table("ELEM_K", elem_k),
-          _int_table("COL_OWN_LO", own_lo), _int_table("COL_OWN_HI", own_hi),
-          _int_table("MV_DIAG", mv_diag), _int_table("MV_GENERIC", mv_generic)]
-    L += [_int_table("MV_GROUP", slot_group), _int_table("MV_Y0", y0_off),
+    L.append("    static constexpr int N_HEAVY = %d;" % len(heavy))
+    L += [_int_table("MV_Y0", y0_off),
           "    static constexpr int N_Y0 = %d;" % max(at, 1)]
     L.append("")
     for gi, g in enumerate(P.groups):

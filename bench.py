@@ -52,10 +52,27 @@ def cpu_baseline(name, seconds=10.0):
         dt = time.perf_counter() - t0
         if dt >= seconds:
             break
-    return {"value": evals / dt, "unit": "callback evals/s", "cores": 1, "kind": "port",
-            "sample": "%d full FD sweeps of %s (n=%d, 3(n+1) callback evaluations each) with the "
-                      "NumPy restatement of the reference path, %.1f s" % (sweeps, name, n, dt),
-            "host_cpus": os.cpu_count()}
+    out = {"value": evals / dt, "unit": "callback evals/s", "cores": 1, "kind": "port",
+           "sample": "%d full FD sweeps of %s (n=%d, 3(n+1) callback evaluations each) with the "
+                     "NumPy restatement of the reference path, %.1f s" % (sweeps, name, n, dt),
+           "host_cpus": os.cpu_count()}
+    # context only: the same dense column loop as compiled C++ (oracle/twin.cpp, one core) - how
+    # much of the GPU/NumPy ratio is Python interpreter overhead rather than arithmetic
+    try:
+        from opengoddard_amd import _native
+        from oracle import twin
+        tw = twin.Twin(prob, obj)
+        h = _native.fd_step(x0, lb, ub)
+        cols = np.arange(min(n, 256))
+        tw.sweep(x0, h, cols[:8])
+        t0 = time.perf_counter()
+        tw.sweep(x0, h, cols)
+        dt2 = time.perf_counter() - t0
+        out["compiled_cpp_dense_loop_evals_per_s"] = 3 * (cols.size + 1) / dt2
+    except Exception as exc:                                   # never let context break the line
+        out["compiled_cpp_dense_loop_evals_per_s"] = None
+        out["compiled_cpp_note"] = repr(exc)
+    return out
 
 
 def measured_traffic(workload):

@@ -363,6 +363,10 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
     if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_fd_sweep: bad column range");
     OG_HIP(hipSetDevice(p->device));
     const size_t need = (size_t)(hi - lo) * (size_t)p->m;
+    if (need == 0) {                     // empty column range: only F(x) is produced
+        if (!F0) return 0;
+        return og_eval(p, x, F0);
+    }
     if (need > p->jt_capacity) {
         if (p->d_jt) OG_HIP(hipFree(p->d_jt));
         p->d_jt = nullptr;

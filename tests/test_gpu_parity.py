@@ -239,3 +239,47 @@ def test_hardware_probe():
                          timeout=300)
     print(out.stdout)
     assert out.returncode == 0, out.stdout
+
+
+def test_cabi_error_paths_on_device(golden):
+    """The C ABI reports misuse through return codes + og_last_error(), never by crashing."""
+    import ctypes as C
+    from opengoddard_amd.engine import HipEngine
+    lib = _native.lib()
+    prob, obj = problems.build("brachistochrone")
+    eng = HipEngine(prob, obj)
+    n, m = eng.n, eng.m
+    dims = [C.c_int32() for _ in range(4)]
+    assert lib.og_problem_dims(eng._handle, *[C.byref(d) for d in dims]) == 0
+    assert [d.value for d in dims] == [n, m, eng.m_eq, eng.m_ineq]
+    x = np.zeros(n)
+    JT = np.zeros((n, m))
+    assert lib.og_fd_sweep(eng._handle, _native.dptr(x), _native.dptr(x), 3, 2, _native.dptr(JT), None) != 0
+    assert b"bad column range" in lib.og_last_error()
+    assert lib.og_fd_sweep(eng._handle, _native.dptr(x), _native.dptr(x), 0, n + 1, _native.dptr(JT), None) != 0
+    assert lib.og_eval(eng._handle, None, _native.dptr(JT)) != 0
+    assert b"null" in lib.og_last_error()
+    # an empty column range is legal and touches nothing
+    sentinel = np.full((1, m), 7.0)
+    F0 = np.zeros(m)
+    h = np.full(n, 1e-8)
+    assert lib.og_fd_sweep(eng._handle, _native.dptr(np.clip(prob.p, 0, None)), _native.dptr(h), 5, 5,
+                           _native.dptr(sentinel), _native.dptr(F0)) == 0
+    assert np.all(sentinel == 7.0) and np.isfinite(F0).any()
+    # descriptor / module mismatch
+    desc = _native.OgDesc(abi_version=_native.OG_ABI_VERSION, device=0, n=n + 1, m_eq=eng.m_eq,
+                          m_ineq=eng.m_ineq, n_phase=1, nodes=eng._nodes, D=eng._Dptr, cvec=None,
+                          n_cvec=int(eng._cvec.size), module_path=eng.module_path.encode())
+    handle = C.c_void_p()
+    assert lib.og_problem_create(C.byref(desc), C.byref(handle)) != 0
+    assert b"does not match" in lib.og_last_error() and not handle.value
+    desc.n = n
+    desc.module_path = b"/nonexistent/libogk.so"
+    assert lib.og_problem_create(C.byref(desc), C.byref(handle)) != 0
+    assert b"dlopen" in lib.og_last_error()
+    desc.module_path = eng.module_path.encode()
+    desc.device = 99
+    assert lib.og_problem_create(C.byref(desc), C.byref(handle)) != 0
+    assert b"device" in lib.og_last_error()
+    eng.close()
+    eng.close()                                   # idempotent

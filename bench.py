@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="polar_tsto")
+    ap.add_argument("--nodes", default=None,
+                    help="comma-separated LGL node counts per phase (size studies; default: the "
+                         "workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-collective", action="store_true",
@@ -125,7 +128,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    prob, obj = problems.build(a.workload)
+    build_kw = {"nodes": [int(v) for v in a.nodes.split(",")]} if a.nodes else {}
+    prob, obj = problems.build(a.workload, **build_kw)
     eng = HipEngine(prob, obj, device=local_rank)
     n, m = eng.n, eng.m
     lb = np.array([-np.inf if b[0] is None else b[0] for b in prob.bounds])

@@ -863,8 +863,14 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     for gi, g in enumerate(P.groups):
         if g.kind == "rows":
             for k0 in range(0, g.length, 64):
-                rowwaves.append([gi, k0, 0, 0])
+                rowwaves.append([gi, k0, g.length, 0])
+    evalblk = []
+    for gi, g in enumerate(P.groups):
+        if g.kind == "defect":
+            for nt in range((g.length + 15) // 16):
+                evalblk.append([gi, nt, g.mv_slots[0], len(g.mv_slots)])
     L = ["#if defined(__HIPCC__)", "struct ogt_int8 { int v[8]; };"]
+    L += table("int4", "OGT_EVALBLK", evalblk)
     L += table("int4", "OGT_ROWWAVE", rowwaves)
     L.append("static constexpr int OGT_N_ROWWAVES = %d;" % len(rowwaves))
     L += table("int4", "OGT_COL", col)

@@ -242,21 +242,19 @@ __device__ __forceinline__ void publish_row(const ogk_args& a, const int row, co
 }
 
 __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx, double* lds) {
-    int nt;
-    const int g = defect_block_to_group(bx, &nt);
-    if (g < 0) return;
-    const int N = OgGen::G_LEN(g);
+    const int4 blk = OGT_EVALBLK[bx];                   // {group, node tile, first slot, #slots}
+    const int nt = blk.y, mv0 = blk.z, nmv = blk.w;
+    const ogt_int8 rec0 = OGT_SLOT[mv0];
+    const int N = rec0.v[0];
     const int KS = (N + 3) >> 2;
     const int NP = KS * 4;
-    const int mv0 = OgGen::G_MV0(g);
-    const int nmv = OgGen::G_NMV(g);
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
 
     double* dpanel = lds;
     double* xt = lds + KS * 64;
     double* ybuf = xt + OgGen::MAX_NMV * NP;            // [state][16 nodes]
-    const double* src = a.dfrag + a.dfrag_off[OgGen::G_PHASE(g)] + (long)nt * KS * 64;
+    const double* src = a.dfrag + a.dfrag_off[rec0.v[5]] + (long)nt * KS * 64;
     constexpr int UNR = 4;
     double pv[UNR];
 #pragma unroll
@@ -269,7 +267,7 @@ __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx
             double v = 0.0;
             if (s < nmv && l < N) {
                 v = OgGen::mv_operand(mv0 + s, l, base, a.cvec);
-                if (nt == 0) a.xop[OgGen::MV_Y0(mv0 + s) + l] = v;
+                if (nt == 0) a.xop[OGT_SLOT[mv0 + s].v[4] + l] = v;
             }
             xt[s * NP + l] = v;
         }
@@ -309,21 +307,22 @@ __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx
     const int k = nt * 16 + lane;
     if (lane >= 16 || k >= N) return;
     for (int s = wave; s < nmv; s += SWEEP_WAVES) {
+        const ogt_int8 rec = OGT_SLOT[mv0 + s];
         const double y = ybuf[s * 16 + lane];
         const double T = OgGen::tail_one(mv0 + s, k, base, a.cvec);
-        const int row = OgGen::G_ROW(g, s) + k;
+        const int row = rec.v[3] + k;
         publish_row(a, row, y - T);
         a.t0[row] = T;
-        a.y0[OgGen::MV_Y0(mv0 + s) + k] = y;
+        a.y0[rec.v[4] + k] = y;
     }
 }
 
 __device__ __forceinline__ void eval_rows_body(const ogk_args& a, const int bx) {
     const int w = bx * SWEEP_WAVES + ((int)threadIdx.x >> 6);
     if (w >= OGT_N_ROWWAVES) return;
-    const int4 rw = OGT_ROWWAVE[w];                       // {group, first element}
+    const int4 rw = OGT_ROWWAVE[w];                       // {group, first element, group length}
     const int k = rw.y + ((int)threadIdx.x & 63);
-    if (k >= OgGen::G_LEN(rw.x)) return;
+    if (k >= rw.z) return;
     const XCol base{a.x0, -1, 0.0};
     int row;
     const double v = OgGen::item_value(rw.x, 0, k, base, a.y0, a.cvec, &row);

@@ -84,6 +84,27 @@ def build_core(force=False):
     return CORE_LIB
 
 
+SQP_LIB = os.path.join(LIBDIR, "libogsqp.so")
+
+
+def build_sqp(force=False):
+    """``lib/libogsqp.so``: the QP subproblem / BFGS kernels of the SQP driver (``include/ogsqp.h``)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    sources = [os.path.join(CSRC, "ogsqp.hip"), os.path.join(HERE, "..", "include", "ogsqp.h")]
+    stamp_path = SQP_LIB + ".stamp"
+    want = _digest_files(sources)
+    if not force and os.path.exists(SQP_LIB) and os.path.exists(stamp_path):
+        with open(stamp_path) as fh:
+            if fh.read().strip() == want:
+                return SQP_LIB
+    tmp = SQP_LIB + ".tmp%d" % os.getpid()
+    _run([hipcc()] + HIP_FLAGS + [sources[0], "-o", tmp])
+    os.replace(tmp, SQP_LIB)
+    with open(stamp_path, "w") as fh:
+        fh.write(want)
+    return SQP_LIB
+
+
 def module_digest(header_source):
     """Key of a callback module: generated header + kernel sources + flags."""
     return _digest_files(_kernel_sources(), extra=header_source)

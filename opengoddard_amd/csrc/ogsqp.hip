@@ -1,0 +1,1189 @@
+// ogsqp.hip - the QP subproblem and quasi-Newton update of the SQP driver on gfx950.
+//
+// Replaces the LSQ/LSEI/LSI/LDP/NNLS chain of SciPy's Fortran slsqp (include/ogsqp.h, DESIGN.md
+// section 9).  Everything O(n^2) stays in HBM:
+//
+//   1. T = [C Z ; Z]  (TN GEMM on the FP64 matrix cores, reading the transposed FD Jacobian as
+//      the sweep kernel left it), then one orthogonal LQ sweep from the right: C Z Q = [L 0],
+//      J = Z Q.  J is again a factor of B^-1, its trailing columns Y span the null space of C
+//      and are B-orthonormal, so the equality-constrained minimiser is two triangular solves
+//      and the inequality part becomes a least-distance problem  min |y|^2, W y + b >= 0  with
+//      W = [G;I] Y.
+//   2. Goldfarb-Idnani dual active set on the LDP, one launch per iteration: all workgroups
+//      evaluate the constraint values W y + b and elect the most violated row; the last
+//      workgroup to arrive performs the O(q nr) update (classical Gram-Schmidt with
+//      re-orthogonalisation against the active normals, explicit inverse triangular factor so
+//      that no triangular solve sits on the critical path).
+//   3. Product-form BFGS on the factor: Z <- Z - s (v'Z)/alpha.
+//
+// Reductions run in a fixed order: results are bit-reproducible from run to run.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/ogsqp.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define OG_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(100 + (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr double DEPENDENT = 1e-10;   // |projection| / |normal| below this: linearly dependent
+constexpr double FEASIBLE = 1e-12;    // rounding level of a normalised constraint value
+constexpr double UNFIXABLE = 1e-7;    // violation of a row the null space cannot move
+constexpr double SINGULAR_C = 1e-13;  // |L_kk| / max |L_jj| below this: C rank deficient
+constexpr int REFINE = 2;             // re-orthogonalisation passes per active-set iteration
+constexpr int GI_THREADS = 512;
+constexpr int GI_WAVES = GI_THREADS / 64;
+constexpr size_t LDS_LIMIT = 160 * 1024 - 2048;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Constraint normals as the sweep kernel stores them: variable-major, constraint j of variable i
+// at jt[i*ld + 1 + j]; the extra variable of the relaxed problem has its own contiguous row.
+struct AView {
+    const double* jt;
+    long ld;
+    const double* extra;
+    int n;
+};
+
+__device__ __forceinline__ double aval(const AView& A, int i, int j) {
+    return i < A.n ? A.jt[(long)i * A.ld + 1 + j] : A.extra[j];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Sum over the workgroup, identical in every thread; `red` holds blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double total = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += red[w];
+    return total;
+}
+
+// (value, index) minimum over the workgroup, ties to the lower index.
+__device__ __forceinline__ void block_argmin(double& v, int& idx, double* redv, int* redi) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        if (ov < v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        redv[threadIdx.x >> 6] = v;
+        redi[threadIdx.x >> 6] = idx;
+    }
+    __syncthreads();
+    v = redv[0];
+    idx = redi[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+        if (redv[w] < v || (redv[w] == v && redi[w] < idx)) {
+            v = redv[w];
+            idx = redi[w];
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[j][k] = sum_i A(i, col0 + j) * Jw[i][k]     (rows x nq, row-major, leading dimension ldw)
+// 64 x 64 output tile per workgroup, 4 wavefronts of 2 x 2 MFMA 16x16x4 tiles, K staged through
+// LDS 16 rows at a time.  Both operands are read along their contiguous direction.
+__global__ __launch_bounds__(256) void k_gemm_tn(AView A, int col0, int rows, const double* __restrict__ Jw,
+                                                 int ldw, int nq, double* __restrict__ out) {
+    __shared__ double As[16][80];
+    __shared__ double Bs[16][80];
+    const int j0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wj = (wave >> 1) * 32, wk = (wave & 1) * 32;
+    const int ii = tid >> 4, jb = (tid & 15) * 4;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int i0 = 0; i0 < nq; i0 += 16) {
+        const int i = i0 + ii;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + jb + e, k = k0 + jb + e;
+            As[ii][jb + e] = (i < nq && j < rows) ? aval(A, i, col0 + j) : 0.0;
+            Bs[ii][jb + e] = (i < nq && k < nq) ? Jw[(long)i * ldw + k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kr = kk * 4 + (lane >> 4);
+            const double a0 = As[kr][wj + (lane & 15)], a1 = As[kr][wj + 16 + (lane & 15)];
+            const double b0 = Bs[kr][wk + (lane & 15)], b1 = Bs[kr][wk + 16 + (lane & 15)];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = j0 + wj + tj * 16 + (lane >> 4) + 4 * reg;
+                const int k = k0 + wk + tk * 16 + (lane & 15);
+                if (j < rows && k < nq) out[(long)j * ldw + k] = acc[tj][tk][reg];
+            }
+}
+
+// Work copy of the factor; the relaxed problem appends the variable delta with 1/rho on the diagonal.
+__global__ void k_copy_factor(const double* __restrict__ Z, double* __restrict__ Jw, int ld, int n, int nq,
+                              double inv_rho) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (k >= nq) return;
+    double v;
+    if (i < n && k < n)
+        v = Z[(long)i * ld + k];
+    else
+        v = (i == k) ? inv_rho : 0.0;
+    Jw[(long)i * ld + k] = v;
+}
+
+__global__ void k_identity(double* Z, int ld, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (k < n) Z[(long)i * ld + k] = (i == k) ? 1.0 : 0.0;
+}
+
+// Coefficients of the relaxation variable: -c_j for equalities, max(-c_j, 0) for inequalities.
+__global__ void k_relaxation_row(const double* c, int meq, int m, double* extra) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) extra[j] = j < meq ? -c[j] : fmax(-c[j], 0.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Step k of the LQ sweep: Householder reflector from Tc[k][k:], applied from the right to the
+// remaining rows of Tc and to every row of Jw.  Row k itself is left as it is (nobody reads its
+// tail again); its new diagonal goes to diagL[k].
+constexpr int LQ_ROWS = 8;
+__global__ __launch_bounds__(256) void k_lq_step(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
+                                                 int meq, int nq, int k, double* __restrict__ diagL) {
+    extern __shared__ double lds[];
+    double* vs = lds;
+    double* red = lds + (nq - k);
+    const int L = nq - k, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const double* src = Tc + (long)k * ld + k;
+    double part = 0.0;
+    for (int j = tid; j < L; j += 256) {
+        const double v = src[j];
+        vs[j] = v;
+        part += v * v;
+    }
+    const double sigma2 = block_sum(part, red);
+    const double x0 = vs[0];
+    const double sigma = sqrt(sigma2);
+    if (sigma == 0.0) {
+        if (blockIdx.x == 0 && tid == 0) diagL[k] = 0.0;
+        return;
+    }
+    const double alpha = x0 >= 0.0 ? -sigma : sigma;
+    const double v0 = x0 - alpha;
+    const double beta = 2.0 / (sigma2 - x0 * x0 + v0 * v0);
+    __syncthreads();
+    if (tid == 0) vs[0] = v0;
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) diagL[k] = alpha;
+    const int below = meq - k - 1, nrows = below + nq;
+    const int r_end = min((int)(blockIdx.x + 1) * LQ_ROWS, nrows);
+    for (int r = blockIdx.x * LQ_ROWS + wave; r < r_end; r += 4) {
+        double* row = (r < below) ? Tc + (long)(k + 1 + r) * ld + k : Jw + (long)(r - below) * ld + k;
+        double dot = 0.0;
+        for (int j = lane; j < L; j += 64) dot += row[j] * vs[j];
+        const double f = beta * wave_sum(dot);
+        for (int j = lane; j < L; j += 64) row[j] -= f * vs[j];
+    }
+}
+
+// max |diag| / min |diag| test of the triangular factor -> flag[0] = 1 when singular
+__global__ void k_check_diag(const double* diagL, int meq, int* flag) {
+    __shared__ double red[16];
+    __shared__ double red2[16];
+    double mx = 0.0, mn = INFINITY;
+    for (int i = threadIdx.x; i < meq; i += blockDim.x) {
+        const double a = fabs(diagL[i]);
+        mx = fmax(mx, a);
+        mn = fmin(mn, a);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmax(mx, __shfl_xor(mx, off));
+        mn = fmin(mn, __shfl_xor(mn, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = mx;
+        red2[threadIdx.x >> 6] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            mx = fmax(mx, red[w]);
+            mn = fmin(mn, red2[w]);
+        }
+        flag[0] = (meq > 0 && !(mn > SINGULAR_C * fmax(mx, 1e-300))) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// L x = rhs (transposed = 0) or L' x = rhs (transposed = 1); L = strictly lower part of Tc with
+// diagL on the diagonal.  One workgroup; 64 x 64 diagonal blocks are solved by one wavefront out
+// of LDS, the panel below (above) is a GEMV spread over all threads.
+__global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, int ld, const double* __restrict__ diagL,
+                                               int meq, int transposed, double scale_rhs, const double* __restrict__ rhs,
+                                               double* __restrict__ x) {
+    extern __shared__ double lds[];
+    double* xs = lds;                 // meq
+    double* blk = lds + meq;          // 64 x 65
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < meq; i += 1024) xs[i] = scale_rhs * rhs[i];
+    __syncthreads();
+    const int nblk = (meq + 63) / 64;
+    for (int bi = 0; bi < nblk; ++bi) {
+        const int b = transposed ? nblk - 1 - bi : bi;
+        const int i0 = b * 64, bs = min(64, meq - i0);
+        for (int e = tid; e < 64 * 64; e += 1024) {
+            const int r = e >> 6, c = e & 63;
+            blk[r * 65 + c] = (r < bs && c < r) ? Tc[(long)(i0 + r) * ld + i0 + c] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double xv = lane < bs ? xs[i0 + lane] : 0.0;
+            if (!transposed) {
+                for (int c = 0; c < bs; ++c) {
+                    const double xc = __shfl(xv, c) / diagL[i0 + c];
+                    if (lane == c)
+                        xv = xc;
+                    else if (lane > c)
+                        xv -= blk[lane * 65 + c] * xc;
+                }
+            } else {
+                for (int c = bs - 1; c >= 0; --c) {
+                    const double xc = __shfl(xv, c) / diagL[i0 + c];
+                    if (lane == c)
+                        xv = xc;
+                    else if (lane < c)
+                        xv -= blk[c * 65 + lane] * xc;
+                }
+            }
+            if (lane < bs) xs[i0 + lane] = xv;
+        }
+        __syncthreads();
+        if (!transposed) {
+            for (int r = i0 + bs + tid; r < meq; r += 1024) {
+                const double* row = Tc + (long)r * ld + i0;
+                double acc = 0.0;
+                for (int c = 0; c < bs; ++c) acc += row[c] * xs[i0 + c];
+                xs[r] -= acc;
+            }
+        } else {
+            for (int r = tid; r < i0; r += 1024) {
+                double acc = 0.0;
+                for (int c = 0; c < bs; ++c) acc += Tc[(long)(i0 + c) * ld + r] * xs[i0 + c];
+                xs[r] -= acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < meq; i += 1024) x[i] = xs[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// out[k] = base[k] + sum_i M[i*ld + k] * x[i]   (k < ncols, i < nrows): 64 columns per workgroup,
+// 16 wavefronts split the rows, fixed-order combination through LDS.
+__global__ __launch_bounds__(1024) void k_gemv_cols(const double* __restrict__ M, long ld, int nrows, int ncols,
+                                                    const double* __restrict__ x, const double* __restrict__ base,
+                                                    double* __restrict__ out) {
+    __shared__ double part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (k < ncols)
+        for (int i = wave; i < nrows; i += 16) acc += M[(long)i * ld + k] * x[i];
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && k < ncols) {
+        double total = base ? base[k] : 0.0;
+        for (int w = 0; w < 16; ++w) total += part[w][lane];
+        out[k] = total;
+    }
+}
+
+// out[j] = base[j] + sum_i A(i, col0 + j) * x[i]
+__global__ __launch_bounds__(1024) void k_gemv_cols_A(AView A, int col0, int nq, int ncols, const double* __restrict__ x,
+                                                      const double* __restrict__ base, double* __restrict__ out) {
+    __shared__ double part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (j < ncols)
+        for (int i = wave; i < nq; i += 16) acc += aval(A, i, col0 + j) * x[i];
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && j < ncols) {
+        double total = base ? base[j] : 0.0;
+        for (int w = 0; w < 16; ++w) total += part[w][lane];
+        out[j] = total;
+    }
+}
+
+// out[i] = add[i] + alpha * sum_k M[i*ld + k] * x[k]   (one wavefront per row)
+__global__ __launch_bounds__(256) void k_gemv_rows(const double* __restrict__ M, long ld, int nrows, int ncols,
+                                                   const double* __restrict__ x, double alpha,
+                                                   const double* __restrict__ add, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nrows) return;
+    const double* row = M + (long)i * ld;
+    double acc = 0.0;
+    for (int k = lane; k < ncols; k += 64) acc += row[k] * x[k];
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = (add ? add[i] : 0.0) + alpha * acc;
+}
+
+// out[i] = sum_k A-row(i)[k] * coef[k] over the 1+m stored columns (Lagrangian gradient)
+__global__ __launch_bounds__(256) void k_jt_times(const double* __restrict__ jt, long ld, int n, int width,
+                                                  const double* __restrict__ coef, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const double* row = jt + (long)i * ld;
+    double acc = 0.0;
+    for (int k = lane; k < width; k += 64) acc += row[k] * coef[k];
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = acc;
+}
+
+__global__ void k_concat_neg(const double* a, int na, const double* b, int nb, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na)
+        out[i] = a[i];
+    else if (i < na + nb)
+        out[i] = -b[i - na];
+}
+
+// ------------------------------------------------------------------------------------------
+// Least-distance problem.  Constraint stack: r < mg general rows (GJ), then nq lower bounds, then
+// nq upper bounds (rows of Jw, negated for the upper ones).
+struct GiState {
+    int phase;  // 0 select, 1 continue with p, 2 solved, 3 iteration limit, 4 incompatible
+    int p;
+    int q;
+    int iters;
+    int cur;  // which of the two R / RI buffers is live
+    unsigned ticket;
+    double up;
+    double ynorm;
+};
+
+struct GiPartial {
+    double value;
+    int index;
+    int pad;
+};
+
+struct GiArgs {
+    const double* GJ;
+    const double* Jw;
+    int ld, meq, nq, mg, nr, qcap;
+    const double* bval;   // mg + 2 nq
+    const double* scale;  // mg + 2 nq, 0 = not usable
+    const double* own;    // mg + 2 nq
+    double* u;            // mg + 2 nq
+    int* isact;           // mg + 2 nq
+    double* y;            // nr
+    int* act;             // qcap
+    double* R[2];
+    double* RI[2];
+    GiPartial* partials;
+    GiState* st;
+    int limit;
+};
+
+__device__ __forceinline__ const double* stack_row(const GiArgs& g, int r, double& sign) {
+    if (r < g.mg) {
+        sign = 1.0;
+        return g.GJ + (long)r * g.ld + g.meq;
+    }
+    r -= g.mg;
+    if (r < g.nq) {
+        sign = 1.0;
+        return g.Jw + (long)r * g.ld + g.meq;
+    }
+    sign = -1.0;
+    return g.Jw + (long)(r - g.nq) * g.ld + g.meq;
+}
+
+// Row norms over all nq columns and over the null-space columns; b, scale, own of every stack row.
+// flag[1] is raised when a row that the null space cannot move is violated beyond FD noise.
+__global__ __launch_bounds__(256) void k_ldp_setup(const double* __restrict__ GJ, const double* __restrict__ Jw, int ld,
+                                                   int meq, int nq, int mg, const double* __restrict__ bG,
+                                                   const double* __restrict__ cin, const double* __restrict__ deq,
+                                                   const double* __restrict__ dl, const double* __restrict__ du,
+                                                   double* __restrict__ bval, double* __restrict__ scale,
+                                                   double* __restrict__ own, int* flag) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= mg + nq) return;
+    const double* row = r < mg ? GJ + (long)r * ld : Jw + (long)(r - mg) * ld;
+    double full = 0.0, red = 0.0;
+    for (int k = lane; k < nq; k += 64) {
+        const double v = row[k];
+        full += v * v;
+        if (k >= meq) red += v * v;
+    }
+    full = sqrt(wave_sum(full));
+    red = sqrt(wave_sum(red));
+    if (lane != 0) return;
+    const bool movable = red > DEPENDENT * full;
+    if (r < mg) {
+        const double b = bG[r];
+        bval[r] = b;
+        scale[r] = movable ? red : 0.0;
+        own[r] = movable ? FEASIBLE * fabs(b) / red : 0.0;
+        if (!movable && b < -UNFIXABLE * fmax(1.0, fabs(cin[r]))) atomicOr(flag + 1, 1);
+    } else {
+        const int i = r - mg;
+        const double lo = dl[i], hi = du[i];
+        const bool has_lo = isfinite(lo), has_hi = isfinite(hi);
+        const double blo = deq[i] - lo, bhi = hi - deq[i];
+        bval[mg + i] = has_lo ? blo : 0.0;
+        bval[mg + nq + i] = has_hi ? bhi : 0.0;
+        scale[mg + i] = (has_lo && movable) ? red : 0.0;
+        scale[mg + nq + i] = (has_hi && movable) ? red : 0.0;
+        own[mg + i] = (has_lo && movable) ? FEASIBLE * fabs(blo) / red : 0.0;
+        own[mg + nq + i] = (has_hi && movable) ? FEASIBLE * fabs(bhi) / red : 0.0;
+        if (!movable && has_lo && blo < -UNFIXABLE * fmax(1.0, fabs(lo))) atomicOr(flag + 1, 1);
+        if (!movable && has_hi && bhi < -UNFIXABLE * fmax(1.0, fabs(hi))) atomicOr(flag + 1, 1);
+    }
+}
+
+__global__ void k_gi_init(GiArgs g, const int* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int mt = g.mg + 2 * g.nq;
+    if (i < mt) {
+        g.u[i] = 0.0;
+        g.isact[i] = 0;
+    }
+    if (i < g.nr) g.y[i] = 0.0;
+    if (i == 0) {
+        GiState s;
+        s.phase = flag[1] ? 4 : 0;
+        s.p = -1;
+        s.q = 0;
+        s.iters = 0;
+        s.cur = 0;
+        s.ticket = 0u;
+        s.up = 0.0;
+        s.ynorm = 0.0;
+        *g.st = s;
+    }
+}
+
+// One active-set iteration.
+__global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
+    extern __shared__ double lds[];
+    __shared__ double redv[GI_WAVES];
+    __shared__ int redi[GI_WAVES];
+    __shared__ int s_last;
+    GiState* st = g.st;
+    const int phase0 = st->phase;
+    if (phase0 >= 2) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nr = g.nr, mg = g.mg, nq = g.nq;
+
+    // ---- all workgroups: constraint values and the most violated usable row -----------------
+    {
+        const double slack = FEASIBLE * st->ynorm;
+        double best = INFINITY;
+        int besti = 0x7fffffff;
+        const int r = blockIdx.x * GI_WAVES + wave;
+        if (r < mg + nq) {
+            const double* row = (r < mg ? g.GJ + (long)r * g.ld : g.Jw + (long)(r - mg) * g.ld) + g.meq;
+            double dot = 0.0;
+            for (int k = lane; k < nr; k += 64) dot += row[k] * g.y[k];
+            dot = wave_sum(dot);
+            if (r < mg) {
+                if (g.scale[r] > 0.0 && !g.isact[r]) {
+                    best = (g.bval[r] + dot) / g.scale[r] + g.own[r] + slack;
+                    besti = r;
+                }
+            } else {
+                const int lo = r, hi = r + nq;
+                if (g.scale[lo] > 0.0 && !g.isact[lo]) {
+                    best = (g.bval[lo] + dot) / g.scale[lo] + g.own[lo] + slack;
+                    besti = lo;
+                }
+                if (g.scale[hi] > 0.0 && !g.isact[hi]) {
+                    const double v = (g.bval[hi] - dot) / g.scale[hi] + g.own[hi] + slack;
+                    if (v < best) {
+                        best = v;
+                        besti = hi;
+                    }
+                }
+            }
+        }
+        block_argmin(best, besti, redv, redi);
+        if (tid == 0) {
+            g.partials[blockIdx.x].value = best;
+            g.partials[blockIdx.x].index = besti;
+            __threadfence();
+            const unsigned t = atomicAdd(&st->ticket, 1u);
+            s_last = (t == gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+    }
+
+    // ---- last workgroup: the update ------------------------------------------------------------
+    const int qcap = g.qcap;
+    double* nv = lds;                 // normal of p in the null-space coordinates
+    double* zv = nv + nr;             // its component orthogonal to the active normals
+    double* av = zv + nr;             // N' vec
+    double* tv = av + qcap;           // RI' av
+    double* rinc = tv + qcap;         // RI tv
+    double* rho = rinc + qcap;        // accumulated  R^-T N' n   (new column of R)
+    double* rv = rho + qcap;          // accumulated  (N'N)^-1 N' n
+    double* sg = rv + qcap;           // sign of every active row
+    const double** rowp = (const double**)(sg + qcap);
+    double* red = (double*)(rowp + qcap);
+
+    if (tid == 0) st->ticket = 0u;
+    int p;
+    if (phase0 == 0) {
+        double v = INFINITY;
+        int idx = 0x7fffffff;
+        for (int b = tid; b < (int)gridDim.x; b += GI_THREADS) {
+            const double pv = ((volatile GiPartial*)g.partials)[b].value;
+            const int pi = ((volatile GiPartial*)g.partials)[b].index;
+            if (pv < v || (pv == v && pi < idx)) {
+                v = pv;
+                idx = pi;
+            }
+        }
+        block_argmin(v, idx, redv, redi);
+        if (!(v < 0.0)) {
+            if (tid == 0) st->phase = 2;
+            return;
+        }
+        p = idx;
+        if (tid == 0) {
+            st->p = p;
+            st->up = 0.0;
+        }
+    } else {
+        p = st->p;
+    }
+    const int iters = st->iters + 1;
+    if (iters > g.limit) {
+        if (tid == 0) st->phase = 3;
+        return;
+    }
+    const int q = st->q, cur = st->cur;
+    const double up_old = (phase0 == 0) ? 0.0 : st->up;
+    double* R = g.R[cur];
+    double* RI = g.RI[cur];
+
+    double psign;
+    const double* prow = stack_row(g, p, psign);
+    double part_y = 0.0, part_nn = 0.0;
+    for (int i = tid; i < nr; i += GI_THREADS) {
+        const double v = psign * prow[i];
+        nv[i] = v;
+        part_y += v * g.y[i];
+        part_nn += v * v;
+    }
+    for (int j = tid; j < q; j += GI_THREADS) {
+        double s;
+        rowp[j] = stack_row(g, g.act[j], s);
+        sg[j] = s;
+        rho[j] = 0.0;
+        rv[j] = 0.0;
+    }
+    const double sp = g.bval[p] + block_sum(part_y, red);
+    const double nn = block_sum(part_nn, red);
+
+    // classical Gram-Schmidt against the active normals, repeated REFINE times
+    for (int pass = 0; pass <= REFINE; ++pass) {
+        const double* vec = pass == 0 ? nv : zv;
+        for (int j = wave; j < q; j += GI_WAVES) {
+            const double* row = rowp[j];
+            double dot = 0.0;
+            for (int i = lane; i < nr; i += 64) dot += row[i] * vec[i];
+            dot = wave_sum(dot);
+            if (lane == 0) av[j] = sg[j] * dot;
+        }
+        __syncthreads();
+        for (int i = wave; i < q; i += GI_WAVES) {
+            const double* col = RI + (long)i * qcap;
+            double dot = 0.0;
+            for (int j = lane; j <= i; j += 64) dot += col[j] * av[j];
+            dot = wave_sum(dot);
+            if (lane == 0) tv[i] = dot;
+        }
+        __syncthreads();
+        for (int i = tid; i < q; i += GI_THREADS) {
+            double acc = 0.0;
+            for (int j = i; j < q; ++j) acc += RI[(long)j * qcap + i] * tv[j];
+            rinc[i] = acc;
+            rho[i] += tv[i];
+            rv[i] += acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < nr; i += GI_THREADS) {
+            double acc = vec[i];
+            for (int j = 0; j < q; ++j) acc -= rinc[j] * sg[j] * rowp[j][i];
+            zv[i] = acc;
+        }
+        __syncthreads();
+    }
+    double part_zz = 0.0;
+    for (int i = tid; i < nr; i += GI_THREADS) part_zz += zv[i] * zv[i];
+    const double zz = block_sum(part_zz, red);
+    const bool dependent = !(zz > (DEPENDENT * DEPENDENT) * nn);
+
+    // ratio test over the active rows
+    double t1 = INFINITY;
+    int kdrop = 0x7fffffff;
+    for (int j = tid; j < q; j += GI_THREADS)
+        if (rv[j] > 0.0) {
+            const double cand = g.u[g.act[j]] / rv[j];
+            if (cand < t1) {
+                t1 = cand;
+                kdrop = j;
+            }
+        }
+    block_argmin(t1, kdrop, redv, redi);
+    const double t2 = dependent ? INFINITY : -sp / zz;
+    const double t = fmin(t1, t2);
+    if (!(t < INFINITY)) {
+        if (tid == 0) {
+            st->phase = 4;
+            st->iters = iters;
+        }
+        return;
+    }
+    for (int j = tid; j < q; j += GI_THREADS) g.u[g.act[j]] -= t * rv[j];
+    const double up = up_old + t;
+    double part_yy = 0.0;
+    for (int i = tid; i < nr; i += GI_THREADS) {
+        double yi = g.y[i];
+        if (!dependent) {
+            yi += t * zv[i];
+            g.y[i] = yi;
+        }
+        part_yy += yi * yi;
+    }
+    const double ynorm = sqrt(block_sum(part_yy, red));
+    const bool full_step = (t2 < INFINITY) && (t2 <= t1);
+    if (full_step) {
+        // p joins the active set: R gets the column [rho; |z|], RI the column [-r/|z|; 1/|z|]
+        const double delta = sqrt(zz);
+        for (int i = tid; i < q; i += GI_THREADS) {
+            R[(long)q * qcap + i] = rho[i];
+            RI[(long)q * qcap + i] = -rv[i] / delta;
+        }
+        if (tid == 0) {
+            R[(long)q * qcap + q] = delta;
+            RI[(long)q * qcap + q] = 1.0 / delta;
+            g.act[q] = p;
+            g.u[p] = up;
+            g.isact[p] = 1;
+            st->q = q + 1;
+            st->phase = 0;
+            st->iters = iters;
+            st->ynorm = ynorm;
+        }
+        return;
+    }
+
+    // ---- partial step: active row k leaves ------------------------------------------------------
+    const int k = kdrop;
+    double* Rn = g.R[cur ^ 1];
+    double* RIn = g.RI[cur ^ 1];
+    double* carried = av;   // row being rotated downwards, indexed by old column
+    double* cs = tv;        // cosine / sine of every rotation (2 per step), tv and rinc are adjacent
+    // unchanged parts: columns before k; rows above k of the columns after k (shifted left)
+    for (int c = wave; c < q; c += GI_WAVES) {
+        if (c == k) continue;
+        const int cn = c < k ? c : c - 1;
+        const int top = c < k ? c + 1 : k;
+        for (int i = lane; i < top; i += 64) Rn[(long)cn * qcap + i] = R[(long)c * qcap + i];
+        if (c < k)
+            for (int i = lane; i <= c; i += 64) RIn[(long)c * qcap + i] = RI[(long)c * qcap + i];
+    }
+    for (int c = k + 1 + tid; c < q; c += GI_THREADS) carried[c] = R[(long)c * qcap + k];
+    __syncthreads();
+    if (wave == 0) {
+        // Givens chain restoring the triangle of R without column k; one wavefront, lanes own the
+        // columns congruent to them modulo 64
+        for (int j = k; j < q - 1; ++j) {
+            const int cp = j + 1;  // old column holding the pivot pair
+            const double a = ((volatile double*)carried)[cp];
+            const double b = R[(long)cp * qcap + j + 1];
+            const double hyp = sqrt(a * a + b * b);
+            const double co = hyp > 0.0 ? a / hyp : 1.0;
+            const double si = hyp > 0.0 ? b / hyp : 0.0;
+            if (lane == 0) {
+                cs[2 * j] = co;
+                cs[2 * j + 1] = si;
+                Rn[(long)j * qcap + j] = hyp;
+            }
+            int c = cp + 1 + ((lane - (cp + 1)) % 64 + 64) % 64;
+            for (; c < q; c += 64) {
+                const double x = carried[c], yv = R[(long)c * qcap + j + 1];
+                Rn[(long)(c - 1) * qcap + j] = co * x + si * yv;
+                carried[c] = -si * x + co * yv;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+    }
+    __syncthreads();
+    // the same rotations on the columns of RI; row k and the last column drop out
+    for (int i = tid; i < q; i += GI_THREADS) {
+        if (i == k) continue;
+        const int in = i < k ? i : i - 1;
+        double x = i < k ? RI[(long)k * qcap + i] : 0.0;
+        for (int j = (i - 1 > k ? i - 1 : k); j < q - 1; ++j) {
+            const double yv = RI[(long)(j + 1) * qcap + i];
+            const double co = cs[2 * j], si = cs[2 * j + 1];
+            RIn[(long)j * qcap + in] = co * x + si * yv;
+            x = -si * x + co * yv;
+        }
+    }
+    __syncthreads();
+    int* shifted = (int*)av;
+    const int leaving = g.act[k];
+    for (int j = k + tid; j < q - 1; j += GI_THREADS) shifted[j] = g.act[j + 1];
+    __syncthreads();
+    for (int j = k + tid; j < q - 1; j += GI_THREADS) g.act[j] = shifted[j];
+    if (tid == 0) {
+        g.u[leaving] = 0.0;
+        g.isact[leaving] = 0;
+    }
+    if (tid == 0) {
+        st->q = q - 1;
+        st->cur = cur ^ 1;
+        st->phase = 1;
+        st->up = up;
+        st->iters = iters;
+        st->ynorm = ynorm;
+    }
+}
+
+// d = clip(deq + Y y), multipliers of the general inequalities and of the bounds
+__global__ __launch_bounds__(256) void k_finish_step(const double* __restrict__ Jw, int ld, int meq, int nq, int nr,
+                                                     int mg, const double* __restrict__ y, const double* __restrict__ deq,
+                                                     const double* __restrict__ dl, const double* __restrict__ du,
+                                                     const double* __restrict__ u, double* __restrict__ d,
+                                                     double* __restrict__ bm) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nq) return;
+    const double* row = Jw + (long)i * ld + meq;
+    double acc = 0.0;
+    for (int k = lane; k < nr; k += 64) acc += row[k] * y[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        double v = deq[i] + acc;
+        if (isfinite(dl[i])) v = fmax(v, dl[i]);
+        if (isfinite(du[i])) v = fmin(v, du[i]);
+        d[i] = v;
+        bm[i] = u[mg + i] - u[mg + nq + i];
+    }
+}
+
+// tvec[i] = g[i] - sum_j A(i, meq + j) mu[j] - bm[i]
+__global__ __launch_bounds__(256) void k_dual_residual(AView A, int meq, int mg, int nq, const double* __restrict__ gvec,
+                                                       const double* __restrict__ mu, const double* __restrict__ bm,
+                                                       double* __restrict__ tvec) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nq) return;
+    double acc = 0.0;
+    for (int j = lane; j < mg; j += 64) acc += aval(A, i, meq + j) * mu[j];
+    acc = wave_sum(acc);
+    if (lane == 0) tvec[i] = gvec[i] - acc - bm[i];
+}
+
+// Z[i][k] -= s[i] * vz[k] * inv_alpha
+__global__ void k_rank1(double* Z, int ld, int n, const double* s, const double* vz, double inv_alpha) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (k < n) Z[(long)i * ld + k] -= s[i] * (vz[k] * inv_alpha);
+}
+
+}  // namespace
+
+struct og_qp_s {
+    int device = 0;
+    int n = 0, n1 = 0, meq = 0, mg = 0, m = 0, qcap = 0;
+    hipStream_t stream = nullptr;
+    double *Z = nullptr, *Jw = nullptr, *Tc = nullptr, *GJ = nullptr, *diagL = nullptr;
+    double *extra = nullptr, *g = nullptr, *c = nullptr, *dl = nullptr, *du = nullptr;
+    double *w1 = nullptr, *t1 = nullptr, *xcat = nullptr, *deq = nullptr, *bG = nullptr;
+    double *bval = nullptr, *scale = nullptr, *own = nullptr, *u = nullptr, *y = nullptr;
+    double *R[2] = {nullptr, nullptr}, *RI[2] = {nullptr, nullptr};
+    double *d = nullptr, *bm = nullptr, *tvec = nullptr, *rhs = nullptr, *lam = nullptr, *vz = nullptr;
+    double *svec = nullptr, *vvec = nullptr, *coef = nullptr, *outn = nullptr;
+    int *isact = nullptr, *act = nullptr, *flag = nullptr;
+    GiPartial* partials = nullptr;
+    GiState* st = nullptr;
+    double* jt_stage = nullptr;
+    std::vector<double> host_stage;
+    std::vector<void*> owned;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(og_qp_s* qp, T** ptr, size_t count) {
+    void* raw = nullptr;
+    OG_HIP(hipMalloc(&raw, (count ? count : 1) * sizeof(T)));
+    qp->owned.push_back(raw);
+    *ptr = (T*)raw;
+    return 0;
+}
+
+#define OG_TRY(expr)          \
+    do {                      \
+        int rc_ = (expr);     \
+        if (rc_) return rc_;  \
+    } while (0)
+
+size_t gi_lds_bytes(int nr, int qcap) {
+    return (size_t)(2 * nr + 6 * qcap) * sizeof(double) + (size_t)qcap * sizeof(void*) + 64 * sizeof(double);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* og_qp_last_error(void) { return g_error.c_str(); }
+
+int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, int32_t m_ineq, og_qp_handle* out) {
+    if (abi_version != OGSQP_ABI_VERSION) return fail(1, "og_qp_create: ABI version mismatch");
+    if (!out || n < 1 || m_eq < 0 || m_ineq < 0) return fail(2, "og_qp_create: bad arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(3, "og_qp_create: no HIP device visible (the SQP core has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(3, "og_qp_create: no such device");
+    OG_HIP(hipSetDevice(device));
+    og_qp_s* qp = new og_qp_s();
+    qp->device = device;
+    qp->n = n;
+    qp->n1 = n + 1;
+    qp->meq = m_eq;
+    qp->mg = m_ineq;
+    qp->m = m_eq + m_ineq;
+    qp->qcap = qp->n1 - (m_eq < qp->n1 ? m_eq : qp->n1);
+    if (qp->qcap < 1) qp->qcap = 1;
+    const size_t n1 = qp->n1, mt = (size_t)qp->mg + 2 * n1, qc = qp->qcap;
+    if (gi_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) {
+        delete qp;
+        return fail(4, "og_qp_create: null space of the equalities too large for the LDS-resident update "
+                       "(n + 1 - m_eq = " + std::to_string(qc) + ")");
+    }
+    int rc = 0;
+    auto A = [&](auto** p, size_t cnt) { if (!rc) rc = dev_alloc(qp, p, cnt); };
+    A(&qp->Z, n1 * n1); A(&qp->Jw, n1 * n1); A(&qp->Tc, (size_t)qp->meq * n1); A(&qp->GJ, (size_t)qp->mg * n1);
+    A(&qp->diagL, qp->meq); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
+    A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
+    A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
+    A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
+    A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
+    A(&qp->isact, mt); A(&qp->act, qc); A(&qp->flag, 2);
+    A(&qp->partials, ((size_t)qp->mg + n1) / GI_WAVES + 2); A(&qp->st, 1);
+    if (!rc && hipStreamCreate(&qp->stream) != hipSuccess) rc = fail(5, "og_qp_create: hipStreamCreate failed");
+    if (!rc && hipFuncSetAttribute((const void*)k_gi_iter, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)LDS_LIMIT) != hipSuccess)
+        rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
+    if (!rc && hipFuncSetAttribute((const void*)k_trsv, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)LDS_LIMIT) != hipSuccess)
+        rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
+    if (!rc && hipFuncSetAttribute((const void*)k_lq_step, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)LDS_LIMIT) != hipSuccess)
+        rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
+    if (rc) {
+        og_qp_destroy(qp);
+        return rc;
+    }
+    *out = qp;
+    return og_qp_reset(qp);
+}
+
+void og_qp_destroy(og_qp_handle qp) {
+    if (!qp) return;
+    (void)hipSetDevice(qp->device);
+    for (void* p : qp->owned) (void)hipFree(p);
+    if (qp->jt_stage) (void)hipFree(qp->jt_stage);
+    if (qp->stream) (void)hipStreamDestroy(qp->stream);
+    delete qp;
+}
+
+int og_qp_reset(og_qp_handle qp) {
+    if (!qp) return fail(2, "og_qp_reset: null handle");
+    OG_HIP(hipSetDevice(qp->device));
+    dim3 grid((qp->n1 + 255) / 256, qp->n1);
+    hipLaunchKernelGGL(k_identity, grid, dim3(256), 0, qp->stream, qp->Z, qp->n1, qp->n1);
+    OG_HIP(hipGetLastError());
+    OG_HIP(hipStreamSynchronize(qp->stream));
+    return 0;
+}
+
+int og_qp_get_factor(og_qp_handle qp, double* Z) {
+    if (!qp || !Z) return fail(2, "og_qp_get_factor: null argument");
+    OG_HIP(hipSetDevice(qp->device));
+    OG_HIP(hipMemcpy2D(Z, (size_t)qp->n * sizeof(double), qp->Z, (size_t)qp->n1 * sizeof(double),
+                       (size_t)qp->n * sizeof(double), qp->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int og_qp_set_factor(og_qp_handle qp, const double* Z) {
+    if (!qp || !Z) return fail(2, "og_qp_set_factor: null argument");
+    OG_HIP(hipSetDevice(qp->device));
+    OG_HIP(hipMemcpy2D(qp->Z, (size_t)qp->n1 * sizeof(double), Z, (size_t)qp->n * sizeof(double),
+                       (size_t)qp->n * sizeof(double), qp->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const double* g, const double* c,
+                    const double* dl, const double* du, int32_t augmented, double rho, double* d, double* mult,
+                    double* bound_mult, int32_t* status, int32_t* iterations, void* hip_stream) {
+    if (!qp || !d_jt || !g || !dl || !du || !d || !mult || !bound_mult || !status)
+        return fail(2, "og_qp_solve_dev: null argument");
+    if (qp->m > 0 && !c) return fail(2, "og_qp_solve_dev: null constraint values");
+    if (ld < 1 + qp->m) return fail(2, "og_qp_solve_dev: leading dimension smaller than 1 + m");
+    if (augmented && !(rho > 0.0)) return fail(2, "og_qp_solve_dev: rho must be positive");
+    OG_HIP(hipSetDevice(qp->device));
+    hipStream_t s = qp->stream;
+    if (hip_stream) OG_HIP(hipStreamSynchronize((hipStream_t)hip_stream));   // producer of d_jt
+    const int n = qp->n, n1 = qp->n1, meq = qp->meq, mg = qp->mg, m = qp->m;
+    const int nq = augmented ? n + 1 : n;
+    const int nr = nq - meq;
+    if (iterations) *iterations = 0;
+    if (meq > nq) {
+        *status = OG_QP_TOO_MANY_EQ;
+        return 0;
+    }
+    // ---- inputs
+    std::vector<double>& hs = qp->host_stage;
+    hs.assign((size_t)3 * n1 + m, 0.0);
+    double* hg = hs.data();
+    double* hdl = hg + n1;
+    double* hdu = hdl + n1;
+    double* hc = hdu + n1;
+    memcpy(hg, g, sizeof(double) * n);
+    memcpy(hdl, dl, sizeof(double) * nq);
+    memcpy(hdu, du, sizeof(double) * nq);
+    if (m) memcpy(hc, c, sizeof(double) * m);
+    OG_HIP(hipMemcpyAsync(qp->g, hg, sizeof(double) * n1, hipMemcpyHostToDevice, s));
+    OG_HIP(hipMemcpyAsync(qp->dl, hdl, sizeof(double) * n1, hipMemcpyHostToDevice, s));
+    OG_HIP(hipMemcpyAsync(qp->du, hdu, sizeof(double) * n1, hipMemcpyHostToDevice, s));
+    if (m) OG_HIP(hipMemcpyAsync(qp->c, hc, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    OG_HIP(hipMemsetAsync(qp->flag, 0, 2 * sizeof(int), s));
+    if (augmented && m)
+        hipLaunchKernelGGL(k_relaxation_row, dim3((m + 255) / 256), dim3(256), 0, s, qp->c, meq, m, qp->extra);
+    AView A{d_jt, (long)ld, qp->extra, n};
+    // ---- work factor, C Z, LQ sweep
+    hipLaunchKernelGGL(k_copy_factor, dim3((nq + 255) / 256, nq), dim3(256), 0, s, qp->Z, qp->Jw, n1, n, nq,
+                       augmented ? 1.0 / rho : 0.0);
+    if (meq) {
+        hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, n1,
+                           nq, qp->Tc);
+        for (int k = 0; k < meq; ++k) {
+            const int nrows = (meq - k - 1) + nq;
+            const size_t lds = (size_t)(nq - k + 16) * sizeof(double);
+            hipLaunchKernelGGL(k_lq_step, dim3((nrows + LQ_ROWS - 1) / LQ_ROWS), dim3(256), lds, s, qp->Tc, qp->Jw, n1,
+                               meq, nq, k, qp->diagL);
+        }
+        hipLaunchKernelGGL(k_check_diag, dim3(1), dim3(1024), 0, s, qp->diagL, meq, qp->flag);
+    }
+    OG_HIP(hipGetLastError());
+    int hflag[2] = {0, 0};
+    OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    OG_HIP(hipStreamSynchronize(s));
+    if (hflag[0]) {
+        *status = OG_QP_SINGULAR_C;
+        return 0;
+    }
+    // ---- equality-constrained minimiser: L w1 = -c,  deq = J1 w1 - Y (Y'g)
+    const size_t trsv_lds = (size_t)(meq + 64 * 65) * sizeof(double);
+    if (meq)
+        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, n1, qp->diagL, meq, 0, -1.0, qp->c,
+                           qp->w1);
+    if (nr > 0)
+        hipLaunchKernelGGL(k_gemv_cols, dim3((nr + 63) / 64), dim3(1024), 0, s, qp->Jw + meq, (long)n1, nq, nr, qp->g,
+                           (const double*)nullptr, qp->t1);
+    hipLaunchKernelGGL(k_concat_neg, dim3((nq + 255) / 256), dim3(256), 0, s, qp->w1, meq, qp->t1, nr, qp->xcat);
+    hipLaunchKernelGGL(k_gemv_rows, dim3((nq + 3) / 4), dim3(256), 0, s, qp->Jw, (long)n1, nq, nq, qp->xcat, 1.0,
+                       (const double*)nullptr, qp->deq);
+    // ---- least-distance problem in the null space
+    if (mg) {
+        hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (mg + 63) / 64), dim3(256), 0, s, A, meq, mg, qp->Jw, n1,
+                           nq, qp->GJ);
+        hipLaunchKernelGGL(k_gemv_cols_A, dim3((mg + 63) / 64), dim3(1024), 0, s, A, meq, nq, mg, qp->deq,
+                           qp->c + meq, qp->bG);
+    }
+    hipLaunchKernelGGL(k_ldp_setup, dim3((mg + nq + 3) / 4), dim3(256), 0, s, qp->GJ, qp->Jw, n1, meq, nq, mg, qp->bG,
+                       qp->c + meq, qp->deq, qp->dl, qp->du, qp->bval, qp->scale, qp->own, qp->flag);
+    GiArgs ga;
+    ga.GJ = qp->GJ; ga.Jw = qp->Jw; ga.ld = n1; ga.meq = meq; ga.nq = nq; ga.mg = mg; ga.nr = nr;
+    ga.qcap = qp->qcap; ga.bval = qp->bval; ga.scale = qp->scale; ga.own = qp->own; ga.u = qp->u;
+    ga.isact = qp->isact; ga.y = qp->y; ga.act = qp->act; ga.R[0] = qp->R[0]; ga.R[1] = qp->R[1];
+    ga.RI[0] = qp->RI[0]; ga.RI[1] = qp->RI[1]; ga.partials = qp->partials; ga.st = qp->st;
+    const int mt = mg + 2 * nq;
+    ga.limit = 10 * (mt + nr) + 100;
+    hipLaunchKernelGGL(k_gi_init, dim3((mt + n1 + 255) / 256), dim3(256), 0, s, ga, qp->flag);
+    OG_HIP(hipGetLastError());
+    GiState hst;
+    memset(&hst, 0, sizeof(hst));
+    if (nr > 0) {
+        const int blocks = (mg + nq + GI_WAVES - 1) / GI_WAVES;
+        const size_t lds = gi_lds_bytes(nr, qp->qcap);
+        int batch = 8;
+        while (true) {
+            for (int it = 0; it < batch; ++it)
+                hipLaunchKernelGGL(k_gi_iter, dim3(blocks), dim3(GI_THREADS), lds, s, ga);
+            OG_HIP(hipGetLastError());
+            OG_HIP(hipMemcpyAsync(&hst, qp->st, sizeof(GiState), hipMemcpyDeviceToHost, s));
+            OG_HIP(hipStreamSynchronize(s));
+            if (hst.phase >= 2) break;
+            if (batch < 64) batch *= 2;
+        }
+    } else {
+        OG_HIP(hipMemcpyAsync(&hst, qp->st, sizeof(GiState), hipMemcpyDeviceToHost, s));
+        OG_HIP(hipStreamSynchronize(s));
+        if (hst.phase < 2) hst.phase = 2;   // nothing to move: feasibility was settled by k_ldp_setup
+    }
+    if (iterations) *iterations = hst.iters;
+    if (hst.phase != 2) {
+        *status = hst.phase == 3 ? OG_QP_ITERATION_LIMIT : OG_QP_INCOMPATIBLE;
+        return 0;
+    }
+    // ---- step and multipliers
+    hipLaunchKernelGGL(k_finish_step, dim3((nq + 3) / 4), dim3(256), 0, s, qp->Jw, n1, meq, nq, nr, mg, qp->y, qp->deq,
+                       qp->dl, qp->du, qp->u, qp->d, qp->bm);
+    hipLaunchKernelGGL(k_dual_residual, dim3((nq + 3) / 4), dim3(256), 0, s, A, meq, mg, nq, qp->g, qp->u, qp->bm,
+                       qp->tvec);
+    if (meq) {
+        hipLaunchKernelGGL(k_gemv_cols, dim3((meq + 63) / 64), dim3(1024), 0, s, qp->Jw, (long)n1, nq, meq, qp->tvec,
+                           qp->w1, qp->rhs);
+        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, n1, qp->diagL, meq, 1, 1.0, qp->rhs,
+                           qp->lam);
+    }
+    OG_HIP(hipGetLastError());
+    OG_HIP(hipMemcpyAsync(d, qp->d, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
+    OG_HIP(hipMemcpyAsync(bound_mult, qp->bm, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
+    if (meq) OG_HIP(hipMemcpyAsync(mult, qp->lam, sizeof(double) * meq, hipMemcpyDeviceToHost, s));
+    if (mg) OG_HIP(hipMemcpyAsync(mult + meq, qp->u, sizeof(double) * mg, hipMemcpyDeviceToHost, s));
+    OG_HIP(hipStreamSynchronize(s));
+    if (!augmented) std::swap(qp->Z, qp->Jw);   // Z Q: same B, what og_qp_bfgs updates next
+    *status = OG_QP_SOLVED;
+    return 0;
+}
+
+int og_qp_solve(og_qp_handle qp, const double* A, const double* g, const double* c, const double* dl,
+                const double* du, int32_t augmented, double rho, double* d, double* mult, double* bound_mult,
+                int32_t* status, int32_t* iterations) {
+    if (!qp || (qp->m > 0 && !A)) return fail(2, "og_qp_solve: null argument");
+    OG_HIP(hipSetDevice(qp->device));
+    const size_t ld = (size_t)qp->m + 1, n = qp->n;
+    if (!qp->jt_stage) OG_HIP(hipMalloc((void**)&qp->jt_stage, sizeof(double) * ld * n));
+    std::vector<double> jt(ld * n, 0.0);
+    for (int j = 0; j < qp->m; ++j)
+        for (size_t i = 0; i < n; ++i) jt[i * ld + 1 + j] = A[(size_t)j * n + i];
+    OG_HIP(hipMemcpy(qp->jt_stage, jt.data(), sizeof(double) * ld * n, hipMemcpyHostToDevice));
+    return og_qp_solve_dev(qp, qp->jt_stage, (int64_t)ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status,
+                           iterations, nullptr);
+}
+
+int og_qp_bfgs(og_qp_handle qp, const double* s, const double* eta, const double* Bs, int32_t* reset_needed) {
+    if (!qp || !s || !eta || !Bs || !reset_needed) return fail(2, "og_qp_bfgs: null argument");
+    OG_HIP(hipSetDevice(qp->device));
+    const int n = qp->n, n1 = qp->n1;
+    double h1 = 0.0, h2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        h1 += s[i] * eta[i];
+        h2 += s[i] * Bs[i];
+    }
+    const double h3 = 0.2 * h2;
+    double theta = 1.0;
+    if (h1 < h3) {
+        theta = (h2 - h3) / (h2 - h1);
+        h1 = h3;
+    }
+    if (!(h1 > 0.0 && h2 > 0.0) || !std::isfinite(h1) || !std::isfinite(h2)) {
+        *reset_needed = 1;
+        return 0;
+    }
+    *reset_needed = 0;
+    const double alpha = std::sqrt(h1 / h2);
+    std::vector<double>& hs = qp->host_stage;
+    hs.assign((size_t)2 * n1, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const double r = theta * eta[i] + (1.0 - theta) * Bs[i];
+        hs[i] = s[i];
+        hs[n1 + i] = (r - alpha * Bs[i]) / (alpha * h2);
+    }
+    hipStream_t st = qp->stream;
+    OG_HIP(hipMemcpyAsync(qp->svec, hs.data(), sizeof(double) * n1, hipMemcpyHostToDevice, st));
+    OG_HIP(hipMemcpyAsync(qp->vvec, hs.data() + n1, sizeof(double) * n1, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gemv_cols, dim3((n + 63) / 64), dim3(1024), 0, st, qp->Z, (long)n1, n, n, qp->vvec,
+                       (const double*)nullptr, qp->vz);
+    hipLaunchKernelGGL(k_rank1, dim3((n + 255) / 256, n), dim3(256), 0, st, qp->Z, n1, n, qp->svec, qp->vz,
+                       1.0 / alpha);
+    OG_HIP(hipGetLastError());
+    OG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int og_jt_times(og_qp_handle qp, const double* d_jt, int64_t ld, const double* coef, double* out, void* hip_stream) {
+    if (!qp || !d_jt || !coef || !out) return fail(2, "og_jt_times: null argument");
+    OG_HIP(hipSetDevice(qp->device));
+    if (hip_stream) OG_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    hipStream_t s = qp->stream;
+    const int width = qp->m + 1;
+    OG_HIP(hipMemcpyAsync(qp->coef, coef, sizeof(double) * width, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_jt_times, dim3((qp->n + 3) / 4), dim3(256), 0, s, d_jt, (long)ld, qp->n, width, qp->coef,
+                       qp->outn);
+    OG_HIP(hipGetLastError());
+    OG_HIP(hipMemcpyAsync(out, qp->outn, sizeof(double) * qp->n, hipMemcpyDeviceToHost, s));
+    OG_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // extern "C"

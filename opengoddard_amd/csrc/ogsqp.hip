@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -46,10 +48,10 @@ int fail(int code, const std::string& msg) {
 
 constexpr double DEPENDENT = 1e-10;   // |projection| / |normal| below this: linearly dependent
 constexpr double FEASIBLE = 1e-12;    // rounding level of a normalised constraint value
-constexpr double UNFIXABLE = 1e-7;    // violation of a row the null space cannot move
 constexpr double SINGULAR_C = 1e-13;  // |L_kk| / max |L_jj| below this: C rank deficient
-constexpr int REFINE = 2;             // re-orthogonalisation passes per active-set iteration
-constexpr int GI_THREADS = 512;
+constexpr int REFINE = 3;             // at most this many re-orthogonalisation passes (one is the rule)
+constexpr double REORTH = 1e-8;       // another pass while the last correction exceeds this, relative
+constexpr int GI_THREADS = 1024;
 constexpr int GI_WAVES = GI_THREADS / 64;
 constexpr size_t LDS_LIMIT = 160 * 1024 - 2048;
 
@@ -405,6 +407,9 @@ struct GiState {
     unsigned ticket;
     double up;
     double ynorm;
+    int dbg;
+    int dbg2;
+    long long tr[12];   // OGSQP_TRACE: accumulated s_memtime ticks (10 ns) per section of the update
 };
 
 struct GiPartial {
@@ -426,6 +431,7 @@ struct GiArgs {
     int* act;             // qcap
     double* R[2];
     double* RI[2];
+    double* Q1t;          // qcap x nr
     GiPartial* partials;
     GiState* st;
     int limit;
@@ -446,7 +452,8 @@ __device__ __forceinline__ const double* stack_row(const GiArgs& g, int r, doubl
 }
 
 // Row norms over all nq columns and over the null-space columns; b, scale, own of every stack row.
-// flag[1] is raised when a row that the null space cannot move is violated beyond FD noise.
+// A row whose projection on the null space vanishes (an inequality or bound that repeats an
+// equality) cannot be influenced by y: scale 0 takes it out of the problem, as LSEI's elimination does.
 __global__ __launch_bounds__(256) void k_ldp_setup(const double* __restrict__ GJ, const double* __restrict__ Jw, int ld,
                                                    int meq, int nq, int mg, const double* __restrict__ bG,
                                                    const double* __restrict__ cin, const double* __restrict__ deq,
@@ -472,7 +479,6 @@ __global__ __launch_bounds__(256) void k_ldp_setup(const double* __restrict__ GJ
         bval[r] = b;
         scale[r] = movable ? red : 0.0;
         own[r] = movable ? FEASIBLE * fabs(b) / red : 0.0;
-        if (!movable && b < -UNFIXABLE * fmax(1.0, fabs(cin[r]))) atomicOr(flag + 1, 1);
     } else {
         const int i = r - mg;
         const double lo = dl[i], hi = du[i];
@@ -484,8 +490,6 @@ __global__ __launch_bounds__(256) void k_ldp_setup(const double* __restrict__ GJ
         scale[mg + nq + i] = (has_hi && movable) ? red : 0.0;
         own[mg + i] = (has_lo && movable) ? FEASIBLE * fabs(blo) / red : 0.0;
         own[mg + nq + i] = (has_hi && movable) ? FEASIBLE * fabs(bhi) / red : 0.0;
-        if (!movable && has_lo && blo < -UNFIXABLE * fmax(1.0, fabs(lo))) atomicOr(flag + 1, 1);
-        if (!movable && has_hi && bhi < -UNFIXABLE * fmax(1.0, fabs(hi))) atomicOr(flag + 1, 1);
     }
 }
 
@@ -507,9 +511,23 @@ __global__ void k_gi_init(GiArgs g, const int* flag) {
         s.ticket = 0u;
         s.up = 0.0;
         s.ynorm = 0.0;
+        s.dbg = 0;
+        s.dbg2 = 0;
+        for (int e = 0; e < 12; ++e) s.tr[e] = 0;
         *g.st = s;
     }
 }
+
+#ifdef OGSQP_TRACE
+#define TRACE_MARK(slot)                                        \
+    do {                                                        \
+        const long long now_ = __builtin_amdgcn_s_memtime();    \
+        if (tid == 0) st->tr[slot] += now_ - t_mark;            \
+        t_mark = now_;                                          \
+    } while (0)
+#else
+#define TRACE_MARK(slot) do { } while (0)
+#endif
 
 // One active-set iteration.
 __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
@@ -522,6 +540,9 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
     if (phase0 >= 2) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nr = g.nr, mg = g.mg, nq = g.nq;
+#ifdef OGSQP_TRACE
+    long long t_mark = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- all workgroups: constraint values and the most violated usable row -----------------
     {
@@ -556,29 +577,29 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
         }
         block_argmin(best, besti, redv, redi);
         if (tid == 0) {
-            g.partials[blockIdx.x].value = best;
-            g.partials[blockIdx.x].index = besti;
-            __threadfence();
-            const unsigned t = atomicAdd(&st->ticket, 1u);
+            // publish at agent scope (write-through, no L2 flush), then take a ticket; the stores are
+            // acknowledged before the ticket is issued, so whoever draws the last ticket sees them all
+            __hip_atomic_store(&g.partials[blockIdx.x].value, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g.partials[blockIdx.x].index, besti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (t == gridDim.x - 1) ? 1 : 0;
         }
         __syncthreads();
         if (!s_last) return;
-        __threadfence();
     }
+    TRACE_MARK(0);   // phase A of the last workgroup + wait for the others
 
     // ---- last workgroup: the update ------------------------------------------------------------
     const int qcap = g.qcap;
     double* nv = lds;                 // normal of p in the null-space coordinates
     double* zv = nv + nr;             // its component orthogonal to the active normals
-    double* av = zv + nr;             // N' vec
-    double* tv = av + qcap;           // RI' av
-    double* rinc = tv + qcap;         // RI tv
-    double* rho = rinc + qcap;        // accumulated  R^-T N' n   (new column of R)
-    double* rv = rho + qcap;          // accumulated  (N'N)^-1 N' n
-    double* sg = rv + qcap;           // sign of every active row
-    const double** rowp = (const double**)(sg + qcap);
-    double* red = (double*)(rowp + qcap);
+    double* av = zv + nr;             // Q1' n, accumulated over the passes  (new column of R)
+    double* ainc = av + qcap;         // Q1' vec of the current pass
+    double* rv = ainc + qcap;         // R^-1 Q1' n                         (dual step direction)
+    double* cs = rv + qcap;           // cosine / sine of the rotations of a removal (2 qcap)
+    double* carried = cs + 2 * qcap;  // row being rotated downwards, indexed by old column
+    double* red = carried + qcap;
 
     if (tid == 0) st->ticket = 0u;
     int p;
@@ -586,8 +607,8 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
         double v = INFINITY;
         int idx = 0x7fffffff;
         for (int b = tid; b < (int)gridDim.x; b += GI_THREADS) {
-            const double pv = ((volatile GiPartial*)g.partials)[b].value;
-            const int pi = ((volatile GiPartial*)g.partials)[b].index;
+            const double pv = __hip_atomic_load(&g.partials[b].value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int pi = __hip_atomic_load(&g.partials[b].index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (pv < v || (pv == v && pi < idx)) {
                 v = pv;
                 idx = pi;
@@ -606,15 +627,25 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
     } else {
         p = st->p;
     }
+    TRACE_MARK(1);   // election
     const int iters = st->iters + 1;
     if (iters > g.limit) {
         if (tid == 0) st->phase = 3;
         return;
     }
     const int q = st->q, cur = st->cur;
+    if (p < 0 || p >= mg + 2 * nq || q < 0 || q > nr || q >= qcap) {   // cannot happen; never index with it
+        if (tid == 0) {
+            st->phase = 3;
+            st->dbg = 100 + q;
+            st->dbg2 = p;
+        }
+        return;
+    }
     const double up_old = (phase0 == 0) ? 0.0 : st->up;
     double* R = g.R[cur];
     double* RI = g.RI[cur];
+    double* Q1t = g.Q1t;              // q x nr, row j = j-th orthonormal direction of the active normals
 
     double psign;
     const double* prow = stack_row(g, p, psign);
@@ -625,54 +656,111 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
         part_y += v * g.y[i];
         part_nn += v * v;
     }
-    for (int j = tid; j < q; j += GI_THREADS) {
-        double s;
-        rowp[j] = stack_row(g, g.act[j], s);
-        sg[j] = s;
-        rho[j] = 0.0;
-        rv[j] = 0.0;
-    }
+    for (int j = tid; j < q; j += GI_THREADS) av[j] = 0.0;
     const double sp = g.bval[p] + block_sum(part_y, red);
     const double nn = block_sum(part_nn, red);
+    TRACE_MARK(2);   // load normal
 
-    // classical Gram-Schmidt against the active normals, repeated REFINE times
+    // z = (I - Q1 Q1') n by classical Gram-Schmidt, repeated ("twice is enough")
     for (int pass = 0; pass <= REFINE; ++pass) {
         const double* vec = pass == 0 ? nv : zv;
-        for (int j = wave; j < q; j += GI_WAVES) {
-            const double* row = rowp[j];
-            double dot = 0.0;
-            for (int i = lane; i < nr; i += 64) dot += row[i] * vec[i];
-            dot = wave_sum(dot);
-            if (lane == 0) av[j] = sg[j] * dot;
+        for (int j0 = wave * 4; j0 < q; j0 += GI_WAVES * 4) {
+            // four directions per trip: 4 x nr/64 independent loads in flight per lane
+            const int cnt = min(4, q - j0);
+            const double* row0 = Q1t + (long)j0 * nr;
+            const double* row1 = cnt > 1 ? row0 + nr : row0;
+            const double* row2 = cnt > 2 ? row0 + 2 * (long)nr : row0;
+            const double* row3 = cnt > 3 ? row0 + 3 * (long)nr : row0;
+            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+            for (int i = lane; i < nr; i += 64) {
+                const double x = vec[i];
+                d0 += row0[i] * x;
+                d1 += row1[i] * x;
+                d2 += row2[i] * x;
+                d3 += row3[i] * x;
+            }
+            d0 = wave_sum(d0);
+            d1 = wave_sum(d1);
+            d2 = wave_sum(d2);
+            d3 = wave_sum(d3);
+            if (lane == 0) {
+                ainc[j0] = d0;
+                if (cnt > 1) ainc[j0 + 1] = d1;
+                if (cnt > 2) ainc[j0 + 2] = d2;
+                if (cnt > 3) ainc[j0 + 3] = d3;
+            }
         }
         __syncthreads();
-        for (int i = wave; i < q; i += GI_WAVES) {
-            const double* col = RI + (long)i * qcap;
-            double dot = 0.0;
-            for (int j = lane; j <= i; j += 64) dot += col[j] * av[j];
-            dot = wave_sum(dot);
-            if (lane == 0) tv[i] = dot;
+        TRACE_MARK(3);   // projections Q1' vec
+        double part_corr = 0.0;
+        for (int j = tid; j < q; j += GI_THREADS) {
+            av[j] += ainc[j];
+            part_corr += ainc[j] * ainc[j];
         }
-        __syncthreads();
-        for (int i = tid; i < q; i += GI_THREADS) {
-            double acc = 0.0;
-            for (int j = i; j < q; ++j) acc += RI[(long)j * qcap + i] * tv[j];
-            rinc[i] = acc;
-            rho[i] += tv[i];
-            rv[i] += acc;
-        }
-        __syncthreads();
+        const double corr = pass == 0 ? INFINITY : block_sum(part_corr, red);
         for (int i = tid; i < nr; i += GI_THREADS) {
-            double acc = vec[i];
-            for (int j = 0; j < q; ++j) acc -= rinc[j] * sg[j] * rowp[j][i];
-            zv[i] = acc;
+            double acc0 = vec[i], acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            const double* col = Q1t + i;
+            int j = 0;
+            for (; j + 32 <= q; j += 32) {
+                double l[32];
+#pragma unroll
+                for (int e = 0; e < 32; ++e) l[e] = col[(long)(j + e) * nr];
+#pragma unroll
+                for (int e = 0; e < 32; e += 4) {
+                    acc0 -= ainc[j + e] * l[e];
+                    acc1 -= ainc[j + e + 1] * l[e + 1];
+                    acc2 -= ainc[j + e + 2] * l[e + 2];
+                    acc3 -= ainc[j + e + 3] * l[e + 3];
+                }
+            }
+            for (; j + 4 <= q; j += 4) {
+                const double l0 = col[(long)j * nr], l1 = col[(long)(j + 1) * nr], l2 = col[(long)(j + 2) * nr],
+                             l3 = col[(long)(j + 3) * nr];
+                acc0 -= ainc[j] * l0;
+                acc1 -= ainc[j + 1] * l1;
+                acc2 -= ainc[j + 2] * l2;
+                acc3 -= ainc[j + 3] * l3;
+            }
+            for (; j < q; ++j) acc0 -= ainc[j] * col[(long)j * nr];
+            zv[i] = (acc0 + acc1) + (acc2 + acc3);
         }
         __syncthreads();
+        TRACE_MARK(4);   // z update
+        if (tid == 0) st->tr[10] += 1;
+        if (pass >= 1 && !(corr > (REORTH * REORTH) * nn)) break;
+        if (pass == 0) {
+            // Daniel-Gragg-Kaufman-Stewart: no second pass when the first one cancelled little
+            double part_z0 = 0.0;
+            for (int i = tid; i < nr; i += GI_THREADS) part_z0 += zv[i] * zv[i];
+            if (block_sum(part_z0, red) > 0.5 * nn) break;
+        }
+    }
+    // r = R^-1 a with the explicit inverse (column sweep, contiguous in i)
+    for (int i = tid; i < q; i += GI_THREADS) {
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        const double* col = RI + i;
+        int j = i;
+        for (; j + 32 <= q; j += 32) {
+            double l[32];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) l[e] = col[(long)(j + e) * qcap];
+#pragma unroll
+            for (int e = 0; e < 32; e += 4) {
+                acc0 += l[e] * av[j + e];
+                acc1 += l[e + 1] * av[j + e + 1];
+                acc2 += l[e + 2] * av[j + e + 2];
+                acc3 += l[e + 3] * av[j + e + 3];
+            }
+        }
+        for (; j < q; ++j) acc0 += col[(long)j * qcap] * av[j];
+        rv[i] = (acc0 + acc1) + (acc2 + acc3);
     }
     double part_zz = 0.0;
     for (int i = tid; i < nr; i += GI_THREADS) part_zz += zv[i] * zv[i];
     const double zz = block_sum(part_zz, red);
-    const bool dependent = !(zz > (DEPENDENT * DEPENDENT) * nn);
+    // q == nr: the active normals already span the null space, nothing is independent of them
+    const bool dependent = (q >= nr) || !(zz > (DEPENDENT * DEPENDENT) * nn);
 
     // ratio test over the active rows
     double t1 = INFINITY;
@@ -686,6 +774,7 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
             }
         }
     block_argmin(t1, kdrop, redv, redi);
+    TRACE_MARK(5);   // r, |z|, ratio test
     const double t2 = dependent ? INFINITY : -sp / zz;
     const double t = fmin(t1, t2);
     if (!(t < INFINITY)) {
@@ -708,16 +797,18 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
     }
     const double ynorm = sqrt(block_sum(part_yy, red));
     const bool full_step = (t2 < INFINITY) && (t2 <= t1);
+    TRACE_MARK(6);   // u, y update
     if (full_step) {
-        // p joins the active set: R gets the column [rho; |z|], RI the column [-r/|z|; 1/|z|]
-        const double delta = sqrt(zz);
+        // p joins the active set: Q1 gets z/|z|, R the column [a; |z|], RI the column [-r/|z|; 1/|z|]
+        const double delta = sqrt(zz), inv = 1.0 / delta;
         for (int i = tid; i < q; i += GI_THREADS) {
-            R[(long)q * qcap + i] = rho[i];
-            RI[(long)q * qcap + i] = -rv[i] / delta;
+            R[(long)q * qcap + i] = av[i];
+            RI[(long)q * qcap + i] = -rv[i] * inv;
         }
+        for (int i = tid; i < nr; i += GI_THREADS) Q1t[(long)q * nr + i] = zv[i] * inv;
         if (tid == 0) {
             R[(long)q * qcap + q] = delta;
-            RI[(long)q * qcap + q] = 1.0 / delta;
+            RI[(long)q * qcap + q] = inv;
             g.act[q] = p;
             g.u[p] = up;
             g.isact[p] = 1;
@@ -726,15 +817,22 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
             st->iters = iters;
             st->ynorm = ynorm;
         }
+        TRACE_MARK(7);   // append
         return;
     }
 
     // ---- partial step: active row k leaves ------------------------------------------------------
     const int k = kdrop;
+    if (k < 0 || k >= q) {
+        if (tid == 0) {
+            st->phase = 3;
+            st->dbg = -7;
+            st->dbg2 = k;
+        }
+        return;
+    }
     double* Rn = g.R[cur ^ 1];
     double* RIn = g.RI[cur ^ 1];
-    double* carried = av;   // row being rotated downwards, indexed by old column
-    double* cs = tv;        // cosine / sine of every rotation (2 per step), tv and rinc are adjacent
     // unchanged parts: columns before k; rows above k of the columns after k (shifted left)
     for (int c = wave; c < q; c += GI_WAVES) {
         if (c == k) continue;
@@ -772,7 +870,7 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
         }
     }
     __syncthreads();
-    // the same rotations on the columns of RI; row k and the last column drop out
+    // the same rotations on the columns of RI (row k and the last column drop out) ...
     for (int i = tid; i < q; i += GI_THREADS) {
         if (i == k) continue;
         const int in = i < k ? i : i - 1;
@@ -784,8 +882,19 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
             x = -si * x + co * yv;
         }
     }
+    // ... and on the orthonormal directions (in place: every thread owns one coordinate)
+    for (int i = tid; i < nr; i += GI_THREADS) {
+        double* col = Q1t + i;
+        double x = col[(long)k * nr];
+        for (int j = k; j < q - 1; ++j) {
+            const double yv = col[(long)(j + 1) * nr];
+            const double co = cs[2 * j], si = cs[2 * j + 1];
+            col[(long)j * nr] = co * x + si * yv;
+            x = -si * x + co * yv;
+        }
+    }
     __syncthreads();
-    int* shifted = (int*)av;
+    int* shifted = (int*)carried;
     const int leaving = g.act[k];
     for (int j = k + tid; j < q - 1; j += GI_THREADS) shifted[j] = g.act[j + 1];
     __syncthreads();
@@ -793,15 +902,15 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
     if (tid == 0) {
         g.u[leaving] = 0.0;
         g.isact[leaving] = 0;
-    }
-    if (tid == 0) {
         st->q = q - 1;
         st->cur = cur ^ 1;
         st->phase = 1;
         st->up = up;
         st->iters = iters;
         st->ynorm = ynorm;
+        st->tr[11] += 1;
     }
+    TRACE_MARK(8);   // removal
 }
 
 // d = clip(deq + Y y), multipliers of the general inequalities and of the bounds
@@ -855,7 +964,7 @@ struct og_qp_s {
     double *extra = nullptr, *g = nullptr, *c = nullptr, *dl = nullptr, *du = nullptr;
     double *w1 = nullptr, *t1 = nullptr, *xcat = nullptr, *deq = nullptr, *bG = nullptr;
     double *bval = nullptr, *scale = nullptr, *own = nullptr, *u = nullptr, *y = nullptr;
-    double *R[2] = {nullptr, nullptr}, *RI[2] = {nullptr, nullptr};
+    double *R[2] = {nullptr, nullptr}, *RI[2] = {nullptr, nullptr}, *Q1t = nullptr;
     double *d = nullptr, *bm = nullptr, *tvec = nullptr, *rhs = nullptr, *lam = nullptr, *vz = nullptr;
     double *svec = nullptr, *vvec = nullptr, *coef = nullptr, *outn = nullptr;
     int *isact = nullptr, *act = nullptr, *flag = nullptr;
@@ -877,6 +986,22 @@ int dev_alloc(og_qp_s* qp, T** ptr, size_t count) {
     return 0;
 }
 
+// OGSQP_DEBUG=1: announce every stage on stderr and synchronise after it, so that a device fault
+// can be attributed to a kernel.
+bool debug_stages() {
+    static const bool on = getenv("OGSQP_DEBUG") != nullptr;
+    return on;
+}
+
+#define OG_STAGE(name)                                                             \
+    do {                                                                           \
+        if (debug_stages()) {                                                      \
+            OG_HIP(hipStreamSynchronize(s));                                       \
+            fprintf(stderr, "[ogsqp] stage done; next: %s\n", name);               \
+            fflush(stderr);                                                        \
+        }                                                                          \
+    } while (0)
+
 #define OG_TRY(expr)          \
     do {                      \
         int rc_ = (expr);     \
@@ -884,7 +1009,7 @@ int dev_alloc(og_qp_s* qp, T** ptr, size_t count) {
     } while (0)
 
 size_t gi_lds_bytes(int nr, int qcap) {
-    return (size_t)(2 * nr + 6 * qcap) * sizeof(double) + (size_t)qcap * sizeof(void*) + 64 * sizeof(double);
+    return (size_t)(2 * nr + 6 * qcap + 64) * sizeof(double);
 }
 
 }  // namespace
@@ -922,7 +1047,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->diagL, qp->meq); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
-    A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
+    A(&qp->Q1t, qc * qc); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
     A(&qp->isact, mt); A(&qp->act, qc); A(&qp->flag, 2);
@@ -1019,17 +1144,21 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         hipLaunchKernelGGL(k_relaxation_row, dim3((m + 255) / 256), dim3(256), 0, s, qp->c, meq, m, qp->extra);
     AView A{d_jt, (long)ld, qp->extra, n};
     // ---- work factor, C Z, LQ sweep
+    OG_STAGE("copy_factor");
     hipLaunchKernelGGL(k_copy_factor, dim3((nq + 255) / 256, nq), dim3(256), 0, s, qp->Z, qp->Jw, n1, n, nq,
                        augmented ? 1.0 / rho : 0.0);
     if (meq) {
+        OG_STAGE("gemm C Z");
         hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, n1,
                            nq, qp->Tc);
+        OG_STAGE("lq sweep");
         for (int k = 0; k < meq; ++k) {
             const int nrows = (meq - k - 1) + nq;
             const size_t lds = (size_t)(nq - k + 16) * sizeof(double);
             hipLaunchKernelGGL(k_lq_step, dim3((nrows + LQ_ROWS - 1) / LQ_ROWS), dim3(256), lds, s, qp->Tc, qp->Jw, n1,
                                meq, nq, k, qp->diagL);
         }
+        OG_STAGE("check diag");
         hipLaunchKernelGGL(k_check_diag, dim3(1), dim3(1024), 0, s, qp->diagL, meq, qp->flag);
     }
     OG_HIP(hipGetLastError());
@@ -1042,9 +1171,11 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     }
     // ---- equality-constrained minimiser: L w1 = -c,  deq = J1 w1 - Y (Y'g)
     const size_t trsv_lds = (size_t)(meq + 64 * 65) * sizeof(double);
+    OG_STAGE("trsv w1");
     if (meq)
         hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, n1, qp->diagL, meq, 0, -1.0, qp->c,
                            qp->w1);
+    OG_STAGE("deq");
     if (nr > 0)
         hipLaunchKernelGGL(k_gemv_cols, dim3((nr + 63) / 64), dim3(1024), 0, s, qp->Jw + meq, (long)n1, nq, nr, qp->g,
                            (const double*)nullptr, qp->t1);
@@ -1052,29 +1183,37 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     hipLaunchKernelGGL(k_gemv_rows, dim3((nq + 3) / 4), dim3(256), 0, s, qp->Jw, (long)n1, nq, nq, qp->xcat, 1.0,
                        (const double*)nullptr, qp->deq);
     // ---- least-distance problem in the null space
+    OG_STAGE("gemm G J");
     if (mg) {
         hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (mg + 63) / 64), dim3(256), 0, s, A, meq, mg, qp->Jw, n1,
                            nq, qp->GJ);
         hipLaunchKernelGGL(k_gemv_cols_A, dim3((mg + 63) / 64), dim3(1024), 0, s, A, meq, nq, mg, qp->deq,
                            qp->c + meq, qp->bG);
     }
+    OG_STAGE("ldp setup");
     hipLaunchKernelGGL(k_ldp_setup, dim3((mg + nq + 3) / 4), dim3(256), 0, s, qp->GJ, qp->Jw, n1, meq, nq, mg, qp->bG,
                        qp->c + meq, qp->deq, qp->dl, qp->du, qp->bval, qp->scale, qp->own, qp->flag);
     GiArgs ga;
     ga.GJ = qp->GJ; ga.Jw = qp->Jw; ga.ld = n1; ga.meq = meq; ga.nq = nq; ga.mg = mg; ga.nr = nr;
     ga.qcap = qp->qcap; ga.bval = qp->bval; ga.scale = qp->scale; ga.own = qp->own; ga.u = qp->u;
     ga.isact = qp->isact; ga.y = qp->y; ga.act = qp->act; ga.R[0] = qp->R[0]; ga.R[1] = qp->R[1];
-    ga.RI[0] = qp->RI[0]; ga.RI[1] = qp->RI[1]; ga.partials = qp->partials; ga.st = qp->st;
+    ga.RI[0] = qp->RI[0]; ga.RI[1] = qp->RI[1]; ga.Q1t = qp->Q1t; ga.partials = qp->partials; ga.st = qp->st;
     const int mt = mg + 2 * nq;
     ga.limit = 10 * (mt + nr) + 100;
+    OG_STAGE("gi init");
     hipLaunchKernelGGL(k_gi_init, dim3((mt + n1 + 255) / 256), dim3(256), 0, s, ga, qp->flag);
     OG_HIP(hipGetLastError());
     GiState hst;
     memset(&hst, 0, sizeof(hst));
+    if (debug_stages()) {
+        OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        OG_HIP(hipStreamSynchronize(s));
+    }
     if (nr > 0) {
         const int blocks = (mg + nq + GI_WAVES - 1) / GI_WAVES;
         const size_t lds = gi_lds_bytes(nr, qp->qcap);
-        int batch = 8;
+        int batch = debug_stages() ? 1 : 8;
+        OG_STAGE("gi iterations");
         while (true) {
             for (int it = 0; it < batch; ++it)
                 hipLaunchKernelGGL(k_gi_iter, dim3(blocks), dim3(GI_THREADS), lds, s, ga);
@@ -1090,11 +1229,27 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         if (hst.phase < 2) hst.phase = 2;   // nothing to move: feasibility was settled by k_ldp_setup
     }
     if (iterations) *iterations = hst.iters;
+    if (debug_stages())
+        fprintf(stderr, "[ogsqp] LDP finished: phase %d after %d iterations, %d active, unfixable-row flag %d\n",
+                hst.phase, hst.iters, hst.q, hflag[1]);
+#ifdef OGSQP_TRACE
+    {
+        static const char* names[9] = {"phase A + wait", "election", "load normal", "projections", "z update",
+                                       "r + ratio test", "u,y update", "append", "removal"};
+        fprintf(stderr, "[ogsqp trace] %d iterations, %lld passes, %lld removals, %d active at the end\n", hst.iters,
+                hst.tr[10], hst.tr[11], hst.q);
+        for (int e = 0; e < 9; ++e)
+            fprintf(stderr, "[ogsqp trace]   %-16s %8.2f us per iteration\n", names[e],
+                    hst.iters ? 0.01 * (double)hst.tr[e] / hst.iters : 0.0);
+    }
+#endif
+    if (hst.dbg != 0) fprintf(stderr, "[ogsqp] internal check failed: code %d aux %d (q %d, p %d)\n", hst.dbg, hst.dbg2, hst.q, hst.p);
     if (hst.phase != 2) {
         *status = hst.phase == 3 ? OG_QP_ITERATION_LIMIT : OG_QP_INCOMPATIBLE;
         return 0;
     }
     // ---- step and multipliers
+    OG_STAGE("finish");
     hipLaunchKernelGGL(k_finish_step, dim3((nq + 3) / 4), dim3(256), 0, s, qp->Jw, n1, meq, nq, nr, mg, qp->y, qp->deq,
                        qp->dl, qp->du, qp->u, qp->d, qp->bm);
     hipLaunchKernelGGL(k_dual_residual, dim3((nq + 3) / 4), dim3(256), 0, s, A, meq, mg, nq, qp->g, qp->u, qp->bm,

@@ -16,6 +16,8 @@ a GPU it raises.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import trace as _tr
@@ -26,6 +28,9 @@ __all__ = ["Problem", "Guess", "Condition", "Dynamics"]
 # engine.  The test-suite swaps in the NumPy oracle here to exercise host logic without a GPU
 # (tests/conftest.py); nothing in this package ever sets it.
 ENGINE_FACTORY = None
+# 'scipy': SciPy's Fortran SLSQP driven by GPU callbacks (the reference's own core);
+# 'hip': the same major iteration with the QP subproblem on the GPU (sqp.py, include/ogsqp.h)
+DEFAULT_SQP_CORE = "scipy"
 
 
 def _default_engine(prob, obj):
@@ -421,11 +426,29 @@ class Problem:
 
         ftol = options.setdefault("ftol", 1e-6)
         maxiter = options.setdefault("maxiter", 25)
+        core = options.pop("sqp_core", None) or os.environ.get("OG_SQP_CORE", DEFAULT_SQP_CORE)
+        if core not in ("scipy", "hip"):
+            raise ValueError("sqp_core must be 'scipy' or 'hip', got %r" % (core,))
+        if core == "hip":
+            from . import sqp as _sqp
+            user_gradient = None
+            if self.cost_derivative is not None:
+                def user_gradient(p):
+                    self.p = p
+                    return self.cost_derivative(self, obj)
         while self.iterator < self.maxIterator:
             print("---- iteration : {0} ----".format(self.iterator + 1))
-            opt = _sciopt.minimize(value_of(0), self.p, args=(self, obj), bounds=self.bounds,
-                                   constraints=cons, jac=cost_jac, method="SLSQP",
-                                   options={"disp": True, "maxiter": maxiter, "ftol": ftol})
+            if core == "hip":
+                # same major iteration, QP subproblem and BFGS factor on the GPU (sqp.py)
+                opt = _sqp.minimize_slsqp_hip(engine, self.p, lb, ub, ftol=ftol, maxiter=maxiter,
+                                              cost_derivative=user_gradient, disp=True)
+                self.p = opt.last_callback_p
+                self.sqp_timing = opt.timing
+            else:
+                opt = _sciopt.minimize(value_of(0), self.p, args=(self, obj), bounds=self.bounds,
+                                       constraints=cons, jac=cost_jac, method="SLSQP",
+                                       options={"disp": True, "maxiter": maxiter, "ftol": ftol})
+            self.last_result = opt
             print(opt.message)
             display_func()
             print("")

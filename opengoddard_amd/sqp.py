@@ -1,0 +1,257 @@
+"""SLSQP major iteration with the QP subproblem and the quasi-Newton matrix on the GPU.
+
+What it stands in for: ``scipy.optimize.minimize(method='SLSQP')`` as the reference calls it
+(``optimize.py:723-749``; SciPy's driver ``scipy:_slsqp_py.py:214-512`` around Kraft's Fortran
+``slsqpb``).  The algorithm is Kraft's, statement for statement where it decides anything - QP
+subproblem, relaxed QP for an inconsistent linearisation (``rho`` = 100, x10 up to five times),
+multiplier averaging for the L1 merit function, the inexact line search
+(``alpha = max(h3 / (2 (h3 - h1)), 0.1)``, at most ten cuts), Powell-damped BFGS, up to five
+resets on a non-descent direction, the relaxed convergence test after the last reset, and the exit
+modes 0 / 4 / 6 / 8 / 9 with SciPy's messages - so iteration counts and results match SciPy's up
+to the rounding of the QP solution (``tests/test_slsqp_core.py`` replays SciPy's own iterates).
+
+What is different is where the data lives.  The FD Jacobian never leaves HBM: the sweep kernel
+writes it transposed, the QP core (``include/ogsqp.h``) reads it in place, and only O(n) vectors
+(step, multipliers, gradients of the Lagrangian) cross PCIe.  The O(n) logic below runs on the
+host in NumPy, like SciPy's wrapper does.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import _native, _sqp_native
+
+EXIT_MODES = {-1: "Gradient evaluation required (g & a)",
+              0: "Optimization terminated successfully",
+              1: "Function evaluation required (f & c)",
+              2: "More equality constraints than independent variables",
+              3: "More than 3*n iterations in LSQ subproblem",
+              4: "Inequality constraints incompatible",
+              5: "Singular matrix E in LSQ subproblem",
+              6: "Singular matrix C in LSQ subproblem",
+              7: "Rank-deficient equality constraint subproblem HFTI",
+              8: "Positive directional derivative for linesearch",
+              9: "Iteration limit reached"}
+
+
+_DEBUG = bool(os.environ.get("OGSQP_DEBUG"))
+
+
+class SqpResult(dict):
+    """Attribute access like ``scipy.optimize.OptimizeResult``."""
+    __getattr__ = dict.get
+    __setattr__ = dict.__setitem__
+
+
+class DeviceJacobian:
+    """The transposed FD Jacobian of one engine, resident in HBM (torch owns the allocation)."""
+
+    def __init__(self, engine):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("the HIP SQP core needs a GPU (no CPU fallback)")
+        self.engine = engine
+        self.torch = torch
+        dev = torch.device("cuda", engine.device)
+        self.n, self.ld = engine.n, engine.m                 # ld = 1 + m_eq + m_ineq
+        self.d_x = torch.empty(self.n, dtype=torch.float64, device=dev)
+        self.d_h = torch.empty(self.n, dtype=torch.float64, device=dev)
+        self.d_F0 = torch.empty(self.ld, dtype=torch.float64, device=dev)
+        self.d_JT = torch.empty(self.n * self.ld, dtype=torch.float64, device=dev)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def sweep(self, x, lb, ub):
+        """One FD sweep at ``x`` (SciPy's step rule); returns F(x) on the host."""
+        torch = self.torch
+        h = _native.fd_step(x, lb, ub)
+        self.last_step = h
+        self.d_x.copy_(torch.from_numpy(np.ascontiguousarray(x)))
+        self.d_h.copy_(torch.from_numpy(h))
+        self.engine.sweep_dev(self.d_x.data_ptr(), self.d_h.data_ptr(), 0, self.n, self.d_JT.data_ptr(),
+                              self.d_F0.data_ptr(), self.stream)
+        return self.d_F0.cpu().numpy()
+
+    @property
+    def ptr(self):
+        return self.d_JT.data_ptr()
+
+
+def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivative=None, disp=False,
+                       callback=None, iprint=1):
+    """Minimise with the engine's callbacks.  ``engine`` is a :class:`~.engine.HipEngine`;
+    ``cost_derivative(x) -> (n,)`` replaces the FD cost gradient when given.  Returns an
+    :class:`SqpResult` with SciPy's fields plus ``timing`` (seconds spent in callbacks / QP / BFGS)."""
+    n, meq, mineq = engine.n, engine.m_eq, engine.m_ineq
+    m = meq + mineq
+    lb = np.asarray(lb, dtype=float)
+    ub = np.asarray(ub, dtype=float)
+    x = np.clip(np.asarray(x0, dtype=float), lb, ub)
+    jacobian = DeviceJacobian(engine)
+    core = _sqp_native.QpCore(n, meq, mineq, device=engine.device)
+    timing = {"callbacks": 0.0, "qp": 0.0, "bfgs": 0.0, "qp_iterations": 0, "qp_solves": 0}
+    unit0 = np.zeros(m + 1)
+    unit0[0] = 1.0
+
+    last_p = [x.copy()]
+
+    def evaluate(xv):
+        t = time.perf_counter()
+        F = engine.eval_stacked(xv)
+        last_p[0] = xv.copy()
+        timing["callbacks"] += time.perf_counter() - t
+        return float(F[0]), F[1:]
+
+    def linearise(xv):
+        """Sweep at xv: JT stays on the device, the cost gradient comes back."""
+        t = time.perf_counter()
+        F = jacobian.sweep(xv, lb, ub)
+        last_p[0] = xv.copy()
+        last_p[0][-1] += jacobian.last_step[-1]          # quirk Q13: the FD loop ends on the last column
+        if cost_derivative is None:
+            grad = core.jt_times(jacobian.ptr, jacobian.ld, unit0, jacobian.stream)
+        else:
+            grad = np.asarray(cost_derivative(xv), dtype=float).reshape(n)
+        timing["callbacks"] += time.perf_counter() - t
+        return float(F[0]), F[1:], grad
+
+    def lagrangian_gradient(grad, r):
+        """v = g - A'r with A on the device."""
+        coef = np.concatenate([[0.0], -r])
+        return grad + core.jt_times(jacobian.ptr, jacobian.ld, coef, jacobian.stream)
+
+    def violation(cv):
+        return float(np.sum(np.abs(cv[:meq])) + np.sum(np.maximum(-cv[meq:], 0.0)))
+
+    acc = abs(ftol)
+    tol = 10.0 * acc
+    f, c, g = linearise(x)
+    nfev, njev = 1, 1
+    mu = np.zeros(m)
+
+    def merit_terms(cv):
+        return float(mu[:meq] @ np.abs(cv[:meq]) + mu[meq:] @ np.maximum(-cv[meq:], 0.0))
+
+    itermx = maxiter - 1
+    it = 0
+    status = None
+    badlin = False
+    f0 = f
+    s = np.zeros(n)
+    ireset = 0
+    reset = True
+    while status is None:
+        if reset:
+            ireset += 1
+            if ireset > 5:
+                ok = ((abs(f - f0) < tol or np.linalg.norm(s) < tol) and violation(c) < tol
+                      and not badlin and f == f)
+                status = 0 if ok else 8
+                break
+            core.reset()
+            reset = False
+        it += 1
+        if it > itermx:
+            status = 9
+            break
+        dl, du = lb - x, ub - x
+        t = time.perf_counter()
+        if _DEBUG:
+            print("[sqp] it %d solving, finite g %s c %s x %s" % (it, bool(np.all(np.isfinite(g))),
+                  bool(np.all(np.isfinite(c))), bool(np.all(np.isfinite(x)))), flush=True, file=sys.stderr)
+        d, r, bmult, mode, qp_it = core.solve_dev(jacobian.ptr, jacobian.ld, g, c, dl, du, False, 100.0,
+                                                  jacobian.stream)
+        timing["qp_solves"] += 1
+        timing["qp_iterations"] += qp_it
+        h4 = 1.0
+        badlin = False
+        if mode == 6 and n == meq:
+            mode = 4
+        if mode == 4:
+            badlin = True
+            rho = 100.0
+            for _ in range(6):
+                da, r, bmult, mode, qp_it = core.solve_dev(jacobian.ptr, jacobian.ld, g, c, np.append(dl, 0.0),
+                                                           np.append(du, 1.0), True, rho, jacobian.stream)
+                timing["qp_solves"] += 1
+                timing["qp_iterations"] += qp_it
+                if mode != 4:
+                    break
+                rho *= 10.0
+            if mode == 1:
+                d = da[:n]
+                h4 = 1.0 - da[n]
+                bmult = bmult[:n]
+        timing["qp"] += time.perf_counter() - t
+        if _DEBUG:
+            print("[sqp] it %d qp mode %d iterations %d badlin %s |d| %.3e finite g %s c %s" % (
+                it, mode, qp_it, badlin, float(np.max(np.abs(d))) if mode == 1 else np.nan,
+                bool(np.all(np.isfinite(g))), bool(np.all(np.isfinite(c)))), flush=True, file=sys.stderr)
+        if mode != 1:
+            status = mode
+            break
+        s = d.copy()
+        v = lagrangian_gradient(g, r)
+        f0 = f
+        x_base = x.copy()
+        gs = float(g @ s)
+        h1 = abs(gs)
+        h2 = violation(c)
+        absr = np.abs(r)
+        mu = np.maximum(absr, 0.5 * (mu + absr))
+        h1 += float(absr @ np.abs(c))
+        if h1 < acc and h2 < acc and not badlin and f == f:
+            status = 0
+            break
+        h1 = merit_terms(c)
+        t0 = f + h1
+        h3 = gs - h1 * h4
+        if h3 >= 0.0:
+            reset = True
+            continue
+        Bd = bmult - v                           # B d from the stationarity of the QP
+        alpha = 1.0
+        fraction = 1.0
+        line = 0
+        while True:
+            line += 1
+            h3 = alpha * h3
+            s = alpha * s
+            fraction *= alpha
+            x = np.clip(x_base + s, lb, ub)
+            f, c = evaluate(x)
+            nfev += 1
+            h1 = f + merit_terms(c) - t0
+            if h1 <= h3 / 10.0 or line > 10:
+                break
+            alpha = max(h3 / (2.0 * (h3 - h1)), 0.1)
+        if callback is not None:
+            callback(np.copy(x))
+        if disp and iprint >= 2:
+            print("%5i %5i % 16.6E % 16.6E" % (it, nfev, f, np.linalg.norm(g)))
+        h3 = violation(c)
+        if (abs(f - f0) < acc or np.linalg.norm(s) < acc) and h3 < acc and not badlin and f == f:
+            status = 0
+            break
+        f, c, g_new = linearise(x)
+        njev += 1
+        eta = lagrangian_gradient(g_new, r) - v
+        g = g_new
+        t = time.perf_counter()
+        if core.bfgs(s, eta, fraction * Bd):
+            reset = True
+        timing["bfgs"] += time.perf_counter() - t
+    core.close()
+    message = EXIT_MODES.get(int(status), "mode %d" % status)
+    if disp:
+        print(message + "    (Exit mode " + str(int(status)) + ")")
+        print("            Current function value:", f)
+        print("            Iterations:", it)
+        print("            Function evaluations:", nfev)
+        print("            Gradient evaluations:", njev)
+    return SqpResult(x=x, fun=f, jac=g, nit=int(it), nfev=nfev, njev=njev, status=int(status),
+                     message=message, success=(status == 0), timing=timing,
+                     last_callback_p=last_p[0])

@@ -37,7 +37,6 @@ EXIT_MODES = {0: "Optimization terminated successfully",
 
 DEPENDENT = 1e-10        # |component outside the active normals| / |normal| below this -> dependent
 FEASIBLE = 1e-12         # normalised violation below this counts as satisfied
-UNFIXABLE = 1e-7         # violation of a constraint that the null space cannot move, relative
 SINGULAR_C = 1e-13       # |R_kk| / max|R_jj| below this -> equality block rank deficient
 
 
@@ -51,8 +50,7 @@ def ldp_gi(W, b, full_norms=None, reference=None, max_iter=None):
     ``full_norms[j]`` is the length of constraint ``j``'s normal before it was projected onto the
     null space of the equalities: a row whose projection is shorter than ``DEPENDENT`` times that
     is a combination of the equalities (e.g. an inequality that repeats an equality) and cannot
-    be influenced by ``y``; it is left out, and reported as incompatible only when it is violated
-    by more than FD noise."""
+    be influenced by ``y``; it is left out."""
     mt, nr = W.shape
     y = np.zeros(nr)
     u = np.zeros(mt)
@@ -62,10 +60,6 @@ def ldp_gi(W, b, full_norms=None, reference=None, max_iter=None):
     if full_norms is None:
         full_norms = norms
     usable = norms > DEPENDENT * full_norms
-    if reference is None:
-        reference = np.abs(b)
-    if np.any(~usable & (b < -UNFIXABLE * np.maximum(1.0, reference))):
-        return y, u, 4, 0
     scale = np.where(usable, norms, 1.0)
     own = FEASIBLE * np.abs(b) / scale                      # rounding level of each row's value
     s = b.astype(float).copy()                              # constraint values W y + b

@@ -19,6 +19,7 @@
 // Reductions run in a fixed order: results are bit-reproducible from run to run.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +49,8 @@ int fail(int code, const std::string& msg) {
 
 constexpr double DEPENDENT = 1e-10;   // |projection| / |normal| below this: linearly dependent
 constexpr double FEASIBLE = 1e-12;    // rounding level of a normalised constraint value
-constexpr double SINGULAR_C = 1e-13;  // |L_kk| / max |L_jj| below this: C rank deficient
+constexpr double SINGULAR_C = 1e-14;  // |L_kk| <= this * max(1, max |L_jj|): C rank deficient to rounding
+                                      // (lsei: ABS(C(I,I)) < EPMACH -> mode 6)
 constexpr int REFINE = 3;             // at most this many re-orthogonalisation passes (one is the rule)
 constexpr double REORTH = 1e-8;       // another pass while the last correction exceeds this, relative
 constexpr int GI_THREADS = 1024;
@@ -188,45 +190,133 @@ __global__ void k_relaxation_row(const double* c, int meq, int m, double* extra)
 }
 
 // ------------------------------------------------------------------------------------------
-// Step k of the LQ sweep: Householder reflector from Tc[k][k:], applied from the right to the
-// remaining rows of Tc and to every row of Jw.  Row k itself is left as it is (nobody reads its
-// tail again); its new diagonal goes to diagL[k].
+// LQ sweep, LQ_NB Householder reflectors per trip (compact WY form, row-vector convention):
+//
+//   k_lq_panel  one workgroup: reflectors of the rows k .. k+nb-1 of Tc, each applied to the panel
+//               rows below it before the next one is formed; stores V (nb x L, L = nq - k, zero
+//               left of its diagonal), the new diagonal entries, and the upper-triangular T with
+//               H_0 H_1 ... H_{nb-1} = I - V' T V.
+//   k_lq_apply  every remaining row of Tc and every row of Jw:  row <- row - ((row V') T) V,
+//               two passes over the row whatever nb is.
+//
+// Of the panel rows only the finished entries of L (left of the diagonal) are written back:
+// nobody reads their tails again, their new diagonals live in diagL.
+constexpr int LQ_NB = 8;
 constexpr int LQ_ROWS = 8;
-__global__ __launch_bounds__(256) void k_lq_step(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
-                                                 int meq, int nq, int k, double* __restrict__ diagL) {
-    extern __shared__ double lds[];
-    double* vs = lds;
-    double* red = lds + (nq - k);
-    const int L = nq - k, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const double* src = Tc + (long)k * ld + k;
-    double part = 0.0;
-    for (int j = tid; j < L; j += 256) {
-        const double v = src[j];
-        vs[j] = v;
-        part += v * v;
-    }
-    const double sigma2 = block_sum(part, red);
-    const double x0 = vs[0];
-    const double sigma = sqrt(sigma2);
-    if (sigma == 0.0) {
-        if (blockIdx.x == 0 && tid == 0) diagL[k] = 0.0;
-        return;
-    }
-    const double alpha = x0 >= 0.0 ? -sigma : sigma;
-    const double v0 = x0 - alpha;
-    const double beta = 2.0 / (sigma2 - x0 * x0 + v0 * v0);
+
+struct LqPanel {
+    double T[LQ_NB][LQ_NB];
+    int nb;
+    int pad;
+};
+
+__global__ __launch_bounds__(1024) void k_lq_panel(double* __restrict__ Tc, int ld, int meq, int nq, int k,
+                                                   double* __restrict__ V, double* __restrict__ diagL,
+                                                   LqPanel* __restrict__ panel) {
+    __shared__ double red[16];
+    __shared__ double gram[LQ_NB][LQ_NB];
+    __shared__ double beta[LQ_NB];
+    const int tid = threadIdx.x;
+    const int nb = min(LQ_NB, meq - k), L = nq - k;
+    // working copy of the panel rows (global scratch V doubles as the work space)
+    for (int b = 0; b < nb; ++b)
+        for (int j = tid; j < L; j += 1024) V[(long)b * ld + j] = Tc[(long)(k + b) * ld + k + j];
     __syncthreads();
-    if (tid == 0) vs[0] = v0;
+    for (int b = 0; b < nb; ++b) {
+        double* vb = V + (long)b * ld;
+        double part = 0.0;
+        for (int j = b + tid; j < L; j += 1024) part += vb[j] * vb[j];
+        const double sigma2 = block_sum(part, red);
+        const double x0 = vb[b];
+        const double sigma = sqrt(sigma2);
+        const double alpha = x0 >= 0.0 ? -sigma : sigma;
+        const double v0 = x0 - alpha;
+        const double vv = sigma2 - x0 * x0 + v0 * v0;
+        const double bt = (sigma > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
+        __syncthreads();
+        if (tid == 0) {
+            vb[b] = v0;
+            beta[b] = bt;
+            diagL[k + b] = sigma > 0.0 ? alpha : 0.0;
+        }
+        for (int j = tid; j < b; j += 1024) {
+            Tc[(long)(k + b) * ld + k + j] = vb[j];   // finished entries of L left of the diagonal
+            vb[j] = 0.0;
+        }
+        __syncthreads();
+        // H_b on the panel rows below
+        for (int r = b + 1; r < nb; ++r) {
+            double* row = V + (long)r * ld;
+            double dot = 0.0;
+            for (int j = b + tid; j < L; j += 1024) dot += row[j] * vb[j];
+            const double f = bt * block_sum(dot, red);
+            for (int j = b + tid; j < L; j += 1024) row[j] -= f * vb[j];
+            __syncthreads();
+        }
+    }
+    // Gram matrix of the reflector vectors, then T by forward accumulation
+    for (int a = 0; a < nb; ++a)
+        for (int b = a + 1; b < nb; ++b) {
+            double dot = 0.0;
+            for (int j = b + tid; j < L; j += 1024) dot += V[(long)a * ld + j] * V[(long)b * ld + j];
+            const double v = block_sum(dot, red);
+            if (tid == 0) gram[a][b] = v;
+        }
     __syncthreads();
-    if (blockIdx.x == 0 && tid == 0) diagL[k] = alpha;
-    const int below = meq - k - 1, nrows = below + nq;
+    if (tid == 0) {
+        LqPanel out;
+        for (int a = 0; a < LQ_NB; ++a)
+            for (int b = 0; b < LQ_NB; ++b) out.T[a][b] = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            out.T[b][b] = beta[b];
+            for (int a = 0; a < b; ++a) {
+                double acc = 0.0;
+                for (int c = a; c < b; ++c) acc += out.T[a][c] * gram[c][b];
+                out.T[a][b] = -beta[b] * acc;
+            }
+        }
+        out.nb = nb;
+        out.pad = 0;
+        *panel = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lq_apply(double* __restrict__ Tc, double* __restrict__ Jw, int ld, int meq,
+                                                  int nq, int k, const double* __restrict__ V,
+                                                  const LqPanel* __restrict__ panel) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = panel->nb, L = nq - k;
+    const int below = meq - k - nb, nrows = below + nq;
     const int r_end = min((int)(blockIdx.x + 1) * LQ_ROWS, nrows);
     for (int r = blockIdx.x * LQ_ROWS + wave; r < r_end; r += 4) {
-        double* row = (r < below) ? Tc + (long)(k + 1 + r) * ld + k : Jw + (long)(r - below) * ld + k;
-        double dot = 0.0;
-        for (int j = lane; j < L; j += 64) dot += row[j] * vs[j];
-        const double f = beta * wave_sum(dot);
-        for (int j = lane; j < L; j += 64) row[j] -= f * vs[j];
+        double* row = (r < below) ? Tc + (long)(k + nb + r) * ld + k : Jw + (long)(r - below) * ld + k;
+        double w[LQ_NB];
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) w[b] = 0.0;
+        for (int j = lane; j < L; j += 64) {
+            const double x = row[j];
+#pragma unroll
+            for (int b = 0; b < LQ_NB; ++b)
+                if (b < nb) w[b] += x * V[(long)b * ld + j];
+        }
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) w[b] = wave_sum(w[b]);
+        double wt[LQ_NB];
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < LQ_NB; ++a)
+                if (a <= b) acc += w[a] * panel->T[a][b];
+            wt[b] = acc;
+        }
+        for (int j = lane; j < L; j += 64) {
+            double x = row[j];
+#pragma unroll
+            for (int b = 0; b < LQ_NB; ++b)
+                if (b < nb) x -= wt[b] * V[(long)b * ld + j];
+            row[j] = x;
+        }
     }
 }
 
@@ -254,7 +344,7 @@ __global__ void k_check_diag(const double* diagL, int meq, int* flag) {
             mx = fmax(mx, red[w]);
             mn = fmin(mn, red2[w]);
         }
-        flag[0] = (meq > 0 && !(mn > SINGULAR_C * fmax(mx, 1e-300))) ? 1 : 0;
+        flag[0] = (meq > 0 && !(mn > SINGULAR_C * fmax(mx, 1.0))) ? 1 : 0;
     }
 }
 
@@ -634,7 +724,7 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
         return;
     }
     const int q = st->q, cur = st->cur;
-    if (p < 0 || p >= mg + 2 * nq || q < 0 || q > nr || q >= qcap) {   // cannot happen; never index with it
+    if (p < 0 || p >= mg + 2 * nq || q < 0 || q > nr || q > qcap) {   // cannot happen; never index with it
         if (tid == 0) {
             st->phase = 3;
             st->dbg = 100 + q;
@@ -960,7 +1050,8 @@ struct og_qp_s {
     int device = 0;
     int n = 0, n1 = 0, meq = 0, mg = 0, m = 0, qcap = 0;
     hipStream_t stream = nullptr;
-    double *Z = nullptr, *Jw = nullptr, *Tc = nullptr, *GJ = nullptr, *diagL = nullptr;
+    double *Z = nullptr, *Jw = nullptr, *Tc = nullptr, *GJ = nullptr, *diagL = nullptr, *Vp = nullptr;
+    LqPanel* panel = nullptr;
     double *extra = nullptr, *g = nullptr, *c = nullptr, *dl = nullptr, *du = nullptr;
     double *w1 = nullptr, *t1 = nullptr, *xcat = nullptr, *deq = nullptr, *bG = nullptr;
     double *bval = nullptr, *scale = nullptr, *own = nullptr, *u = nullptr, *y = nullptr;
@@ -1044,7 +1135,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     int rc = 0;
     auto A = [&](auto** p, size_t cnt) { if (!rc) rc = dev_alloc(qp, p, cnt); };
     A(&qp->Z, n1 * n1); A(&qp->Jw, n1 * n1); A(&qp->Tc, (size_t)qp->meq * n1); A(&qp->GJ, (size_t)qp->mg * n1);
-    A(&qp->diagL, qp->meq); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    A(&qp->diagL, qp->meq); A(&qp->Vp, (size_t)LQ_NB * n1); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
     A(&qp->Q1t, qc * qc); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
@@ -1057,9 +1148,6 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
                                    (int)LDS_LIMIT) != hipSuccess)
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
     if (!rc && hipFuncSetAttribute((const void*)k_trsv, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)LDS_LIMIT) != hipSuccess)
-        rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
-    if (!rc && hipFuncSetAttribute((const void*)k_lq_step, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)LDS_LIMIT) != hipSuccess)
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
     if (rc) {
@@ -1152,11 +1240,13 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, n1,
                            nq, qp->Tc);
         OG_STAGE("lq sweep");
-        for (int k = 0; k < meq; ++k) {
-            const int nrows = (meq - k - 1) + nq;
-            const size_t lds = (size_t)(nq - k + 16) * sizeof(double);
-            hipLaunchKernelGGL(k_lq_step, dim3((nrows + LQ_ROWS - 1) / LQ_ROWS), dim3(256), lds, s, qp->Tc, qp->Jw, n1,
-                               meq, nq, k, qp->diagL);
+        for (int k = 0; k < meq; k += LQ_NB) {
+            const int nb = std::min(LQ_NB, meq - k);
+            const int nrows = (meq - k - nb) + nq;
+            hipLaunchKernelGGL(k_lq_panel, dim3(1), dim3(1024), 0, s, qp->Tc, n1, meq, nq, k, qp->Vp, qp->diagL,
+                               qp->panel);
+            hipLaunchKernelGGL(k_lq_apply, dim3((nrows + LQ_ROWS - 1) / LQ_ROWS), dim3(256), 0, s, qp->Tc, qp->Jw, n1,
+                               meq, nq, k, qp->Vp, qp->panel);
         }
         OG_STAGE("check diag");
         hipLaunchKernelGGL(k_check_diag, dim3(1), dim3(1024), 0, s, qp->diagL, meq, qp->flag);

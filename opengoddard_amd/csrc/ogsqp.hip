@@ -202,7 +202,6 @@ __global__ void k_relaxation_row(const double* c, int meq, int m, double* extra)
 // Of the panel rows only the finished entries of L (left of the diagonal) are written back:
 // nobody reads their tails again, their new diagonals live in diagL.
 constexpr int LQ_NB = 8;
-constexpr int LQ_ROWS = 8;
 
 struct LqPanel {
     double T[LQ_NB][LQ_NB];
@@ -210,112 +209,224 @@ struct LqPanel {
     int pad;
 };
 
-__global__ __launch_bounds__(1024) void k_lq_panel(double* __restrict__ Tc, int ld, int meq, int nq, int k,
-                                                   double* __restrict__ V, double* __restrict__ diagL,
-                                                   LqPanel* __restrict__ panel) {
-    __shared__ double red[16];
-    __shared__ double gram[LQ_NB][LQ_NB];
-    __shared__ double beta[LQ_NB];
-    const int tid = threadIdx.x;
-    const int nb = min(LQ_NB, meq - k), L = nq - k;
-    // working copy of the panel rows (global scratch V doubles as the work space)
-    for (int b = 0; b < nb; ++b)
-        for (int j = tid; j < L; j += 1024) V[(long)b * ld + j] = Tc[(long)(k + b) * ld + k + j];
+// K sums over the workgroup at once (identical in every thread); red holds (blockDim/64) * K doubles.
+template <int K>
+__device__ __forceinline__ void block_sum_vec(double (&v)[K], double* red) {
+#pragma unroll
+    for (int e = 0; e < K; ++e) v[e] = wave_sum(v[e]);
     __syncthreads();
-    for (int b = 0; b < nb; ++b) {
-        double* vb = V + (long)b * ld;
-        double part = 0.0;
-        for (int j = b + tid; j < L; j += 1024) part += vb[j] * vb[j];
-        const double sigma2 = block_sum(part, red);
-        const double x0 = vb[b];
-        const double sigma = sqrt(sigma2);
-        const double alpha = x0 >= 0.0 ? -sigma : sigma;
-        const double v0 = x0 - alpha;
-        const double vv = sigma2 - x0 * x0 + v0 * v0;
-        const double bt = (sigma > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
-        __syncthreads();
-        if (tid == 0) {
-            vb[b] = v0;
-            beta[b] = bt;
-            diagL[k + b] = sigma > 0.0 ? alpha : 0.0;
-        }
-        for (int j = tid; j < b; j += 1024) {
-            Tc[(long)(k + b) * ld + k + j] = vb[j];   // finished entries of L left of the diagonal
-            vb[j] = 0.0;
-        }
-        __syncthreads();
-        // H_b on the panel rows below
-        for (int r = b + 1; r < nb; ++r) {
-            double* row = V + (long)r * ld;
-            double dot = 0.0;
-            for (int j = b + tid; j < L; j += 1024) dot += row[j] * vb[j];
-            const double f = bt * block_sum(dot, red);
-            for (int j = b + tid; j < L; j += 1024) row[j] -= f * vb[j];
-            __syncthreads();
-        }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) red[(threadIdx.x >> 6) * K + e] = v[e];
     }
-    // Gram matrix of the reflector vectors, then T by forward accumulation
-    for (int a = 0; a < nb; ++a)
-        for (int b = a + 1; b < nb; ++b) {
-            double dot = 0.0;
-            for (int j = b + tid; j < L; j += 1024) dot += V[(long)a * ld + j] * V[(long)b * ld + j];
-            const double v = block_sum(dot, red);
-            if (tid == 0) gram[a][b] = v;
-        }
     __syncthreads();
-    if (tid == 0) {
-        LqPanel out;
-        for (int a = 0; a < LQ_NB; ++a)
-            for (int b = 0; b < LQ_NB; ++b) out.T[a][b] = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            out.T[b][b] = beta[b];
-            for (int a = 0; a < b; ++a) {
-                double acc = 0.0;
-                for (int c = a; c < b; ++c) acc += out.T[a][c] * gram[c][b];
-                out.T[a][b] = -beta[b] * acc;
-            }
-        }
-        out.nb = nb;
-        out.pad = 0;
-        *panel = out;
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+        double total = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += red[w * K + e];
+        v[e] = total;
     }
 }
 
+constexpr int LQ_PT = 512;       // threads of the panel kernel
+constexpr int LQ_CPT_MAX = 16;  // panel columns per thread: rows of up to LQ_PT * LQ_CPT_MAX entries
+
+template <int LQ_CPT>
+__global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int ld, int meq, int nq, int k,
+                                                   double* __restrict__ V, double* __restrict__ diagL,
+                                                   LqPanel* __restrict__ panel) {
+    constexpr int NPAIR = LQ_NB * (LQ_NB - 1) / 2;
+    __shared__ double red[(LQ_PT / 64) * NPAIR];
+    const int tid = threadIdx.x;
+    const int nb = min(LQ_NB, meq - k), L = nq - k;
+    // the panel lives in registers: thread t owns the columns t, t + LQ_PT, ...
+    double P[LQ_NB][LQ_CPT];
+#pragma unroll
+    for (int b = 0; b < LQ_NB; ++b)
+#pragma unroll
+        for (int e = 0; e < LQ_CPT; ++e) {
+            const int j = tid + e * LQ_PT;
+            P[b][e] = (b < nb && j < L) ? Tc[(long)(k + b) * ld + k + j] : 0.0;
+        }
+    double beta[LQ_NB];
+#pragma unroll
+    for (int b = 0; b < LQ_NB; ++b) {
+        beta[b] = 0.0;
+        if (b < nb) {
+            double one[1] = {0.0};
+#pragma unroll
+            for (int e = 0; e < LQ_CPT; ++e) {
+                const int j = tid + e * LQ_PT;
+                if (j >= b) one[0] += P[b][e] * P[b][e];
+            }
+            block_sum_vec<1>(one, red);
+            const double sigma2 = one[0];
+            // x0 = P[b][column b] lives in thread b (b < LQ_NB <= LQ_PT), slot 0
+            __shared__ double s_x0;
+            if (tid == b) s_x0 = P[b][0];
+            __syncthreads();
+            const double x0 = s_x0;
+            const double sigma = sqrt(sigma2);
+            const double alpha = x0 >= 0.0 ? -sigma : sigma;
+            const double v0 = x0 - alpha;
+            const double vv = sigma2 - x0 * x0 + v0 * v0;
+            const double bt = (sigma > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
+            beta[b] = bt;
+            if (tid == 0) diagL[k + b] = sigma > 0.0 ? alpha : 0.0;
+            // finished entries of L left of the diagonal go back to Tc; the vector is zero there
+#pragma unroll
+            for (int e = 0; e < LQ_CPT; ++e) {
+                const int j = tid + e * LQ_PT;
+                if (j < b) {
+                    Tc[(long)(k + b) * ld + k + j] = P[b][e];
+                    P[b][e] = 0.0;
+                }
+            }
+            if (tid == b) P[b][0] = v0;
+            // H_b on the panel rows below: all their projections in one reduction
+            double dots[LQ_NB];
+#pragma unroll
+            for (int r = 0; r < LQ_NB; ++r) {
+                dots[r] = 0.0;
+                if (r > b)
+#pragma unroll
+                    for (int e = 0; e < LQ_CPT; ++e) dots[r] += P[r][e] * P[b][e];
+            }
+            block_sum_vec<LQ_NB>(dots, red);
+#pragma unroll
+            for (int r = 0; r < LQ_NB; ++r)
+                if (r > b && r < nb) {
+                    const double f = bt * dots[r];
+#pragma unroll
+                    for (int e = 0; e < LQ_CPT; ++e) {
+                        const int j = tid + e * LQ_PT;
+                        if (j >= b) P[r][e] -= f * P[b][e];
+                    }
+                }
+        }
+    }
+    // Gram matrix of the reflector vectors in one reduction, then T by forward accumulation
+    double gram[NPAIR];
+    {
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < LQ_NB; ++a)
+#pragma unroll
+            for (int b = a + 1; b < LQ_NB; ++b) {
+                double acc = 0.0;
+#pragma unroll
+                for (int e = 0; e < LQ_CPT; ++e) acc += P[a][e] * P[b][e];
+                gram[idx++] = acc;
+            }
+    }
+    block_sum_vec<NPAIR>(gram, red);
+#pragma unroll
+    for (int b = 0; b < LQ_NB; ++b)
+#pragma unroll
+        for (int e = 0; e < LQ_CPT; ++e) {
+            const int j = tid + e * LQ_PT;
+            if (b < nb && j < L) V[(long)b * ld + j] = P[b][e];
+        }
+    // T in LDS (keeps the serial tail out of the register file)
+    __shared__ double s_gram[LQ_NB][LQ_NB];
+    __shared__ double s_T[LQ_NB][LQ_NB];
+    __shared__ double s_beta[LQ_NB];
+    if (tid == 0) {
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < LQ_NB; ++a)
+#pragma unroll
+            for (int b = a + 1; b < LQ_NB; ++b) s_gram[a][b] = gram[idx++];
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) s_beta[b] = beta[b];
+    }
+    __syncthreads();
+    if (tid < LQ_NB * LQ_NB) s_T[tid / LQ_NB][tid % LQ_NB] = 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int b = 0; b < nb; ++b) {
+            s_T[b][b] = s_beta[b];
+            for (int a = 0; a < b; ++a) {
+                double acc = 0.0;
+                for (int c = a; c < b; ++c) acc += s_T[a][c] * s_gram[c][b];
+                s_T[a][b] = -s_beta[b] * acc;
+            }
+        }
+        panel->nb = nb;
+        panel->pad = 0;
+    }
+    __syncthreads();
+    if (tid < LQ_NB * LQ_NB) panel->T[tid / LQ_NB][tid % LQ_NB] = s_T[tid / LQ_NB][tid % LQ_NB];
+}
+
+// One workgroup = LQ_RW rows; its four wavefronts split the columns, so every load of V serves
+// LQ_RW rows and there are enough wavefronts (rows) to fill the chip.
+constexpr int LQ_RW = 4;
 __global__ __launch_bounds__(256) void k_lq_apply(double* __restrict__ Tc, double* __restrict__ Jw, int ld, int meq,
                                                   int nq, int k, const double* __restrict__ V,
                                                   const LqPanel* __restrict__ panel) {
+    __shared__ double part[4][LQ_RW][LQ_NB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = panel->nb, L = nq - k;
     const int below = meq - k - nb, nrows = below + nq;
-    const int r_end = min((int)(blockIdx.x + 1) * LQ_ROWS, nrows);
-    for (int r = blockIdx.x * LQ_ROWS + wave; r < r_end; r += 4) {
-        double* row = (r < below) ? Tc + (long)(k + nb + r) * ld + k : Jw + (long)(r - below) * ld + k;
-        double w[LQ_NB];
+    const int r0 = blockIdx.x * LQ_RW;
+    double* rows[LQ_RW];
 #pragma unroll
-        for (int b = 0; b < LQ_NB; ++b) w[b] = 0.0;
-        for (int j = lane; j < L; j += 64) {
-            const double x = row[j];
+    for (int i = 0; i < LQ_RW; ++i) {
+        const int r = min(r0 + i, nrows - 1);            // tail: repeat the last row, masked on store
+        rows[i] = (r < below) ? Tc + (long)(k + nb + r) * ld + k : Jw + (long)(r - below) * ld + k;
+    }
+    const int valid = min(LQ_RW, nrows - r0);
+    double w[LQ_RW][LQ_NB];
 #pragma unroll
-            for (int b = 0; b < LQ_NB; ++b)
-                if (b < nb) w[b] += x * V[(long)b * ld + j];
+    for (int i = 0; i < LQ_RW; ++i)
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) w[i][b] = 0.0;
+    for (int j = tid; j < L; j += 256) {
+        double v[LQ_NB];
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) v[b] = b < nb ? V[(long)b * ld + j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < LQ_RW; ++i) {
+            const double x = rows[i][j];
+#pragma unroll
+            for (int b = 0; b < LQ_NB; ++b) w[i][b] += x * v[b];
         }
+    }
 #pragma unroll
-        for (int b = 0; b < LQ_NB; ++b) w[b] = wave_sum(w[b]);
-        double wt[LQ_NB];
+    for (int i = 0; i < LQ_RW; ++i)
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) {
+            const double t = wave_sum(w[i][b]);
+            if (lane == 0) part[wave][i][b] = t;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LQ_RW; ++i) {
+        double t[LQ_NB];
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) t[b] = (part[0][i][b] + part[1][i][b]) + (part[2][i][b] + part[3][i][b]);
 #pragma unroll
         for (int b = 0; b < LQ_NB; ++b) {
             double acc = 0.0;
 #pragma unroll
             for (int a = 0; a < LQ_NB; ++a)
-                if (a <= b) acc += w[a] * panel->T[a][b];
-            wt[b] = acc;
+                if (a <= b) acc += t[a] * panel->T[a][b];
+            w[i][b] = acc;
         }
-        for (int j = lane; j < L; j += 64) {
-            double x = row[j];
+    }
+    for (int j = tid; j < L; j += 256) {
+        double v[LQ_NB];
 #pragma unroll
-            for (int b = 0; b < LQ_NB; ++b)
-                if (b < nb) x -= wt[b] * V[(long)b * ld + j];
-            row[j] = x;
+        for (int b = 0; b < LQ_NB; ++b) v[b] = b < nb ? V[(long)b * ld + j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < LQ_RW; ++i) {
+            if (i < valid) {
+                double x = rows[i][j];
+#pragma unroll
+                for (int b = 0; b < LQ_NB; ++b) x -= w[i][b] * v[b];
+                rows[i][j] = x;
+            }
         }
     }
 }
@@ -1132,6 +1243,10 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         return fail(4, "og_qp_create: null space of the equalities too large for the LDS-resident update "
                        "(n + 1 - m_eq = " + std::to_string(qc) + ")");
     }
+    if (n1 > (size_t)LQ_PT * LQ_CPT_MAX) {
+        delete qp;
+        return fail(4, "og_qp_create: more than " + std::to_string(LQ_PT * LQ_CPT_MAX - 1) + " variables");
+    }
     int rc = 0;
     auto A = [&](auto** p, size_t cnt) { if (!rc) rc = dev_alloc(qp, p, cnt); };
     A(&qp->Z, n1 * n1); A(&qp->Jw, n1 * n1); A(&qp->Tc, (size_t)qp->meq * n1); A(&qp->GJ, (size_t)qp->mg * n1);
@@ -1243,9 +1358,17 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         for (int k = 0; k < meq; k += LQ_NB) {
             const int nb = std::min(LQ_NB, meq - k);
             const int nrows = (meq - k - nb) + nq;
-            hipLaunchKernelGGL(k_lq_panel, dim3(1), dim3(1024), 0, s, qp->Tc, n1, meq, nq, k, qp->Vp, qp->diagL,
-                               qp->panel);
-            hipLaunchKernelGGL(k_lq_apply, dim3((nrows + LQ_ROWS - 1) / LQ_ROWS), dim3(256), 0, s, qp->Tc, qp->Jw, n1,
+            const int cpt = (nq - k + LQ_PT - 1) / LQ_PT;          // registers per panel row and thread
+#define OG_PANEL(CPT)                                                                                         \
+    hipLaunchKernelGGL(k_lq_panel<CPT>, dim3(1), dim3(LQ_PT), 0, s, qp->Tc, n1, meq, nq, k, qp->Vp, qp->diagL, \
+                       qp->panel)
+            if (cpt <= 1) OG_PANEL(1);
+            else if (cpt <= 2) OG_PANEL(2);
+            else if (cpt <= 4) OG_PANEL(4);
+            else if (cpt <= 8) OG_PANEL(8);
+            else OG_PANEL(LQ_CPT_MAX);
+#undef OG_PANEL
+            hipLaunchKernelGGL(k_lq_apply, dim3((nrows + LQ_RW - 1) / LQ_RW), dim3(256), 0, s, qp->Tc, qp->Jw, n1,
                                meq, nq, k, qp->Vp, qp->panel);
         }
         OG_STAGE("check diag");

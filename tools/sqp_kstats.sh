@@ -13,5 +13,7 @@ import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:14]:
-    print("%-34s calls %7s total %9.2f ms avg %9.2f us  %5.1f%%"%(r["Name"].split("(")[0].split("::")[-1][:34], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e3, 100*float(r["TotalDurationNs"])/tot))
+    import re
+    nm=re.search(r"(k_\w+|ogk_\w+|__amd\w+)", r["Name"]); nm=nm.group(1) if nm else r["Name"][:34]
+    print("%-22s calls %7s total %9.2f ms avg %9.2f us  %5.1f%%"%(nm[:22], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e3, 100*float(r["TotalDurationNs"])/tot))
 PY

@@ -506,15 +506,38 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
         if (!transposed) {
             for (int r = i0 + bs + tid; r < meq; r += 1024) {
                 const double* row = Tc + (long)r * ld + i0;
-                double acc = 0.0;
-                for (int c = 0; c < bs; ++c) acc += row[c] * xs[i0 + c];
-                xs[r] -= acc;
+                double acc0 = 0.0, acc1 = 0.0;
+                int c = 0;
+                for (; c + 16 <= bs; c += 16) {          // 16 independent loads in flight
+                    double l[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) l[e] = row[c + e];
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        acc0 += l[e] * xs[i0 + c + e];
+                        acc1 += l[e + 1] * xs[i0 + c + e + 1];
+                    }
+                }
+                for (; c < bs; ++c) acc0 += row[c] * xs[i0 + c];
+                xs[r] -= acc0 + acc1;
             }
         } else {
             for (int r = tid; r < i0; r += 1024) {
-                double acc = 0.0;
-                for (int c = 0; c < bs; ++c) acc += Tc[(long)(i0 + c) * ld + r] * xs[i0 + c];
-                xs[r] -= acc;
+                const double* col = Tc + (long)i0 * ld + r;
+                double acc0 = 0.0, acc1 = 0.0;
+                int c = 0;
+                for (; c + 16 <= bs; c += 16) {
+                    double l[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) l[e] = col[(long)(c + e) * ld];
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        acc0 += l[e] * xs[i0 + c + e];
+                        acc1 += l[e + 1] * xs[i0 + c + e + 1];
+                    }
+                }
+                for (; c < bs; ++c) acc0 += col[(long)c * ld] * xs[i0 + c];
+                xs[r] -= acc0 + acc1;
             }
         }
         __syncthreads();

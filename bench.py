@@ -92,6 +92,26 @@ def measured_traffic(workload):
     return best
 
 
+def sqp_leg(eng, prob, iterations):
+    """Second BASELINE metric, "wall-clock to SLSQP convergence", on a bounded sample: the first
+    ``iterations`` major iterations of ``Problem.solve`` with the QP subproblems on the GPU
+    (``sqp_core="hip"``), split into callbacks / QP / BFGS.  The same iterations with SciPy's Fortran
+    core take 8 s each at n = 1442 (profiles/r01_solve_timing.jsonl), which is why they are not
+    re-timed in every bench run."""
+    import numpy as np
+    from opengoddard_amd import sqp
+    lb = np.array([-np.inf if b[0] is None else b[0] for b in prob.bounds], dtype=float)
+    ub = np.array([np.inf if b[1] is None else b[1] for b in prob.bounds], dtype=float)
+    t0 = time.perf_counter()
+    res = sqp.minimize_slsqp_hip(eng, prob.p.copy(), lb, ub, ftol=1e-6, maxiter=iterations + 1)
+    wall = time.perf_counter() - t0
+    t = res.timing
+    return {"core": "hip (include/ogsqp.h)", "major_iterations": int(res.nit - 1 if res.status == 9 else res.nit),
+            "exit_mode": int(res.status), "wall_s": wall, "callbacks_s": t["callbacks"], "qp_s": t["qp"],
+            "bfgs_s": t["bfgs"], "qp_solves": t["qp_solves"], "active_set_iterations": t["qp_iterations"],
+            "ms_per_major_iteration": 1e3 * wall / max(1, res.nit - 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +122,8 @@ def main():
                     help="comma-separated LGL node counts per phase (size studies; default: the "
                          "workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sqp-iterations", type=int, default=10,
+                    help="major iterations of the SQP leg (0 = skip); skipped above n = 3000")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (plumbing test)")
@@ -252,6 +274,8 @@ def main():
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if world == 1 and rank == 0 and a.sqp_iterations > 0 and n <= 3000:
+        result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if collective and rank == 0:

@@ -366,3 +366,22 @@ def test_solve_with_hip_core_converges_like_scipy_core(capsys):
     assert abs(ours.fun - ref.fun) <= 1e-6
     assert np.max(np.abs(results["hip"][1] - results["scipy"][1])) <= 1e-3
     assert abs(ours.fun - 1.7724562) <= 2e-5                        # the golden optimum of example 01
+
+
+@pytest.mark.gpu
+def test_goddard_converges_with_both_cores(capsys):
+    """C2 with the FD cost gradient taken from the device-resident Jacobian (og_jt_times): both cores
+    stop with exit mode 0 at the same optimum (ftol 1e-10; the paths differ after a few iterations
+    because the FD Jacobian amplifies rounding differences, the optimum does not)."""
+    found = {}
+    for core in ("scipy", "hip"):
+        prob, obj = problems.build("goddard")
+        prob.maxIterator = 1
+        prob.solve(obj, maxiter=600, ftol=1e-10, sqp_core=core)
+        found[core] = prob.last_result
+    capsys.readouterr()
+    assert found["scipy"].status == 0 and found["hip"].status == 0
+    assert abs(found["hip"].fun - found["scipy"].fun) <= 5e-6
+    assert abs(found["hip"].fun + 1.01283) <= 2e-5                   # final altitude 1.01283 (example 04)
+    timing = found["hip"].timing
+    assert timing["qp_solves"] >= found["hip"].nit - 1 and timing["qp"] > 0.0

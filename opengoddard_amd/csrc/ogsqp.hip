@@ -253,19 +253,27 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
     for (int b = 0; b < LQ_NB; ++b) {
         beta[b] = 0.0;
         if (b < nb) {
-            double one[1] = {0.0};
+            // one reduction per reflector: |row b|^2 and the raw products of the rows below with row b;
+            // column b of the panel (owned by thread b) is passed through LDS alongside
+            __shared__ double s_col[LQ_NB];
+            double vals[LQ_NB];
 #pragma unroll
-            for (int e = 0; e < LQ_CPT; ++e) {
-                const int j = tid + e * LQ_PT;
-                if (j >= b) one[0] += P[b][e] * P[b][e];
+            for (int r = 0; r < LQ_NB; ++r) {
+                vals[r] = 0.0;
+                if (r >= b)
+#pragma unroll
+                    for (int e = 0; e < LQ_CPT; ++e) {
+                        const int j = tid + e * LQ_PT;
+                        if (j >= b) vals[r] += P[r][e] * P[b][e];
+                    }
             }
-            block_sum_vec<1>(one, red);
-            const double sigma2 = one[0];
-            // x0 = P[b][column b] lives in thread b (b < LQ_NB <= LQ_PT), slot 0
-            __shared__ double s_x0;
-            if (tid == b) s_x0 = P[b][0];
-            __syncthreads();
-            const double x0 = s_x0;
+            if (tid == b) {
+#pragma unroll
+                for (int r = 0; r < LQ_NB; ++r) s_col[r] = P[r][0];
+            }
+            block_sum_vec<LQ_NB>(vals, red);
+            const double sigma2 = vals[b];
+            const double x0 = s_col[b];
             const double sigma = sqrt(sigma2);
             const double alpha = x0 >= 0.0 ? -sigma : sigma;
             const double v0 = x0 - alpha;
@@ -283,26 +291,18 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
                 }
             }
             if (tid == b) P[b][0] = v0;
-            // H_b on the panel rows below: all their projections in one reduction
-            double dots[LQ_NB];
-#pragma unroll
-            for (int r = 0; r < LQ_NB; ++r) {
-                dots[r] = 0.0;
-                if (r > b)
-#pragma unroll
-                    for (int e = 0; e < LQ_CPT; ++e) dots[r] += P[r][e] * P[b][e];
-            }
-            block_sum_vec<LQ_NB>(dots, red);
+            // H_b on the panel rows below:  row . v_b = (row . row_b) - row[b] alpha
 #pragma unroll
             for (int r = 0; r < LQ_NB; ++r)
                 if (r > b && r < nb) {
-                    const double f = bt * dots[r];
+                    const double f = bt * (vals[r] - s_col[r] * alpha);
 #pragma unroll
                     for (int e = 0; e < LQ_CPT; ++e) {
                         const int j = tid + e * LQ_PT;
                         if (j >= b) P[r][e] -= f * P[b][e];
                     }
                 }
+            __syncthreads();                      // s_col is rewritten by the next reflector
         }
     }
     // Gram matrix of the reflector vectors in one reduction, then T by forward accumulation

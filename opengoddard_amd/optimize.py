@@ -444,6 +444,7 @@ class Problem:
                                               cost_derivative=user_gradient, disp=True)
                 self.p = opt.last_callback_p
                 self.sqp_timing = opt.timing
+                self.sqp_timings = getattr(self, "sqp_timings", []) + [opt.timing]
             else:
                 opt = _sciopt.minimize(value_of(0), self.p, args=(self, obj), bounds=self.bounds,
                                        constraints=cons, jac=cost_jac, method="SLSQP",

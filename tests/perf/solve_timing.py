@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--engine", default="hip", choices=["hip", "oracle"])
     ap.add_argument("--max-restarts", type=int, default=None)
     ap.add_argument("--ftol", type=float, default=None)
+    ap.add_argument("--maxiter", type=int, default=None)
+    ap.add_argument("--sqp-core", default="scipy", choices=["scipy", "hip"],
+                    help="hip: QP subproblems on the GPU (include/ogsqp.h); needs --engine hip")
     a = ap.parse_args()
     prob, obj = problems.build(a.workload)
     if a.max_restarts is not None:
@@ -53,15 +56,32 @@ def main():
         holder["e"] = Timed(inner)
         return holder["e"]
 
-    og.ENGINE_FACTORY = factory
+    if a.sqp_core == "scipy":
+        og.ENGINE_FACTORY = factory
     opts = {"ftol": a.ftol} if a.ftol is not None else ({"ftol": 1e-10} if a.workload == "goddard" else {})
+    if a.maxiter is not None:
+        opts["maxiter"] = a.maxiter
+    opts["sqp_core"] = a.sqp_core
     buf = io.StringIO()
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(buf):
         prob.solve(obj, **opts)
     wall = time.perf_counter() - t0
-    e = holder["e"]
     out = buf.getvalue()
+    if a.sqp_core == "hip":
+        tm = prob.sqp_timings
+        cb = sum(t["callbacks"] for t in tm)
+        print(json.dumps({"workload": a.workload, "engine": "hip", "sqp_core": "hip",
+                          "n": int(prob.number_of_variables), "wall_s": wall, "t_callbacks_s": cb,
+                          "t_qp_s": sum(t["qp"] for t in tm), "t_bfgs_s": sum(t["bfgs"] for t in tm),
+                          "qp_solves": sum(t["qp_solves"] for t in tm),
+                          "active_set_iterations": sum(t["qp_iterations"] for t in tm),
+                          "t_driver_and_python_s": wall - cb - sum(t["qp"] + t["bfgs"] for t in tm),
+                          "major_iterations": int(prob.last_result.nit), "exit_mode": int(prob.last_result.status),
+                          "restarts": out.count("---- iteration"), "converged": "successfully" in out,
+                          "cost": float(prob.last_result.fun)}))
+        return
+    e = holder["e"]
     print(json.dumps({"workload": a.workload, "engine": a.engine, "n": int(prob.number_of_variables),
                       "wall_s": wall, "t_callbacks_s": e.t_values + e.t_jac,
                       "t_values_s": e.t_values, "t_jacobians_s": e.t_jac,

@@ -72,10 +72,28 @@ __device__ __forceinline__ double aval(const AView& A, int i, int j) {
     return i < A.n ? A.jt[(long)i * A.ld + 1 + j] : A.extra[j];
 }
 
+// Cross-lane moves through DPP (4-cycle VALU modifiers) instead of __shfl_xor, which is a pair of
+// ds_bpermute round trips through the LDS crossbar per 64-bit value (measured: 7 us for eight
+// sums in k_lq_panel).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double lane_f64(double x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane),
+                            __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+
+// Sum over the wavefront, the same value in every lane; fixed order.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x124>(v);   // row_ror 4
+    v += dpp_f64<0x128>(v);   // row_ror 8   -> every lane holds the total of its row of 16
+    return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
 }
 
 // Sum over the workgroup, identical in every thread; `red` holds blockDim/64 doubles.
@@ -207,6 +225,7 @@ struct LqPanel {
     double T[LQ_NB][LQ_NB];
     int nb;
     int pad;
+    long long tr[8];   // OGSQP_TRACE: s_memtime ticks per section of the last panel kernel
 };
 
 // K sums over the workgroup at once (identical in every thread); red holds (blockDim/64) * K doubles.
@@ -238,6 +257,13 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
     constexpr int NPAIR = LQ_NB * (LQ_NB - 1) / 2;
     __shared__ double red[(LQ_PT / 64) * NPAIR];
     const int tid = threadIdx.x;
+#ifdef OGSQP_TRACE
+    long long t_mark = __builtin_amdgcn_s_memtime();
+    long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PMARK(slot) do { const long long now_ = __builtin_amdgcn_s_memtime(); t_sec[slot] += now_ - t_mark; t_mark = now_; } while (0)
+#else
+#define PMARK(slot) do { } while (0)
+#endif
     const int nb = min(LQ_NB, meq - k), L = nq - k;
     // the panel lives in registers: thread t owns the columns t, t + LQ_PT, ...
     double P[LQ_NB][LQ_CPT];
@@ -248,6 +274,8 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
             const int j = tid + e * LQ_PT;
             P[b][e] = (b < nb && j < L) ? Tc[(long)(k + b) * ld + k + j] : 0.0;
         }
+    __syncthreads();
+    PMARK(0);   // load
     double beta[LQ_NB];
 #pragma unroll
     for (int b = 0; b < LQ_NB; ++b) {
@@ -271,7 +299,9 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
 #pragma unroll
                 for (int r = 0; r < LQ_NB; ++r) s_col[r] = P[r][0];
             }
+            PMARK(1);   // products
             block_sum_vec<LQ_NB>(vals, red);
+            PMARK(2);   // reduction
             const double sigma2 = vals[b];
             const double x0 = s_col[b];
             const double sigma = sqrt(sigma2);
@@ -303,6 +333,7 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
                     }
                 }
             __syncthreads();                      // s_col is rewritten by the next reflector
+            PMARK(3);   // update
         }
     }
     // Gram matrix of the reflector vectors in one reduction, then T by forward accumulation
@@ -319,7 +350,9 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
                 gram[idx++] = acc;
             }
     }
+    PMARK(4);   // gram products
     block_sum_vec<NPAIR>(gram, red);
+    PMARK(5);   // gram reduction
 #pragma unroll
     for (int b = 0; b < LQ_NB; ++b)
 #pragma unroll
@@ -357,6 +390,12 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
     }
     __syncthreads();
     if (tid < LQ_NB * LQ_NB) panel->T[tid / LQ_NB][tid % LQ_NB] = s_T[tid / LQ_NB][tid % LQ_NB];
+    PMARK(6);   // store V, T
+#ifdef OGSQP_TRACE
+    if (tid == 0)
+        for (int e = 0; e < 8; ++e) panel->tr[e] = t_sec[e];
+#endif
+#undef PMARK
 }
 
 // One workgroup = LQ_RW rows; its four wavefronts split the columns, so every load of V serves
@@ -1394,6 +1433,15 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
             hipLaunchKernelGGL(k_lq_apply, dim3((nrows + LQ_RW - 1) / LQ_RW), dim3(256), 0, s, qp->Tc, qp->Jw, n1,
                                meq, nq, k, qp->Vp, qp->panel);
         }
+#ifdef OGSQP_TRACE
+        {
+            LqPanel hp;
+            OG_HIP(hipMemcpyAsync(&hp, qp->panel, sizeof(LqPanel), hipMemcpyDeviceToHost, s));
+            OG_HIP(hipStreamSynchronize(s));
+            fprintf(stderr, "[ogsqp trace] last panel kernel ticks: load %lld products %lld reduction %lld update %lld gram %lld gram-red %lld store %lld\n",
+                    hp.tr[0], hp.tr[1], hp.tr[2], hp.tr[3], hp.tr[4], hp.tr[5], hp.tr[6]);
+        }
+#endif
         OG_STAGE("check diag");
         hipLaunchKernelGGL(k_check_diag, dim3(1), dim3(1024), 0, s, qp->diagL, meq, qp->flag);
     }

@@ -284,16 +284,20 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
             // one reduction per reflector: |row b|^2 and the raw products of the rows below with row b;
             // column b of the panel (owned by thread b) is passed through LDS alongside
             __shared__ double s_col[LQ_NB];
+            // entries of row b left of its diagonal are finished entries of L: back to Tc, and zero
+            // in the register copy, so that neither the products nor the updates below need a
+            // column predicate (the reflector vector is zero there)
+            if (tid < b) {
+                Tc[(long)(k + b) * ld + k + tid] = P[b][0];
+                P[b][0] = 0.0;
+            }
             double vals[LQ_NB];
 #pragma unroll
             for (int r = 0; r < LQ_NB; ++r) {
                 vals[r] = 0.0;
                 if (r >= b)
 #pragma unroll
-                    for (int e = 0; e < LQ_CPT; ++e) {
-                        const int j = tid + e * LQ_PT;
-                        if (j >= b) vals[r] += P[r][e] * P[b][e];
-                    }
+                    for (int e = 0; e < LQ_CPT; ++e) vals[r] += P[r][e] * P[b][e];
             }
             if (tid == b) {
 #pragma unroll
@@ -311,15 +315,6 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
             const double bt = (sigma > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
             beta[b] = bt;
             if (tid == 0) diagL[k + b] = sigma > 0.0 ? alpha : 0.0;
-            // finished entries of L left of the diagonal go back to Tc; the vector is zero there
-#pragma unroll
-            for (int e = 0; e < LQ_CPT; ++e) {
-                const int j = tid + e * LQ_PT;
-                if (j < b) {
-                    Tc[(long)(k + b) * ld + k + j] = P[b][e];
-                    P[b][e] = 0.0;
-                }
-            }
             if (tid == b) P[b][0] = v0;
             // H_b on the panel rows below:  row . v_b = (row . row_b) - row[b] alpha
 #pragma unroll
@@ -327,10 +322,7 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
                 if (r > b && r < nb) {
                     const double f = bt * (vals[r] - s_col[r] * alpha);
 #pragma unroll
-                    for (int e = 0; e < LQ_CPT; ++e) {
-                        const int j = tid + e * LQ_PT;
-                        if (j >= b) P[r][e] -= f * P[b][e];
-                    }
+                    for (int e = 0; e < LQ_CPT; ++e) P[r][e] -= f * P[b][e];
                 }
             __syncthreads();                      // s_col is rewritten by the next reflector
             PMARK(3);   // update

@@ -385,3 +385,43 @@ def test_goddard_converges_with_both_cores(capsys):
     assert abs(found["hip"].fun + 1.01283) <= 2e-5                   # final altitude 1.01283 (example 04)
     timing = found["hip"].timing
     assert timing["qp_solves"] >= found["hip"].nit - 1 and timing["qp"] > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,tol", [("brachistochrone", 1e-5),      # v(0) = 0: cond(C) = 3e10 at the initial guess
+                                      ("goddard", 1e-8), ("polar_tsto_shipped", 1e-8),
+                                      ("low_thrust_shipped", 1e-8), ("table_ascent", 1e-8)])
+def test_gpu_first_subproblem_of_every_small_configuration(name, tol):
+    """The first QP subproblem (B = I) of each small configuration, on the Jacobian the sweep kernel
+    produces: same exit mode as the restatement; same step and multipliers where it is solvable, the
+    relaxed problem (rho = 100) where the linearisation is inconsistent.  These Jacobians contain
+    what random matrices do not: inequality rows that repeat equalities, zero rows, bounds that
+    coincide with path constraints."""
+    from opengoddard_amd.engine import HipEngine
+    prob, obj = problems.build(name)
+    eng = HipEngine(prob, obj)
+    lb, ub = np_path.bounds_arrays(prob)
+    x = np.clip(prob.p, lb, ub)
+    F0, JT = eng.sweep_stacked(x, _native.fd_step(x, lb, ub))
+    n, meq = eng.n, eng.m_eq
+    g, A, c = JT[:, 0].copy(), JT[:, 1:].T.copy(), F0[1:]
+    ref = slsqp_np.qp_solve(np.eye(n), g, A[:meq], c[:meq], A[meq:], c[meq:], lb - x, ub - x)
+    core = _sqp_native.QpCore(n, meq, eng.m_ineq)
+    d, mult, bm, status, iters = core.solve(A, g, c, lb - x, ub - x)
+    assert status == ref[3]
+    if status != 1:
+        assert status == 4
+        Za = np.eye(n + 1)
+        Za[n, n] = 1.0 / 100.0
+        extra = np.concatenate([-c[:meq], np.maximum(-c[meq:], 0.0)])
+        Aa = np.hstack([A, extra[:, None]])
+        lo, hi = np.append(lb - x, 0.0), np.append(ub - x, 1.0)
+        ref = slsqp_np.qp_solve(Za, np.append(g, 0.0), Aa[:meq], c[:meq], Aa[meq:], c[meq:], lo, hi)
+        d, mult, bm, status, iters = core.solve(A, g, c, lo, hi, True, 100.0)
+        assert status == ref[3] == 1
+    scale = max(1.0, np.abs(ref[0]).max())
+    assert np.max(np.abs(d - ref[0])) <= tol * scale
+    mscale = max(1.0, np.abs(ref[1]).max(initial=0.0), np.abs(ref[2]).max(initial=0.0))
+    assert np.max(np.abs(mult - np.concatenate([ref[1], ref[2]]))) <= 100 * tol * mscale
+    core.close()
+    eng.close()

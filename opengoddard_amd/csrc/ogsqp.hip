@@ -247,10 +247,16 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[K], double* red) {
     }
 }
 
-constexpr int LQ_PT = 512;       // threads of the panel kernel
-constexpr int LQ_CPT_MAX = 16;  // panel columns per thread: rows of up to LQ_PT * LQ_CPT_MAX entries
+#ifndef OGSQP_PANEL_SMALL_PT
+#define OGSQP_PANEL_SMALL_PT 128
+#endif
+constexpr int PANEL_SMALL_PT = OGSQP_PANEL_SMALL_PT;   // threads of the panel kernel for rows that fit their registers
+constexpr int LQ_PT_MAX = 512;   // threads of the panel kernel for long rows
+constexpr int LQ_CPT_MAX = 16;   // panel columns per thread: rows of up to LQ_PT_MAX * LQ_CPT_MAX entries
 
-template <int LQ_CPT>
+// Few threads with many columns each keep the reductions cheap (fewer wavefronts to combine) as long
+// as the panel fits in their registers; long rows need the full 512 threads.
+template <int LQ_PT, int LQ_CPT>
 __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int ld, int meq, int nq, int k,
                                                    double* __restrict__ V, double* __restrict__ diagL,
                                                    LqPanel* __restrict__ panel) {
@@ -276,6 +282,8 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
         }
     __syncthreads();
     PMARK(0);   // load
+    __shared__ double s_lower[LQ_NB][LQ_NB];
+    __shared__ double s_diag[LQ_NB];
     double beta[LQ_NB];
 #pragma unroll
     for (int b = 0; b < LQ_NB; ++b) {
@@ -287,8 +295,10 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
             // entries of row b left of its diagonal are finished entries of L: back to Tc, and zero
             // in the register copy, so that neither the products nor the updates below need a
             // column predicate (the reflector vector is zero there)
+            // (kept in LDS until the end: a global store here would make every barrier below wait
+            // for its acknowledgement)
             if (tid < b) {
-                Tc[(long)(k + b) * ld + k + tid] = P[b][0];
+                s_lower[b][tid] = P[b][0];
                 P[b][0] = 0.0;
             }
             double vals[LQ_NB];
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
             const double vv = sigma2 - x0 * x0 + v0 * v0;
             const double bt = (sigma > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
             beta[b] = bt;
-            if (tid == 0) diagL[k + b] = sigma > 0.0 ? alpha : 0.0;
+            if (tid == 0) s_diag[b] = sigma > 0.0 ? alpha : 0.0;
             if (tid == b) P[b][0] = v0;
             // H_b on the panel rows below:  row . v_b = (row . row_b) - row[b] alpha
 #pragma unroll
@@ -328,8 +338,11 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
             PMARK(3);   // update
         }
     }
-    // Gram matrix of the reflector vectors in one reduction, then T by forward accumulation
-    double gram[NPAIR];
+    // Gram matrix of the reflector vectors: per-thread products, 16-lane sums by DPP, then the
+    // (LQ_PT / 16) partial sums of every pair are added by one thread per pair out of LDS
+    __shared__ double s_part[NPAIR][LQ_PT / 16 + 1];
+    __shared__ double s_gram[LQ_NB][LQ_NB];
+    __shared__ double s_T[LQ_NB][LQ_NB];
     {
         int idx = 0;
 #pragma unroll
@@ -339,11 +352,29 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
                 double acc = 0.0;
 #pragma unroll
                 for (int e = 0; e < LQ_CPT; ++e) acc += P[a][e] * P[b][e];
-                gram[idx++] = acc;
+                acc += dpp_f64<0xB1>(acc);
+                acc += dpp_f64<0x4E>(acc);
+                acc += dpp_f64<0x124>(acc);
+                acc += dpp_f64<0x128>(acc);
+                if ((tid & 15) == 0) s_part[idx][tid >> 4] = acc;
+                ++idx;
             }
     }
     PMARK(4);   // gram products
-    block_sum_vec<NPAIR>(gram, red);
+    __syncthreads();
+    if (tid < NPAIR) {
+        double total = 0.0;
+        for (int w = 0; w < LQ_PT / 16; ++w) total += s_part[tid][w];
+        // pair index -> (a, b), a < b
+        int a = 0, rem = tid;
+        while (rem >= LQ_NB - 1 - a) {
+            rem -= LQ_NB - 1 - a;
+            ++a;
+        }
+        s_gram[a][a + 1 + rem] = total;
+    }
+    if (tid < LQ_NB * LQ_NB) s_T[tid / LQ_NB][tid % LQ_NB] = 0.0;
+    __syncthreads();
     PMARK(5);   // gram reduction
 #pragma unroll
     for (int b = 0; b < LQ_NB; ++b)
@@ -352,36 +383,31 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
             const int j = tid + e * LQ_PT;
             if (b < nb && j < L) V[(long)b * ld + j] = P[b][e];
         }
-    // T in LDS (keeps the serial tail out of the register file)
-    __shared__ double s_gram[LQ_NB][LQ_NB];
-    __shared__ double s_T[LQ_NB][LQ_NB];
+    // T by forward accumulation; row a of T depends only on itself: thread a does row a
     __shared__ double s_beta[LQ_NB];
     if (tid == 0) {
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < LQ_NB; ++a)
-#pragma unroll
-            for (int b = a + 1; b < LQ_NB; ++b) s_gram[a][b] = gram[idx++];
 #pragma unroll
         for (int b = 0; b < LQ_NB; ++b) s_beta[b] = beta[b];
-    }
-    __syncthreads();
-    if (tid < LQ_NB * LQ_NB) s_T[tid / LQ_NB][tid % LQ_NB] = 0.0;
-    __syncthreads();
-    if (tid == 0) {
-        for (int b = 0; b < nb; ++b) {
-            s_T[b][b] = s_beta[b];
-            for (int a = 0; a < b; ++a) {
-                double acc = 0.0;
-                for (int c = a; c < b; ++c) acc += s_T[a][c] * s_gram[c][b];
-                s_T[a][b] = -s_beta[b] * acc;
-            }
-        }
         panel->nb = nb;
         panel->pad = 0;
     }
     __syncthreads();
-    if (tid < LQ_NB * LQ_NB) panel->T[tid / LQ_NB][tid % LQ_NB] = s_T[tid / LQ_NB][tid % LQ_NB];
+    if (tid < nb) {
+        const int a = tid;
+        s_T[a][a] = s_beta[a];
+        for (int b = a + 1; b < nb; ++b) {
+            double acc = 0.0;
+            for (int c = a; c < b; ++c) acc += s_T[a][c] * s_gram[c][b];
+            s_T[a][b] = -s_beta[b] * acc;
+        }
+    }
+    __syncthreads();
+    if (tid < LQ_NB * LQ_NB) {
+        const int a = tid / LQ_NB, b = tid % LQ_NB;
+        panel->T[a][b] = s_T[a][b];
+        if (a < nb && b < a) Tc[(long)(k + a) * ld + k + b] = s_lower[a][b];   // finished entries of L
+        if (a < nb && b == 0) diagL[k + a] = s_diag[a];
+    }
     PMARK(6);   // store V, T
 #ifdef OGSQP_TRACE
     if (tid == 0)
@@ -1297,9 +1323,9 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         return fail(4, "og_qp_create: null space of the equalities too large for the LDS-resident update "
                        "(n + 1 - m_eq = " + std::to_string(qc) + ")");
     }
-    if (n1 > (size_t)LQ_PT * LQ_CPT_MAX) {
+    if (n1 > (size_t)LQ_PT_MAX * LQ_CPT_MAX) {
         delete qp;
-        return fail(4, "og_qp_create: more than " + std::to_string(LQ_PT * LQ_CPT_MAX - 1) + " variables");
+        return fail(4, "og_qp_create: more than " + std::to_string(LQ_PT_MAX * LQ_CPT_MAX - 1) + " variables");
     }
     int rc = 0;
     auto A = [&](auto** p, size_t cnt) { if (!rc) rc = dev_alloc(qp, p, cnt); };
@@ -1412,15 +1438,25 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         for (int k = 0; k < meq; k += LQ_NB) {
             const int nb = std::min(LQ_NB, meq - k);
             const int nrows = (meq - k - nb) + nq;
-            const int cpt = (nq - k + LQ_PT - 1) / LQ_PT;          // registers per panel row and thread
-#define OG_PANEL(CPT)                                                                                         \
-    hipLaunchKernelGGL(k_lq_panel<CPT>, dim3(1), dim3(LQ_PT), 0, s, qp->Tc, n1, meq, nq, k, qp->Vp, qp->diagL, \
+            const int len = nq - k;                                // length of the panel rows
+#define OG_PANEL(PT, CPT)                                                                                      \
+    hipLaunchKernelGGL((k_lq_panel<PT, CPT>), dim3(1), dim3(PT), 0, s, qp->Tc, n1, meq, nq, k, qp->Vp, qp->diagL, \
                        qp->panel)
-            if (cpt <= 1) OG_PANEL(1);
-            else if (cpt <= 2) OG_PANEL(2);
-            else if (cpt <= 4) OG_PANEL(4);
-            else if (cpt <= 8) OG_PANEL(8);
-            else OG_PANEL(LQ_CPT_MAX);
+            if (len <= PANEL_SMALL_PT * 4) OG_PANEL(PANEL_SMALL_PT, 4);
+            else if (len <= PANEL_SMALL_PT * 8) OG_PANEL(PANEL_SMALL_PT, 8);
+            else if (len <= PANEL_SMALL_PT * 12) OG_PANEL(PANEL_SMALL_PT, 12);
+            else if (len <= LQ_PT_MAX * 4) OG_PANEL(LQ_PT_MAX, 4);
+            else if (len <= LQ_PT_MAX * 8) OG_PANEL(LQ_PT_MAX, 8);
+            else OG_PANEL(LQ_PT_MAX, LQ_CPT_MAX);
+#ifdef OGSQP_TRACE
+            if (k == 0) {
+                LqPanel hp;
+                OG_HIP(hipMemcpyAsync(&hp, qp->panel, sizeof(LqPanel), hipMemcpyDeviceToHost, s));
+                OG_HIP(hipStreamSynchronize(s));
+                fprintf(stderr, "[ogsqp trace] first panel kernel (len %d) ticks: load %lld products %lld reduction %lld update %lld gram %lld gram-red %lld store %lld\n",
+                        len, hp.tr[0], hp.tr[1], hp.tr[2], hp.tr[3], hp.tr[4], hp.tr[5], hp.tr[6]);
+            }
+#endif
 #undef OG_PANEL
             hipLaunchKernelGGL(k_lq_apply, dim3((nrows + LQ_RW - 1) / LQ_RW), dim3(256), 0, s, qp->Tc, qp->Jw, n1,
                                meq, nq, k, qp->Vp, qp->panel);

@@ -488,6 +488,70 @@ __global__ __launch_bounds__(256) void k_lq_apply(double* __restrict__ Tc, doubl
     }
 }
 
+// Same with the row segments and the reflector vectors held in registers between the two passes
+// (rows of up to 256 * JT entries): one trip to memory instead of two.
+template <int JT>
+__global__ __launch_bounds__(256) void k_lq_apply_reg(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
+                                                      int meq, int nq, int k, const double* __restrict__ V,
+                                                      const LqPanel* __restrict__ panel) {
+    __shared__ double part[4][LQ_RW][LQ_NB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = panel->nb, L = nq - k;
+    const int below = meq - k - nb, nrows = below + nq;
+    const int r0 = blockIdx.x * LQ_RW;
+    double* rows[LQ_RW];
+#pragma unroll
+    for (int i = 0; i < LQ_RW; ++i) {
+        const int r = min(r0 + i, nrows - 1);
+        rows[i] = (r < below) ? Tc + (long)(k + nb + r) * ld + k : Jw + (long)(r - below) * ld + k;
+    }
+    const int valid = min(LQ_RW, nrows - r0);
+    double x[LQ_RW][JT], v[LQ_NB][JT];
+#pragma unroll
+    for (int t = 0; t < JT; ++t) {
+        const int j = tid + t * 256;
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) v[b][t] = (b < nb && j < L) ? V[(long)b * ld + j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < LQ_RW; ++i) x[i][t] = j < L ? rows[i][j] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < LQ_RW; ++i)
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < JT; ++t) acc += x[i][t] * v[b][t];
+            acc = wave_sum(acc);
+            if (lane == 0) part[wave][i][b] = acc;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LQ_RW; ++i) {
+        double t8[LQ_NB], wt[LQ_NB];
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) t8[b] = (part[0][i][b] + part[1][i][b]) + (part[2][i][b] + part[3][i][b]);
+#pragma unroll
+        for (int b = 0; b < LQ_NB; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < LQ_NB; ++a)
+                if (a <= b) acc += t8[a] * panel->T[a][b];
+            wt[b] = acc;
+        }
+        if (i < valid) {
+#pragma unroll
+            for (int t = 0; t < JT; ++t) {
+                const int j = tid + t * 256;
+                double xv = x[i][t];
+#pragma unroll
+                for (int b = 0; b < LQ_NB; ++b) xv -= wt[b] * v[b][t];
+                if (j < L) rows[i][j] = xv;
+            }
+        }
+    }
+}
+
 // max |diag| / min |diag| test of the triangular factor -> flag[0] = 1 when singular
 __global__ void k_check_diag(const double* diagL, int meq, int* flag) {
     __shared__ double red[16];
@@ -1458,8 +1522,17 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
             }
 #endif
 #undef OG_PANEL
-            hipLaunchKernelGGL(k_lq_apply, dim3((nrows + LQ_RW - 1) / LQ_RW), dim3(256), 0, s, qp->Tc, qp->Jw, n1,
-                               meq, nq, k, qp->Vp, qp->panel);
+            {
+                const dim3 grid((nrows + LQ_RW - 1) / LQ_RW);
+                const int jt = (len + 255) / 256;
+#define OG_APPLY(KERNEL) \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, qp->Tc, qp->Jw, n1, meq, nq, k, qp->Vp, qp->panel)
+                if (jt <= 2) OG_APPLY(k_lq_apply_reg<2>);
+                else if (jt <= 4) OG_APPLY(k_lq_apply_reg<4>);
+                else if (jt <= 6) OG_APPLY(k_lq_apply_reg<6>);
+                else OG_APPLY(k_lq_apply);
+#undef OG_APPLY
+            }
         }
 #ifdef OGSQP_TRACE
         {

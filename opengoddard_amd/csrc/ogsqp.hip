@@ -219,7 +219,10 @@ __global__ void k_relaxation_row(const double* c, int meq, int m, double* extra)
 //
 // Of the panel rows only the finished entries of L (left of the diagonal) are written back:
 // nobody reads their tails again, their new diagonals live in diagL.
-constexpr int LQ_NB = 8;
+#ifndef OGSQP_LQ_NB
+#define OGSQP_LQ_NB 8
+#endif
+constexpr int LQ_NB = OGSQP_LQ_NB;   // reflectors per panel
 
 struct LqPanel {
     double T[LQ_NB][LQ_NB];
@@ -362,18 +365,18 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
     }
     PMARK(4);   // gram products
     __syncthreads();
-    if (tid < NPAIR) {
+    for (int pair = tid; pair < NPAIR; pair += LQ_PT) {
         double total = 0.0;
-        for (int w = 0; w < LQ_PT / 16; ++w) total += s_part[tid][w];
+        for (int w = 0; w < LQ_PT / 16; ++w) total += s_part[pair][w];
         // pair index -> (a, b), a < b
-        int a = 0, rem = tid;
+        int a = 0, rem = pair;
         while (rem >= LQ_NB - 1 - a) {
             rem -= LQ_NB - 1 - a;
             ++a;
         }
         s_gram[a][a + 1 + rem] = total;
     }
-    if (tid < LQ_NB * LQ_NB) s_T[tid / LQ_NB][tid % LQ_NB] = 0.0;
+    for (int e = tid; e < LQ_NB * LQ_NB; e += LQ_PT) s_T[e / LQ_NB][e % LQ_NB] = 0.0;
     __syncthreads();
     PMARK(5);   // gram reduction
 #pragma unroll
@@ -402,8 +405,8 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
         }
     }
     __syncthreads();
-    if (tid < LQ_NB * LQ_NB) {
-        const int a = tid / LQ_NB, b = tid % LQ_NB;
+    for (int e = tid; e < LQ_NB * LQ_NB; e += LQ_PT) {
+        const int a = e / LQ_NB, b = e % LQ_NB;
         panel->T[a][b] = s_T[a][b];
         if (a < nb && b < a) Tc[(long)(k + a) * ld + k + b] = s_lower[a][b];   // finished entries of L
         if (a < nb && b == 0) diagL[k + a] = s_diag[a];

@@ -92,7 +92,7 @@ def measured_traffic(workload):
     return best
 
 
-def sqp_leg(eng, prob, iterations):
+def sqp_leg(eng, prob, iterations, reference_iterations=0):
     """Second BASELINE metric, "wall-clock to SLSQP convergence", on a bounded sample: the first
     ``iterations`` major iterations of ``Problem.solve`` with the QP subproblems on the GPU
     (``sqp_core="hip"``), split into callbacks / QP / BFGS.  The same iterations with SciPy's Fortran
@@ -106,6 +106,41 @@ def sqp_leg(eng, prob, iterations):
     res = sqp.minimize_slsqp_hip(eng, prob.p.copy(), lb, ub, ftol=1e-6, maxiter=iterations + 1)
     wall = time.perf_counter() - t0
     t = res.timing
+    out = _sqp_result(res, wall, t, iterations)
+    if reference_iterations > 0:
+        out["scipy_core"] = scipy_core_sample(eng, prob, lb, ub, reference_iterations)
+        out["speedup_per_major_iteration"] = (out["scipy_core"]["ms_per_major_iteration"] /
+                                              out["ms_per_major_iteration"])
+    return out
+
+
+def scipy_core_sample(eng, prob, lb, ub, iterations):
+    """The same solve with SciPy's Fortran SLSQP core (GPU callbacks and Jacobians, as
+    Problem.solve(sqp_core="scipy") runs it), for ``iterations`` major iterations: the measured
+    baseline of the SQP leg on this machine."""
+    import numpy as np
+    from scipy import optimize
+    import warnings
+
+    def fun(which):
+        return lambda p: eng.values(p)[which]
+
+    def jac(which):
+        return lambda p: eng.jacobians(p, lb, ub)[0][which]
+
+    cons = ({"type": "eq", "fun": fun(1), "jac": jac(1)}, {"type": "ineq", "fun": fun(2), "jac": jac(2)})
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = optimize.minimize(fun(0), prob.p.copy(), jac=jac(0), bounds=list(zip(lb, ub)), constraints=cons,
+                                method="SLSQP", options={"maxiter": iterations + 1, "ftol": 1e-6})
+    wall = time.perf_counter() - t0
+    done = max(1, int(res.nit) - 1)
+    return {"core": "scipy %s _slsqp (Fortran)" % __import__("scipy").__version__, "major_iterations": done,
+            "wall_s": wall, "ms_per_major_iteration": 1e3 * wall / done}
+
+
+def _sqp_result(res, wall, t, iterations):
     return {"core": "hip (include/ogsqp.h)", "major_iterations": int(res.nit - 1 if res.status == 9 else res.nit),
             "exit_mode": int(res.status), "wall_s": wall, "callbacks_s": t["callbacks"], "qp_s": t["qp"],
             "bfgs_s": t["bfgs"], "qp_solves": t["qp_solves"], "active_set_iterations": t["qp_iterations"],
@@ -124,6 +159,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sqp-iterations", type=int, default=10,
                     help="major iterations of the SQP leg (0 = skip); skipped above n = 3000")
+    ap.add_argument("--sqp-reference-iterations", type=int, default=2,
+                    help="major iterations of the same solve with SciPy's Fortran core, timed next to the SQP "
+                         "leg (0 = skip; about 8 s each at n = 1442); skipped above n = 1600")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (plumbing test)")
@@ -275,7 +313,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if world == 1 and rank == 0 and a.sqp_iterations > 0 and n <= 3000:
-        result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations)
+        result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations,
+                                a.sqp_reference_iterations if n <= 1600 else 0)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if collective and rank == 0:

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 p=$1; it=$2; tag=${3:-sqp_$p}
 out=/tmp/sqpk_$tag
-( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python $R/tools/dev/g_solve.py $p $it 1e-6 hip > $out.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python $R/tools/sqp_solve.py $p $it 1e-6 hip > $out.log 2>&1 )
 grep -v amdgpu.ids $out.log | tail -3
 f=$(ls $out/*kernel_stats.csv 2>/dev/null | head -1)
 mkdir -p $R/gpurun_out

@@ -1,5 +1,8 @@
-import sys, time, io, contextlib
-sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
+"""usage: python tools/sqp_solve.py <problem> <maxiter> <ftol> <core[,core]>   (cores: scipy, hip)
+One Problem.solve per core with maxIterator = 1; prints status, counts, objective, wall time and the
+SQP core's own timing split.  Used by tools/sqp_kstats.sh."""
+import contextlib, io, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from opengoddard_amd import problems
 name = sys.argv[1]; maxiter = int(sys.argv[2]); ftol = float(sys.argv[3]); cores = sys.argv[4].split(',')

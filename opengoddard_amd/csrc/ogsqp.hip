@@ -1261,6 +1261,620 @@ __global__ __launch_bounds__(GI_THREADS) void k_gi_iter(GiArgs g) {
     TRACE_MARK(8);   // removal
 }
 
+// ------------------------------------------------------------------------------------------
+// The same active-set method spread over G workgroups (cooperative launch, resident for the whole
+// LDP).  One CU streams the orthonormal basis at ~50 GB/s, which is what bounds k_gi_iter; here every
+// workgroup owns a slice of `width` null-space coordinates - its columns of Q1, its part of the
+// incoming normal, of z and of y - plus the rows of R^-1 whose storage slot is congruent to it, and a
+// share of the pricing.  What has to be global (the projections Q1'n, |z|^2, the election of the
+// incoming and of the leaving row) goes through small per-workgroup partial vectors in HBM and a
+// grid barrier; the O(q) book-keeping (active list, slot map, free list) is replicated, every
+// workgroup executing the same deterministic updates.  Only the Givens chain on R of a removal is
+// serial (workgroup 0); the rotations are then applied by everybody to their own slices.
+constexpr int COOP_THREADS = 512;   // 256 VGPRs per thread: the batched loads below need them
+constexpr int COOP_WAVES = COOP_THREADS / 64;
+
+struct CoopPartial {
+    double metric;
+    int index;
+    int k;
+    double ratio;
+    double pad;
+};
+
+struct CoopArgs {
+    GiArgs g;
+    int G, width, astride;
+    double* Q1s;        // G x qcap x width
+    double* RIr;        // qcap slots x qcap, row-major: row slot[i] = row i of the upper-triangular R^-1
+    double* apart;      // G x astride: [a_0 .. a_{q-1} | nn, sp, zz, yy]
+    double* uact;       // multipliers of the active rows, logical order
+    double* cs;         // rotations of a removal
+    CoopPartial* cpart; // G
+    unsigned* bar;      // barrier counter
+    int* abort_flag;
+};
+
+constexpr long COOP_SPIN_LIMIT = 200L * 1000 * 1000;
+
+// Barrier over the cooperative grid: monotone counter, bounded spin (a lost workgroup aborts the
+// solve instead of hanging the GPU).
+__device__ __forceinline__ bool grid_barrier(const CoopArgs& c, unsigned& epoch) {
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++epoch;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // my workgroup's stores leave this XCD's L2
+        __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * (unsigned)c.G;
+        long spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > COOP_SPIN_LIMIT ||
+                ((spins & 1023) == 0 && __hip_atomic_load(c.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(c.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // and the others' become visible here
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// Everything the workgroups of k_gi_coop tell each other goes through agent-scope (write-through /
+// L2-bypassing) loads and stores, and the grid barrier carries no fence: an acquire fence would
+// invalidate this XCD's whole L2 and with it the workgroup's private slice of Q1 and rows of R^-1,
+// which is exactly what has to stay close.
+__device__ __forceinline__ double ld_shared(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_shared(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_shared(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_shared(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Slice kernels of k_gi_coop.  `width` is 16 or 64: with 16 coordinates per workgroup a wavefront
+// works on four rows of the slice at a time (one per 16-lane DPP row), with 64 on one.
+__device__ __forceinline__ double row16_sum(double v) {       // sum over each aligned group of 16 lanes
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x124>(v);
+    v += dpp_f64<0x128>(v);
+    return v;
+}
+
+// out[j] = Q1s[j][:] . vec  for j < q  (my columns only)
+__device__ __forceinline__ void slice_project(const double* __restrict__ Q1s, int width, int cw, int q,
+                                              const double* vec, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (width == 16) {
+        const int grp = lane >> 4, col = lane & 15;
+        const double x = col < cw ? vec[col] : 0.0;
+        for (int j0 = wave * 4; j0 < q; j0 += COOP_WAVES * 4) {
+            const int j = j0 + grp;
+            double v = (j < q && col < cw) ? Q1s[(long)j * 16 + col] * x : 0.0;
+            v = row16_sum(v);
+            if (col == 0 && j < q) st_shared(out + j, v);
+        }
+    } else {
+        const double x = lane < cw ? vec[lane] : 0.0;
+        for (int j = wave; j < q; j += COOP_WAVES) {
+            double v = lane < cw ? Q1s[(long)j * width + lane] * x : 0.0;
+            v = wave_sum(v);
+            if (lane == 0) st_shared(out + j, v);
+        }
+    }
+}
+
+// zsl[i] = base[i] - sum_j coef[j] Q1s[j][i]  on my columns; `scratch` holds COOP_THREADS doubles
+__device__ __forceinline__ void slice_subtract(const double* __restrict__ Q1s, int width, int cw, int q,
+                                               const double* coef, const double* base, double* zsl,
+                                               double* scratch) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc = 0.0;
+    if (width == 16) {
+        const int grp = lane >> 4, col = lane & 15;
+        if (col < cw)
+            for (int j = wave * 4 + grp; j < q; j += COOP_WAVES * 4) acc += coef[j] * Q1s[(long)j * 16 + col];
+        scratch[(wave * 4 + grp) * 16 + col] = acc;       // 64 partial sums per column
+        __syncthreads();
+        if (tid < 16) {
+            double sum = 0.0;
+            for (int part = 0; part < COOP_WAVES * 4; ++part) sum += scratch[part * 16 + tid];
+            zsl[tid] = tid < cw ? base[tid] - sum : 0.0;
+        }
+    } else {
+        if (lane < cw)
+            for (int j = wave; j < q; j += COOP_WAVES) acc += coef[j] * Q1s[(long)j * width + lane];
+        scratch[wave * 64 + lane] = acc;
+        __syncthreads();
+        if (tid < 64) {
+            double sum = 0.0;
+            for (int part = 0; part < COOP_WAVES; ++part) sum += scratch[part * 64 + tid];
+            zsl[tid] = tid < cw ? base[tid] - sum : 0.0;
+        }
+    }
+    __syncthreads();
+}
+
+// sum over the G workgroups of entry j of their partial vectors, eight loads in flight
+__device__ __forceinline__ double sum_partials(const double* __restrict__ apart, int astride, int G, int j) {
+    // 32 loads issued before the first is consumed: one memory round trip per 32 workgroups, fixed order
+    double acc = 0.0;
+    for (int b0 = 0; b0 < G; b0 += 32) {
+        double l[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) l[e] = b0 + e < G ? ld_shared(apart + (long)(b0 + e) * astride + j) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) acc += l[e];
+    }
+    return acc;
+}
+
+// Entries j < q of the summed partial vectors into vec[], the scalar slots (qcap + 0 .. 3) into sc[]:
+// one pass, every entry by its own thread.
+__device__ __forceinline__ void gather_partials(const double* __restrict__ apart, int astride, int G, int q, int qcap,
+                                                double* vec, double* sc) {
+    for (int j = threadIdx.x; j < q + 4; j += COOP_THREADS) {
+        const int idx = j < q ? j : qcap + (j - q);
+        const double v = sum_partials(apart, astride, G, idx);
+        if (j < q)
+            vec[j] = v;
+        else
+            sc[j - q] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
+    extern __shared__ double lds[];
+    __shared__ double redv[COOP_WAVES];
+    __shared__ int redi[COOP_WAVES];
+    __shared__ double red[COOP_WAVES];
+    __shared__ double scal[4];
+    const GiArgs& g = c.g;
+    GiState* st = g.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x, G = c.G, width = c.width;
+    const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
+    const int c0 = w * width;
+    const int cw = max(0, min(width, nr - c0));          // my null-space coordinates: c0 .. c0+cw-1
+    // LDS: replicated vectors and book-keeping
+    double* av = lds;                   // accumulated projections (new column of R)
+    double* a2 = av + qcap;             // projections of the current pass / rotations of a removal (2 qcap)
+    double* carried = a2 + 2 * qcap;    // workgroup 0: row carried down the Givens chain; diag copy behind it
+    double* diagc = carried + qcap;
+    double* ysl = diagc + qcap;         // slices: y, incoming normal, z
+    double* nsl = ysl + width;
+    double* zsl = nsl + width;
+    double* yfull = zsl + width;        // all of y, refreshed for every pricing
+    double* scratch = yfull + nr;       // COOP_THREADS partial sums of the slice kernels
+    int* act = (int*)(scratch + COOP_THREADS);   // active rows, logical order
+    int* slot = act + qcap;             // storage slot of every active row (rows of RIr)
+    int* freel = slot + qcap;           // free slots, a stack
+    double* Q1s = c.Q1s + (long)w * qcap * width;
+    double* mypart = c.apart + (long)w * c.astride;
+
+#ifdef OGSQP_TRACE
+    long long t_mark = __builtin_amdgcn_s_memtime();
+    long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define CMARK(slot) do { const long long now_ = __builtin_amdgcn_s_memtime(); t_acc[slot] += now_ - t_mark; t_mark = now_; } while (0)
+#else
+#define CMARK(slot) do { } while (0)
+#endif
+    unsigned epoch = 0;
+    int q = 0, iters = 0, cur = 0, nfree = qcap, phase = st->phase;
+    double ynorm = 0.0;
+    for (int i = tid; i < qcap; i += COOP_THREADS) freel[i] = qcap - 1 - i;      // pop order 0, 1, 2, ...
+    for (int i = tid; i < width; i += COOP_THREADS) ysl[i] = 0.0;
+    __syncthreads();
+    if (phase >= 2) return;
+
+    for (;;) {
+        // ---- pricing: my share of the rows at the current y ------------------------------------
+        int p;
+        {
+            const double slack = FEASIBLE * ynorm;
+            double best = INFINITY;
+            int besti = 0x7fffffff;
+            for (int i = tid; i < nr; i += COOP_THREADS) yfull[i] = ld_shared(g.y + i);
+            __syncthreads();
+            // my rows in groups of PG: the row data and the per-row constants of a whole group are
+            // requested together, so a group costs one memory round trip, not one per row and field
+            constexpr int PG = 4;
+            const int rstride = G * COOP_WAVES;
+            for (int r0 = (w * COOP_WAVES) + wave; r0 < mg + nq; r0 += PG * rstride) {
+                double dots[PG], sc_lo[PG], sc_hi[PG], bv_lo[PG], bv_hi[PG], ow_lo[PG], ow_hi[PG];
+                int ia_lo[PG], ia_hi[PG];
+#pragma unroll
+                for (int e = 0; e < PG; ++e) {
+                    const int r = r0 + e * rstride;
+                    const bool live = r < mg + nq;
+                    const int lo = live ? r : 0, hi = (live && r >= mg) ? r + nq : lo;
+                    sc_lo[e] = live ? g.scale[lo] : 0.0;
+                    bv_lo[e] = g.bval[lo];
+                    ow_lo[e] = g.own[lo];
+                    ia_lo[e] = ld_shared(g.isact + lo);
+                    sc_hi[e] = (live && r >= mg) ? g.scale[hi] : 0.0;
+                    bv_hi[e] = g.bval[hi];
+                    ow_hi[e] = g.own[hi];
+                    ia_hi[e] = ld_shared(g.isact + hi);
+                    dots[e] = 0.0;
+                }
+                if (nr <= 512) {
+                    double x[PG][8];
+#pragma unroll
+                    for (int e = 0; e < PG; ++e) {
+                        const int r = min(r0 + e * rstride, mg + nq - 1);
+                        const double* row = (r < mg ? g.GJ + (long)r * g.ld : g.Jw + (long)(r - mg) * g.ld) + g.meq;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int k = lane + 64 * t;
+                            x[e][t] = k < nr ? row[k] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < PG; ++e)
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int k = lane + 64 * t;
+                            if (k < nr) dots[e] += x[e][t] * yfull[k];
+                        }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < PG; ++e) {
+                        const int r = min(r0 + e * rstride, mg + nq - 1);
+                        const double* row = (r < mg ? g.GJ + (long)r * g.ld : g.Jw + (long)(r - mg) * g.ld) + g.meq;
+                        double acc = 0.0;
+                        int k = lane;
+                        for (; k + 64 * 15 < nr; k += 64 * 16) {
+                            double l[16];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) l[t] = row[k + 64 * t];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) acc += l[t] * yfull[k + 64 * t];
+                        }
+                        for (; k < nr; k += 64) acc += row[k] * yfull[k];
+                        dots[e] = acc;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < PG; ++e) {
+                    const int r = r0 + e * rstride;
+                    const double dot = wave_sum(dots[e]);
+                    if (r >= mg + nq) continue;
+                    if (sc_lo[e] > 0.0 && !ia_lo[e]) {
+                        const double v = (bv_lo[e] + dot) / sc_lo[e] + ow_lo[e] + slack;
+                        if (v < best || (v == best && r < besti)) {
+                            best = v;
+                            besti = r;
+                        }
+                    }
+                    if (r >= mg && sc_hi[e] > 0.0 && !ia_hi[e]) {
+                        const double v = (bv_hi[e] - dot) / sc_hi[e] + ow_hi[e] + slack;
+                        if (v < best || (v == best && r + nq < besti)) {
+                            best = v;
+                            besti = r + nq;
+                        }
+                    }
+                }
+            }
+            block_argmin(best, besti, redv, redi);
+            if (tid == 0) {
+                st_shared(&c.cpart[w].metric, best);
+                st_shared(&c.cpart[w].index, besti);
+            }
+            CMARK(0);   // pricing
+            if (!grid_barrier(c, epoch)) return;
+            CMARK(1);   // barrier 1
+            double v = INFINITY;
+            int idx = 0x7fffffff;
+            if (tid < G) {                          // one partial per thread, then the usual reduction:
+                v = ld_shared(&c.cpart[tid].metric);            // the same answer in every workgroup
+                idx = ld_shared(&c.cpart[tid].index);
+            }
+            block_argmin(v, idx, redv, redi);
+            if (!(v < 0.0)) {
+                phase = 2;
+                break;
+            }
+            p = idx;
+        }
+        double up = 0.0;
+        bool leave = false;
+        // ---- steps with p until it joins the active set ------------------------------------------
+        for (;;) {
+            ++iters;
+            if (iters > g.limit || q > nr || q > qcap) {
+                phase = 3;
+                leave = true;
+                break;
+            }
+            double psign;
+            const double* prow = stack_row(g, p, psign) + c0;
+            // my slice of the normal; partial projections on my columns of Q1, |n|^2 and n.y
+            if (tid < width) nsl[tid] = tid < cw ? psign * prow[tid] : 0.0;
+            __syncthreads();
+            slice_project(Q1s, width, cw, q, nsl, mypart);
+            {
+                double pn = 0.0, py = 0.0;
+                if (tid < cw) {
+                    pn = nsl[tid] * nsl[tid];
+                    py = nsl[tid] * ysl[tid];
+                }
+                pn = block_sum(pn, red);
+                py = block_sum(py, red);
+                if (tid == 0) {
+                    st_shared(mypart + qcap, pn);
+                    st_shared(mypart + qcap + 1, py);
+                }
+            }
+            CMARK(2);   // projections 1
+            if (!grid_barrier(c, epoch)) return;
+            CMARK(3);   // barrier 2
+            gather_partials(c.apart, c.astride, G, q, qcap, av, scal);
+            const double nn = scal[0];
+            const double sp = g.bval[p] + scal[1];
+            // z = n - Q1 a on my coordinates, then the second Gram-Schmidt pass's partial projections
+            slice_subtract(Q1s, width, cw, q, av, nsl, zsl, scratch);
+            CMARK(4);   // gather a, z1
+            if (!grid_barrier(c, epoch)) return;         // everybody has read the first-pass partials
+            CMARK(5);   // barrier 2b
+            slice_project(Q1s, width, cw, q, zsl, mypart);
+            {
+                double pz = tid < cw ? zsl[tid] * zsl[tid] : 0.0;
+                pz = block_sum(pz, red);
+                if (tid == 0) st_shared(mypart + qcap + 2, pz);
+            }
+            CMARK(6);   // projections 2
+            if (!grid_barrier(c, epoch)) return;
+            CMARK(7);   // barrier 3
+            gather_partials(c.apart, c.astride, G, q, qcap, a2, scal);
+            double zz = scal[2];
+            double corr_part = 0.0;
+            for (int j = tid; j < q; j += COOP_THREADS) {
+                const double acc = a2[j];
+                av[j] += acc;
+                corr_part += acc * acc;
+            }
+            const double corr = block_sum(corr_part, red);
+            zz = fmax(zz - corr, 0.0);                    // |z - Q1 a2|^2 = |z|^2 - |a2|^2
+            slice_subtract(Q1s, width, cw, q, a2, zsl, zsl, scratch);
+            const bool dependent = (q >= nr) || !(zz > (DEPENDENT * DEPENDENT) * nn);
+            // dual direction on my rows of R^-1, candidates of the ratio test
+            double t1 = INFINITY;
+            int kdrop = 0x7fffffff;
+            for (int i = wave; i < q; i += COOP_WAVES) {
+                if (slot[i] % G != w) continue;
+                const double* row = c.RIr + (long)slot[i] * qcap;
+                double dot = 0.0;
+                for (int j = i + lane; j < q; j += 64) dot += row[j] * av[j];
+                dot = wave_sum(dot);
+                if (lane == 0) {
+                    a2[qcap + i] = dot;                   // my r_i, kept for the updates below
+                    if (dot > 0.0) {
+                        const double cand = ld_shared(c.uact + i) / dot;
+                        if (cand < t1 || (cand == t1 && i < kdrop)) {
+                            t1 = cand;
+                            kdrop = i;
+                        }
+                    }
+                }
+            }
+            if (lane != 0) {
+                t1 = INFINITY;
+                kdrop = 0x7fffffff;
+            }
+            block_argmin(t1, kdrop, redv, redi);
+            if (tid == 0) {
+                st_shared(&c.cpart[w].ratio, t1);
+                st_shared(&c.cpart[w].k, kdrop);
+            }
+            CMARK(8);   // gather a2, z2, dual direction
+            if (!grid_barrier(c, epoch)) return;
+            CMARK(9);   // barrier 4
+            t1 = INFINITY;
+            kdrop = 0x7fffffff;
+            if (tid < G) {
+                t1 = ld_shared(&c.cpart[tid].ratio);
+                kdrop = ld_shared(&c.cpart[tid].k);
+            }
+            block_argmin(t1, kdrop, redv, redi);
+            const double t2 = dependent ? INFINITY : -sp / zz;
+            const double t = fmin(t1, t2);
+            if (!(t < INFINITY)) {
+                phase = 4;
+                leave = true;
+                break;
+            }
+            // multipliers of my rows, my part of y
+            for (int i = wave; i < q; i += COOP_WAVES)
+                if (slot[i] % G == w && lane == 0) st_shared(c.uact + i, ld_shared(c.uact + i) - t * a2[qcap + i]);
+            up += t;
+            double pyy = 0.0;
+            if (tid < cw) {
+                double yi = ysl[tid];
+                if (!dependent) {
+                    yi += t * zsl[tid];
+                    ysl[tid] = yi;
+                    st_shared(g.y + c0 + tid, yi);
+                }
+                pyy = yi * yi;
+            }
+            pyy = block_sum(pyy, red);
+            if (tid == 0) st_shared(mypart + qcap + 3, pyy);
+            const bool full_step = (t2 < INFINITY) && (t2 <= t1);
+            if (full_step) {
+                // p joins: Q1 gets z/|z| (my columns), R the column [a; |z|] (workgroup 0), R^-1 the
+                // column [-r/|z|; 1/|z|] (row owners), in the first free slot
+                const double delta = sqrt(zz), inv = 1.0 / delta;
+                const int sl = freel[nfree - 1];
+                if (tid < cw) Q1s[(long)q * width + tid] = zsl[tid] * inv;
+                for (int i = wave; i < q; i += COOP_WAVES)
+                    if (slot[i] % G == w && lane == 0) c.RIr[(long)slot[i] * qcap + q] = -a2[qcap + i] * inv;
+                if (sl % G == w && tid == 0) c.RIr[(long)sl * qcap + q] = inv;
+                if (w == 0) {
+                    double* R = g.R[cur];
+                    for (int i = tid; i < q; i += COOP_THREADS) R[(long)q * qcap + i] = av[i];
+                    if (tid == 0) {
+                        R[(long)q * qcap + q] = delta;
+                        st_shared(c.uact + q, up);
+                        st_shared(g.isact + p, 1);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    act[q] = p;
+                    slot[q] = sl;
+                }
+                --nfree;
+                ++q;
+                CMARK(10);  // updates, append
+                if (!grid_barrier(c, epoch)) return;     // y, isact, uact visible before the next pricing
+                CMARK(11);  // barrier 5
+                ynorm = sqrt(sum_partials(c.apart, c.astride, G, qcap + 3));
+                break;
+            }
+            // ---- partial step: active row k leaves --------------------------------------------------
+            const int k = kdrop;
+            if (w == 0) {
+                double* R = g.R[cur];
+                double* Rn = g.R[cur ^ 1];
+                for (int cc = wave; cc < q; cc += COOP_WAVES) {
+                    if (cc == k) continue;
+                    const int cn = cc < k ? cc : cc - 1;
+                    const int top = cc < k ? cc + 1 : k;
+                    for (int i = lane; i < top; i += 64) Rn[(long)cn * qcap + i] = R[(long)cc * qcap + i];
+                }
+                for (int cc = k + 1 + tid; cc < q; cc += COOP_THREADS) {
+                    carried[cc] = R[(long)cc * qcap + k];
+                    diagc[cc] = R[(long)cc * qcap + cc];
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    for (int j = k; j < q - 1; ++j) {
+                        const int cp = j + 1;
+                        const double a = ((volatile double*)carried)[cp];
+                        const double b = diagc[cp];
+                        const double hyp = sqrt(a * a + b * b);
+                        const double co = hyp > 0.0 ? a / hyp : 1.0;
+                        const double si = hyp > 0.0 ? b / hyp : 0.0;
+                        if (lane == 0) {
+                            st_shared(c.cs + 2 * j, co);
+                            st_shared(c.cs + 2 * j + 1, si);
+                            Rn[(long)j * qcap + j] = hyp;
+                        }
+                        int cc = cp + 1 + ((lane - (cp + 1)) % 64 + 64) % 64;
+                        for (; cc < q; cc += 64) {
+                            const double x = carried[cc], yv = R[(long)cc * qcap + j + 1];
+                            Rn[(long)(cc - 1) * qcap + j] = co * x + si * yv;
+                            carried[cc] = -si * x + co * yv;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_s_waitcnt(0);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    st_shared(g.isact + act[k], 0);
+                }
+            }
+            if (!grid_barrier(c, epoch)) return;         // rotations published
+            double* cs = a2;                              // (the second-pass projections are spent)
+            const double my_r_k = 0.0;
+            (void)my_r_k;
+            for (int j = k + tid; j < q - 1; j += COOP_THREADS) {
+                cs[2 * j] = ld_shared(c.cs + 2 * j);
+                cs[2 * j + 1] = ld_shared(c.cs + 2 * j + 1);
+            }
+            __syncthreads();
+            // my columns of Q1: rotate rows k .. q-1, the last one drops out
+            if (tid < cw) {
+                double* col = Q1s + tid;
+                double x = col[(long)k * width];
+                for (int j = k; j < q - 1; ++j) {
+                    const double yv = col[(long)(j + 1) * width];
+                    const double co = cs[2 * j], si = cs[2 * j + 1];
+                    col[(long)j * width] = co * x + si * yv;
+                    x = -si * x + co * yv;
+                }
+            }
+            // my rows of R^-1: the same rotations on their columns, shifted left by one
+            for (int i = wave; i < q; i += COOP_WAVES) {
+                if (i == k || slot[i] % G != w || lane != 0) continue;
+                double* row = c.RIr + (long)slot[i] * qcap;
+                double x = i < k ? row[k] : 0.0;
+                for (int j = (i - 1 > k ? i - 1 : k); j < q - 1; ++j) {
+                    const double yv = row[j + 1];
+                    const double co = cs[2 * j], si = cs[2 * j + 1];
+                    row[j] = co * x + si * yv;
+                    x = -si * x + co * yv;
+                }
+            }
+            // multipliers shift (their owners wrote them before the last barrier)
+            __syncthreads();
+            if (w == 0) {
+                double keep = 0.0;
+                for (int base = k; base < q - 1; base += COOP_THREADS) {
+                    const int j = base + tid;
+                    if (j < q - 1) keep = ld_shared(c.uact + j + 1);
+                    __syncthreads();
+                    if (j < q - 1) st_shared(c.uact + j, keep);
+                    __syncthreads();
+                }
+            }
+            // replicated book-keeping
+            {
+                const int freed = slot[k];
+                int a_keep = 0, s_keep = 0;
+                for (int base = k; base < q - 1; base += COOP_THREADS) {
+                    const int j = base + tid;
+                    if (j < q - 1) {
+                        a_keep = act[j + 1];
+                        s_keep = slot[j + 1];
+                    }
+                    __syncthreads();
+                    if (j < q - 1) {
+                        act[j] = a_keep;
+                        slot[j] = s_keep;
+                    }
+                    __syncthreads();
+                }
+                if (tid == 0) freel[nfree] = freed;
+                ++nfree;
+                --q;
+                cur ^= 1;
+                __syncthreads();
+            }
+        }
+        if (leave) break;
+    }
+    // ---- results: multipliers back to the per-constraint array, state for the host ------------------
+    if (!grid_barrier(c, epoch)) return;
+    if (w == 0) {
+        for (int j = tid; j < q; j += COOP_THREADS) g.u[act[j]] = ld_shared(c.uact + j);
+        if (tid == 0) {
+            st->phase = phase;
+            st->q = q;
+            st->iters = iters;
+            st->cur = cur;
+            st->ynorm = ynorm;
+#ifdef OGSQP_TRACE
+            for (int e = 0; e < 12; ++e) st->tr[e] = t_acc[e];
+#endif
+        }
+    }
+#undef CMARK
+}
+
 // d = clip(deq + Y y), multipliers of the general inequalities and of the bounds
 __global__ __launch_bounds__(256) void k_finish_step(const double* __restrict__ Jw, int ld, int meq, int nq, int nr,
                                                      int mg, const double* __restrict__ y, const double* __restrict__ deq,
@@ -1314,6 +1928,11 @@ struct og_qp_s {
     double *w1 = nullptr, *t1 = nullptr, *xcat = nullptr, *deq = nullptr, *bG = nullptr;
     double *bval = nullptr, *scale = nullptr, *own = nullptr, *u = nullptr, *y = nullptr;
     double *R[2] = {nullptr, nullptr}, *RI[2] = {nullptr, nullptr}, *Q1t = nullptr;
+    double *apart = nullptr, *uact = nullptr, *csbuf = nullptr;
+    CoopPartial* cpart = nullptr;
+    unsigned* bar = nullptr;
+    int* abort_flag = nullptr;
+    int coop_mode = 1;                 // 0 never, 1 by size, 2 always (when it fits)
     double *d = nullptr, *bm = nullptr, *tvec = nullptr, *rhs = nullptr, *lam = nullptr, *vz = nullptr;
     double *svec = nullptr, *vvec = nullptr, *coef = nullptr, *outn = nullptr;
     int *isact = nullptr, *act = nullptr, *flag = nullptr;
@@ -1400,7 +2019,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->diagL, qp->meq); A(&qp->Vp, (size_t)LQ_NB * n1); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
-    A(&qp->Q1t, qc * qc); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
+    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->csbuf, 2 * qc);
+    A(&qp->cpart, 64); A(&qp->bar, 1); A(&qp->abort_flag, 1); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
     A(&qp->isact, mt); A(&qp->act, qc); A(&qp->flag, 2);
@@ -1409,12 +2029,24 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     if (!rc && hipFuncSetAttribute((const void*)k_gi_iter, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)LDS_LIMIT) != hipSuccess)
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
+    if (!rc && hipFuncSetAttribute((const void*)k_gi_coop, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)LDS_LIMIT) != hipSuccess)
+        rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
     if (!rc && hipFuncSetAttribute((const void*)k_trsv, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)LDS_LIMIT) != hipSuccess)
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
     if (rc) {
         og_qp_destroy(qp);
         return rc;
+    }
+    {
+        int can = 0;
+        (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCooperativeLaunch, device);
+        // OGSQP_GI = "single": one-workgroup active-set update (k_gi_iter), "coop": the cooperative
+        // multi-workgroup one (k_gi_coop); default: by size (the barriers of the cooperative kernel cost
+        // 12 us per change, its bandwidth pays from a null space of about 500 on)
+        const char* mode = getenv("OGSQP_GI");
+        qp->coop_mode = !can ? 0 : (mode && std::string(mode) == "single") ? 0 : (mode && std::string(mode) == "coop") ? 2 : 1;
     }
     *out = qp;
     return og_qp_reset(qp);
@@ -1597,7 +2229,50 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         OG_HIP(hipStreamSynchronize(s));
     }
-    if (nr > 0) {
+    const int coop_width = nr <= 1024 ? 16 : 64;
+    const int coop_G = nr > 0 ? (nr + coop_width - 1) / coop_width : 0;
+    const size_t coop_lds = (size_t)(5 * qp->qcap + 3 * coop_width + nr + COOP_THREADS) * sizeof(double) +
+                            (size_t)3 * qp->qcap * sizeof(int) + 64;
+    const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 512);
+    if (nr > 0 && use_coop && coop_G <= 64 && coop_lds <= LDS_LIMIT) {
+        // the whole active-set loop in one cooperative launch
+        CoopArgs ca;
+        ca.g = ga;
+        ca.g.Q1t = nullptr;
+        ca.G = coop_G;
+        ca.width = coop_width;
+        ca.astride = qp->qcap + 8;
+        ca.Q1s = qp->Q1t;
+        ca.RIr = qp->RI[0];
+        ca.apart = qp->apart;
+        ca.uact = qp->uact;
+        ca.cs = qp->csbuf;
+        ca.cpart = qp->cpart;
+        ca.bar = qp->bar;
+        ca.abort_flag = qp->abort_flag;
+        OG_HIP(hipMemsetAsync(qp->bar, 0, sizeof(unsigned), s));
+        OG_HIP(hipMemsetAsync(qp->abort_flag, 0, sizeof(int), s));
+        void* kargs[] = {(void*)&ca};
+        OG_STAGE("gi cooperative");
+        OG_HIP(hipLaunchCooperativeKernel((const void*)k_gi_coop, dim3(coop_G), dim3(COOP_THREADS), kargs,
+                                          (unsigned)coop_lds, s));
+        int habort = 0;
+        OG_HIP(hipMemcpyAsync(&hst, qp->st, sizeof(GiState), hipMemcpyDeviceToHost, s));
+        OG_HIP(hipMemcpyAsync(&habort, qp->abort_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        OG_HIP(hipStreamSynchronize(s));
+#ifdef OGSQP_TRACE
+        {
+            static const char* nm[12] = {"pricing", "barrier 1", "projections 1", "barrier 2", "gather a, z1", "barrier 2b",
+                                         "projections 2", "barrier 3", "gather a2, z2, r", "barrier 4", "updates",
+                                         "barrier 5"};
+            fprintf(stderr, "[ogsqp trace] cooperative: %d iterations, G = %d\n", hst.iters, coop_G);
+            for (int e = 0; e < 12; ++e)
+                fprintf(stderr, "[ogsqp trace]   %-18s %8.0f ticks per iteration\n", nm[e],
+                        hst.iters ? (double)hst.tr[e] / hst.iters : 0.0);
+        }
+#endif
+        if (habort) return fail(7, "og_qp_solve_dev: the cooperative active-set kernel lost a workgroup at a barrier");
+    } else if (nr > 0) {
         const int blocks = (mg + nq + GI_WAVES - 1) / GI_WAVES;
         const size_t lds = gi_lds_bytes(nr, qp->qcap);
         int batch = debug_stages() ? 1 : 8;

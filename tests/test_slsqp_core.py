@@ -204,7 +204,11 @@ def gpu_qp(core_box):
 
 
 @pytest.mark.gpu
-def test_gpu_qp_matches_restatement_on_random_qps():
+@pytest.mark.parametrize("update", ["single", "coop"])
+def test_gpu_qp_matches_restatement_on_random_qps(update, monkeypatch):
+    """Both implementations of the active-set update: one workgroup (k_gi_iter, with the restatement's
+    pivoting: identical iteration counts) and the cooperative multi-workgroup kernel (k_gi_coop)."""
+    monkeypatch.setenv("OGSQP_GI", update)
     rng = np.random.default_rng(1)
     for trial in range(24):
         n = int(rng.integers(3, 140))
@@ -227,7 +231,9 @@ def test_gpu_qp_matches_restatement_on_random_qps():
 
 
 @pytest.mark.gpu
-def test_gpu_qp_relaxed_incompatible_and_singular_cases():
+@pytest.mark.parametrize("update", ["single", "coop"])
+def test_gpu_qp_relaxed_incompatible_and_singular_cases(update, monkeypatch):
+    monkeypatch.setenv("OGSQP_GI", update)
     rng = np.random.default_rng(2)
     n, meq, mg = 30, 8, 25
     Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg, feasible=False)
@@ -388,16 +394,18 @@ def test_goddard_converges_with_both_cores(capsys):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("update", ["single", "coop"])
 @pytest.mark.parametrize("name,tol", [("brachistochrone", 1e-5),      # v(0) = 0: cond(C) = 3e10 at the initial guess
                                       ("goddard", 1e-8), ("polar_tsto_shipped", 1e-8),
                                       ("low_thrust_shipped", 1e-8), ("table_ascent", 1e-8)])
-def test_gpu_first_subproblem_of_every_small_configuration(name, tol):
+def test_gpu_first_subproblem_of_every_small_configuration(name, tol, update, monkeypatch):
     """The first QP subproblem (B = I) of each small configuration, on the Jacobian the sweep kernel
     produces: same exit mode as the restatement; same step and multipliers where it is solvable, the
     relaxed problem (rho = 100) where the linearisation is inconsistent.  These Jacobians contain
     what random matrices do not: inequality rows that repeat equalities, zero rows, bounds that
-    coincide with path constraints."""
+    coincide with path constraints.  Both active-set updates."""
     from opengoddard_amd.engine import HipEngine
+    monkeypatch.setenv("OGSQP_GI", update)
     prob, obj = problems.build(name)
     eng = HipEngine(prob, obj)
     lb, ub = np_path.bounds_arrays(prob)

@@ -1287,8 +1287,9 @@ struct CoopArgs {
     int G, width, astride;
     double* Q1s;        // G x qcap x width
     double* RIr;        // qcap slots x qcap, row-major: row slot[i] = row i of the upper-triangular R^-1
-    double* apart;      // G x astride: [a_0 .. a_{q-1} | nn, sp, zz, yy]
-    double* uact;       // multipliers of the active rows, logical order
+    double* apart;      // 2 x G x astride (one set per Gram-Schmidt pass): [a_0 .. a_{q-1} | nn, sp, zz, -]
+    double* zg;         // z, all slices
+    double* rg;         // dual direction r, logical order
     double* cs;         // rotations of a removal
     CoopPartial* cpart; // G
     unsigned* bar;      // barrier counter
@@ -1445,23 +1446,30 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w = blockIdx.x, G = c.G, width = c.width;
     const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
+    const int mt = mg + 2 * nq;
     const int c0 = w * width;
     const int cw = max(0, min(width, nr - c0));          // my null-space coordinates: c0 .. c0+cw-1
-    // LDS: replicated vectors and book-keeping
-    double* av = lds;                   // accumulated projections (new column of R)
-    double* a2 = av + qcap;             // projections of the current pass / rotations of a removal (2 qcap)
-    double* carried = a2 + 2 * qcap;    // workgroup 0: row carried down the Givens chain; diag copy behind it
-    double* diagc = carried + qcap;
-    double* ysl = diagc + qcap;         // slices: y, incoming normal, z
-    double* nsl = ysl + width;
+    // LDS.  Replicated in every workgroup (identical, updated by identical code): y, the
+    // multipliers and the list of the active rows, their storage slots, the free slots, the
+    // active-row bitmap.  Private: my slices of the incoming normal and of z.
+    double* av = lds;                   // accumulated projections (new column of R); Givens carry (workgroup 0)
+    double* a2 = av + qcap;             // projections of the second pass | dual direction r; rotations (2 qcap)
+    double* uact = a2 + 2 * qcap;       // multipliers of the active rows, logical order
+    double* nsl = uact + qcap;          // slices: incoming normal, z
     double* zsl = nsl + width;
-    double* yfull = zsl + width;        // all of y, refreshed for every pricing
-    double* scratch = yfull + nr;       // COOP_THREADS partial sums of the slice kernels
+    double* yfull = zsl + width;        // y
+    double* zfull = yfull + nr;         // z gathered from all slices; diagonal of R (workgroup 0, removal)
+    double* scratch = zfull + nr;       // COOP_THREADS partial sums of the slice kernels
     int* act = (int*)(scratch + COOP_THREADS);   // active rows, logical order
     int* slot = act + qcap;             // storage slot of every active row (rows of RIr)
     int* freel = slot + qcap;           // free slots, a stack
+    unsigned* abits = (unsigned*)(freel + qcap);   // bit r: stack row r is active
+    double* rv = a2 + qcap;
+    double* carried = av;
+    double* diagc = zfull;
     double* Q1s = c.Q1s + (long)w * qcap * width;
-    double* mypart = c.apart + (long)w * c.astride;
+    double* part[2] = {c.apart + (long)w * c.astride, c.apart + (long)(G + w) * c.astride};
+    const double* parts[2] = {c.apart, c.apart + (long)G * c.astride};
 
 #ifdef OGSQP_TRACE
     long long t_mark = __builtin_amdgcn_s_memtime();
@@ -1474,7 +1482,8 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
     int q = 0, iters = 0, cur = 0, nfree = qcap, phase = st->phase;
     double ynorm = 0.0;
     for (int i = tid; i < qcap; i += COOP_THREADS) freel[i] = qcap - 1 - i;      // pop order 0, 1, 2, ...
-    for (int i = tid; i < width; i += COOP_THREADS) ysl[i] = 0.0;
+    for (int i = tid; i < nr; i += COOP_THREADS) yfull[i] = 0.0;
+    for (int i = tid; i < (mt + 31) / 32; i += COOP_THREADS) abits[i] = 0u;
     __syncthreads();
     if (phase >= 2) return;
 
@@ -1485,15 +1494,12 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
             const double slack = FEASIBLE * ynorm;
             double best = INFINITY;
             int besti = 0x7fffffff;
-            for (int i = tid; i < nr; i += COOP_THREADS) yfull[i] = ld_shared(g.y + i);
-            __syncthreads();
             // my rows in groups of PG: the row data and the per-row constants of a whole group are
             // requested together, so a group costs one memory round trip, not one per row and field
             constexpr int PG = 4;
             const int rstride = G * COOP_WAVES;
             for (int r0 = (w * COOP_WAVES) + wave; r0 < mg + nq; r0 += PG * rstride) {
                 double dots[PG], sc_lo[PG], sc_hi[PG], bv_lo[PG], bv_hi[PG], ow_lo[PG], ow_hi[PG];
-                int ia_lo[PG], ia_hi[PG];
 #pragma unroll
                 for (int e = 0; e < PG; ++e) {
                     const int r = r0 + e * rstride;
@@ -1502,11 +1508,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                     sc_lo[e] = live ? g.scale[lo] : 0.0;
                     bv_lo[e] = g.bval[lo];
                     ow_lo[e] = g.own[lo];
-                    ia_lo[e] = ld_shared(g.isact + lo);
                     sc_hi[e] = (live && r >= mg) ? g.scale[hi] : 0.0;
                     bv_hi[e] = g.bval[hi];
                     ow_hi[e] = g.own[hi];
-                    ia_hi[e] = ld_shared(g.isact + hi);
                     dots[e] = 0.0;
                 }
                 if (nr <= 512) {
@@ -1551,18 +1555,19 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                     const int r = r0 + e * rstride;
                     const double dot = wave_sum(dots[e]);
                     if (r >= mg + nq) continue;
-                    if (sc_lo[e] > 0.0 && !ia_lo[e]) {
+                    if (sc_lo[e] > 0.0 && !((abits[r >> 5] >> (r & 31)) & 1u)) {
                         const double v = (bv_lo[e] + dot) / sc_lo[e] + ow_lo[e] + slack;
                         if (v < best || (v == best && r < besti)) {
                             best = v;
                             besti = r;
                         }
                     }
-                    if (r >= mg && sc_hi[e] > 0.0 && !ia_hi[e]) {
+                    const int hi = r + nq;
+                    if (r >= mg && sc_hi[e] > 0.0 && !((abits[hi >> 5] >> (hi & 31)) & 1u)) {
                         const double v = (bv_hi[e] - dot) / sc_hi[e] + ow_hi[e] + slack;
-                        if (v < best || (v == best && r + nq < besti)) {
+                        if (v < best || (v == best && hi < besti)) {
                             best = v;
-                            besti = r + nq;
+                            besti = hi;
                         }
                     }
                 }
@@ -1603,53 +1608,56 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
             // my slice of the normal; partial projections on my columns of Q1, |n|^2 and n.y
             if (tid < width) nsl[tid] = tid < cw ? psign * prow[tid] : 0.0;
             __syncthreads();
-            slice_project(Q1s, width, cw, q, nsl, mypart);
+            slice_project(Q1s, width, cw, q, nsl, part[0]);
             {
                 double pn = 0.0, py = 0.0;
                 if (tid < cw) {
                     pn = nsl[tid] * nsl[tid];
-                    py = nsl[tid] * ysl[tid];
+                    py = nsl[tid] * yfull[c0 + tid];
                 }
                 pn = block_sum(pn, red);
                 py = block_sum(py, red);
                 if (tid == 0) {
-                    st_shared(mypart + qcap, pn);
-                    st_shared(mypart + qcap + 1, py);
+                    st_shared(part[0] + qcap, pn);
+                    st_shared(part[0] + qcap + 1, py);
                 }
             }
             CMARK(2);   // projections 1
             if (!grid_barrier(c, epoch)) return;
             CMARK(3);   // barrier 2
-            gather_partials(c.apart, c.astride, G, q, qcap, av, scal);
+            gather_partials(parts[0], c.astride, G, q, qcap, av, scal);
             const double nn = scal[0];
             const double sp = g.bval[p] + scal[1];
-            // z = n - Q1 a on my coordinates, then the second Gram-Schmidt pass's partial projections
+            // z = n - Q1 a on my coordinates; |z|^2 = |n|^2 - |a|^2 needs no further reduction
             slice_subtract(Q1s, width, cw, q, av, nsl, zsl, scratch);
+            double aa_part = 0.0;
+            for (int j = tid; j < q; j += COOP_THREADS) aa_part += av[j] * av[j];
+            double zz = fmax(nn - block_sum(aa_part, red), 0.0);
             CMARK(4);   // gather a, z1
-            if (!grid_barrier(c, epoch)) return;         // everybody has read the first-pass partials
-            CMARK(5);   // barrier 2b
-            slice_project(Q1s, width, cw, q, zsl, mypart);
-            {
-                double pz = tid < cw ? zsl[tid] * zsl[tid] : 0.0;
-                pz = block_sum(pz, red);
-                if (tid == 0) st_shared(mypart + qcap + 2, pz);
+            // Daniel-Gragg-Kaufman-Stewart: a second Gram-Schmidt pass only when the first one cancelled
+            // more than half of |n|^2 (every workgroup takes the same branch: nn and a are the same bits)
+            if (!(zz > 0.5 * nn)) {
+                slice_project(Q1s, width, cw, q, zsl, part[1]);
+                {
+                    double pz = tid < cw ? zsl[tid] * zsl[tid] : 0.0;
+                    pz = block_sum(pz, red);
+                    if (tid == 0) st_shared(part[1] + qcap + 2, pz);
+                }
+                CMARK(6);   // projections 2
+                if (!grid_barrier(c, epoch)) return;
+                CMARK(7);   // barrier 3
+                gather_partials(parts[1], c.astride, G, q, qcap, a2, scal);
+                double corr_part = 0.0;
+                for (int j = tid; j < q; j += COOP_THREADS) {
+                    av[j] += a2[j];
+                    corr_part += a2[j] * a2[j];
+                }
+                zz = fmax(scal[2] - block_sum(corr_part, red), 0.0);      // |z - Q1 a2|^2 = |z|^2 - |a2|^2
+                slice_subtract(Q1s, width, cw, q, a2, zsl, zsl, scratch);
             }
-            CMARK(6);   // projections 2
-            if (!grid_barrier(c, epoch)) return;
-            CMARK(7);   // barrier 3
-            gather_partials(c.apart, c.astride, G, q, qcap, a2, scal);
-            double zz = scal[2];
-            double corr_part = 0.0;
-            for (int j = tid; j < q; j += COOP_THREADS) {
-                const double acc = a2[j];
-                av[j] += acc;
-                corr_part += acc * acc;
-            }
-            const double corr = block_sum(corr_part, red);
-            zz = fmax(zz - corr, 0.0);                    // |z - Q1 a2|^2 = |z|^2 - |a2|^2
-            slice_subtract(Q1s, width, cw, q, a2, zsl, zsl, scratch);
             const bool dependent = (q >= nr) || !(zz > (DEPENDENT * DEPENDENT) * nn);
-            // dual direction on my rows of R^-1, candidates of the ratio test
+            // my part of z and my entries of the dual direction r = R^-1 a go out for everybody
+            if (tid < cw) st_shared(c.zg + c0 + tid, zsl[tid]);
             double t1 = INFINITY;
             int kdrop = 0x7fffffff;
             for (int i = wave; i < q; i += COOP_WAVES) {
@@ -1659,9 +1667,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                 for (int j = i + lane; j < q; j += 64) dot += row[j] * av[j];
                 dot = wave_sum(dot);
                 if (lane == 0) {
-                    a2[qcap + i] = dot;                   // my r_i, kept for the updates below
+                    st_shared(c.rg + i, dot);
                     if (dot > 0.0) {
-                        const double cand = ld_shared(c.uact + i) / dot;
+                        const double cand = uact[i] / dot;
                         if (cand < t1 || (cand == t1 && i < kdrop)) {
                             t1 = cand;
                             kdrop = i;
@@ -1678,7 +1686,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                 st_shared(&c.cpart[w].ratio, t1);
                 st_shared(&c.cpart[w].k, kdrop);
             }
-            CMARK(8);   // gather a2, z2, dual direction
+            CMARK(8);   // z2, dual direction
             if (!grid_barrier(c, epoch)) return;
             CMARK(9);   // barrier 4
             t1 = INFINITY;
@@ -1695,22 +1703,23 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                 leave = true;
                 break;
             }
-            // multipliers of my rows, my part of y
-            for (int i = wave; i < q; i += COOP_WAVES)
-                if (slot[i] % G == w && lane == 0) st_shared(c.uact + i, ld_shared(c.uact + i) - t * a2[qcap + i]);
+            // everybody updates its copy of the multipliers and of y from the gathered r and z
+            for (int i = tid; i < q; i += COOP_THREADS) {
+                const double ri = ld_shared(c.rg + i);
+                rv[i] = ri;
+                uact[i] -= t * ri;
+            }
             up += t;
             double pyy = 0.0;
-            if (tid < cw) {
-                double yi = ysl[tid];
+            for (int i = tid; i < nr; i += COOP_THREADS) {
+                double yi = yfull[i];
                 if (!dependent) {
-                    yi += t * zsl[tid];
-                    ysl[tid] = yi;
-                    st_shared(g.y + c0 + tid, yi);
+                    yi += t * ld_shared(c.zg + i);
+                    yfull[i] = yi;
                 }
-                pyy = yi * yi;
+                pyy += yi * yi;
             }
-            pyy = block_sum(pyy, red);
-            if (tid == 0) st_shared(mypart + qcap + 3, pyy);
+            ynorm = sqrt(block_sum(pyy, red));
             const bool full_step = (t2 < INFINITY) && (t2 <= t1);
             if (full_step) {
                 // p joins: Q1 gets z/|z| (my columns), R the column [a; |z|] (workgroup 0), R^-1 the
@@ -1718,29 +1727,25 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                 const double delta = sqrt(zz), inv = 1.0 / delta;
                 const int sl = freel[nfree - 1];
                 if (tid < cw) Q1s[(long)q * width + tid] = zsl[tid] * inv;
-                for (int i = wave; i < q; i += COOP_WAVES)
-                    if (slot[i] % G == w && lane == 0) c.RIr[(long)slot[i] * qcap + q] = -a2[qcap + i] * inv;
+                for (int i = tid; i < q; i += COOP_THREADS)
+                    if (slot[i] % G == w) c.RIr[(long)slot[i] * qcap + q] = -rv[i] * inv;
                 if (sl % G == w && tid == 0) c.RIr[(long)sl * qcap + q] = inv;
                 if (w == 0) {
                     double* R = g.R[cur];
                     for (int i = tid; i < q; i += COOP_THREADS) R[(long)q * qcap + i] = av[i];
-                    if (tid == 0) {
-                        R[(long)q * qcap + q] = delta;
-                        st_shared(c.uact + q, up);
-                        st_shared(g.isact + p, 1);
-                    }
+                    if (tid == 0) R[(long)q * qcap + q] = delta;
                 }
                 __syncthreads();
                 if (tid == 0) {
                     act[q] = p;
                     slot[q] = sl;
+                    uact[q] = up;
+                    abits[p >> 5] |= 1u << (p & 31);
                 }
                 --nfree;
                 ++q;
+                __syncthreads();
                 CMARK(10);  // updates, append
-                if (!grid_barrier(c, epoch)) return;     // y, isact, uact visible before the next pricing
-                CMARK(11);  // barrier 5
-                ynorm = sqrt(sum_partials(c.apart, c.astride, G, qcap + 3));
                 break;
             }
             // ---- partial step: active row k leaves --------------------------------------------------
@@ -1783,14 +1788,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                     }
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    st_shared(g.isact + act[k], 0);
-                }
             }
             if (!grid_barrier(c, epoch)) return;         // rotations published
-            double* cs = a2;                              // (the second-pass projections are spent)
-            const double my_r_k = 0.0;
-            (void)my_r_k;
+            double* cs = a2;                              // (second-pass projections and r are spent)
             for (int j = k + tid; j < q - 1; j += COOP_THREADS) {
                 cs[2 * j] = ld_shared(c.cs + 2 * j);
                 cs[2 * j + 1] = ld_shared(c.cs + 2 * j + 1);
@@ -1819,36 +1819,31 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                     x = -si * x + co * yv;
                 }
             }
-            // multipliers shift (their owners wrote them before the last barrier)
             __syncthreads();
-            if (w == 0) {
-                double keep = 0.0;
-                for (int base = k; base < q - 1; base += COOP_THREADS) {
-                    const int j = base + tid;
-                    if (j < q - 1) keep = ld_shared(c.uact + j + 1);
-                    __syncthreads();
-                    if (j < q - 1) st_shared(c.uact + j, keep);
-                    __syncthreads();
-                }
-            }
-            // replicated book-keeping
+            // replicated book-keeping: row k leaves the lists, its slot is free again
             {
-                const int freed = slot[k];
+                const int freed = slot[k], gone = act[k];
                 int a_keep = 0, s_keep = 0;
+                double u_keep = 0.0;
                 for (int base = k; base < q - 1; base += COOP_THREADS) {
                     const int j = base + tid;
                     if (j < q - 1) {
                         a_keep = act[j + 1];
                         s_keep = slot[j + 1];
+                        u_keep = uact[j + 1];
                     }
                     __syncthreads();
                     if (j < q - 1) {
                         act[j] = a_keep;
                         slot[j] = s_keep;
+                        uact[j] = u_keep;
                     }
                     __syncthreads();
                 }
-                if (tid == 0) freel[nfree] = freed;
+                if (tid == 0) {
+                    freel[nfree] = freed;
+                    abits[gone >> 5] &= ~(1u << (gone & 31));
+                }
                 ++nfree;
                 --q;
                 cur ^= 1;
@@ -1857,10 +1852,10 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
         }
         if (leave) break;
     }
-    // ---- results: multipliers back to the per-constraint array, state for the host ------------------
-    if (!grid_barrier(c, epoch)) return;
+    // ---- results: y and the multipliers back to the per-constraint arrays, state for the host -----
     if (w == 0) {
-        for (int j = tid; j < q; j += COOP_THREADS) g.u[act[j]] = ld_shared(c.uact + j);
+        for (int i = tid; i < nr; i += COOP_THREADS) g.y[i] = yfull[i];
+        for (int j = tid; j < q; j += COOP_THREADS) g.u[act[j]] = uact[j];
         if (tid == 0) {
             st->phase = phase;
             st->q = q;
@@ -1928,7 +1923,7 @@ struct og_qp_s {
     double *w1 = nullptr, *t1 = nullptr, *xcat = nullptr, *deq = nullptr, *bG = nullptr;
     double *bval = nullptr, *scale = nullptr, *own = nullptr, *u = nullptr, *y = nullptr;
     double *R[2] = {nullptr, nullptr}, *RI[2] = {nullptr, nullptr}, *Q1t = nullptr;
-    double *apart = nullptr, *uact = nullptr, *csbuf = nullptr;
+    double *apart = nullptr, *uact = nullptr, *csbuf = nullptr, *zg = nullptr;
     CoopPartial* cpart = nullptr;
     unsigned* bar = nullptr;
     int* abort_flag = nullptr;
@@ -2019,7 +2014,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->diagL, qp->meq); A(&qp->Vp, (size_t)LQ_NB * n1); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
-    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->csbuf, 2 * qc);
+    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->csbuf, 2 * qc);
     A(&qp->cpart, 64); A(&qp->bar, 1); A(&qp->abort_flag, 1); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
@@ -2234,8 +2229,8 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     const int coop_slices = nr > 0 ? (nr + coop_width - 1) / coop_width : 0;
     // (64 in all: measured 15 % on C5, neutral below)
     const int coop_G = std::max(coop_slices, 64);
-    const size_t coop_lds = (size_t)(5 * qp->qcap + 3 * coop_width + nr + COOP_THREADS) * sizeof(double) +
-                            (size_t)3 * qp->qcap * sizeof(int) + 64;
+    const size_t coop_lds = (size_t)(4 * qp->qcap + 2 * coop_width + 2 * nr + COOP_THREADS) * sizeof(double) +
+                            (size_t)3 * qp->qcap * sizeof(int) + (size_t)((mg + 2 * nq + 31) / 32 + 1) * sizeof(unsigned) + 64;
     const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 512);
     if (nr > 0 && use_coop && coop_slices <= 64 && coop_lds <= LDS_LIMIT) {
         // the whole active-set loop in one cooperative launch
@@ -2248,7 +2243,8 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         ca.Q1s = qp->Q1t;
         ca.RIr = qp->RI[0];
         ca.apart = qp->apart;
-        ca.uact = qp->uact;
+        ca.zg = qp->zg;
+        ca.rg = qp->uact;
         ca.cs = qp->csbuf;
         ca.cpart = qp->cpart;
         ca.bar = qp->bar;

@@ -2232,6 +2232,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     const size_t coop_lds = (size_t)(4 * qp->qcap + 2 * coop_width + 2 * nr + COOP_THREADS) * sizeof(double) +
                             (size_t)3 * qp->qcap * sizeof(int) + (size_t)((mg + 2 * nq + 31) / 32 + 1) * sizeof(unsigned) + 64;
     const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 512);
+    bool coop_done = false;
     if (nr > 0 && use_coop && coop_slices <= 64 && coop_lds <= LDS_LIMIT) {
         // the whole active-set loop in one cooperative launch
         CoopArgs ca;
@@ -2253,8 +2254,18 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         OG_HIP(hipMemsetAsync(qp->abort_flag, 0, sizeof(int), s));
         void* kargs[] = {(void*)&ca};
         OG_STAGE("gi cooperative");
-        OG_HIP(hipLaunchCooperativeKernel((const void*)k_gi_coop, dim3(coop_G), dim3(COOP_THREADS), kargs,
-                                          (unsigned)coop_lds, s));
+        const hipError_t launched = hipLaunchCooperativeKernel((const void*)k_gi_coop, dim3(coop_G),
+                                                               dim3(COOP_THREADS), kargs, (unsigned)coop_lds, s);
+        if (launched != hipSuccess) {
+            // the runtime cannot keep 64 workgroups of this size resident: the one-workgroup kernel
+            // below does the same job (both run on the GPU; nothing leaves it)
+            (void)hipGetLastError();
+            qp->coop_mode = 0;
+        } else {
+            coop_done = true;
+        }
+    }
+    if (coop_done) {
         int habort = 0;
         OG_HIP(hipMemcpyAsync(&hst, qp->st, sizeof(GiState), hipMemcpyDeviceToHost, s));
         OG_HIP(hipMemcpyAsync(&habort, qp->abort_flag, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -59,6 +59,10 @@ class HipEngine:
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
+        cache = getattr(self, "_sqp_cache", None)
+        if cache is not None:                       # QP work space of the SQP driver (sqp.py)
+            cache[1].close()
+            self._sqp_cache = None
         if getattr(self, "_handle", None) is not None and self._handle.value:
             self._lib.og_problem_destroy(self._handle)
             self._handle = C.c_void_p()

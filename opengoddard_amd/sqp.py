@@ -90,8 +90,15 @@ def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivati
     lb = np.asarray(lb, dtype=float)
     ub = np.asarray(ub, dtype=float)
     x = np.clip(np.asarray(x0, dtype=float), lb, ub)
-    jacobian = DeviceJacobian(engine)
-    core = _sqp_native.QpCore(n, meq, mineq, device=engine.device)
+    # device buffers and the QP work space belong to the engine: the restarts of Problem.solve reuse them
+    cache = getattr(engine, "_sqp_cache", None)
+    if cache is None:
+        cache = (DeviceJacobian(engine), _sqp_native.QpCore(n, meq, mineq, device=engine.device))
+        try:
+            engine._sqp_cache = cache
+        except AttributeError:
+            pass
+    jacobian, core = cache
     timing = {"callbacks": 0.0, "qp": 0.0, "bfgs": 0.0, "qp_iterations": 0, "qp_solves": 0}
     unit0 = np.zeros(m + 1)
     unit0[0] = 1.0
@@ -244,7 +251,8 @@ def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivati
         if core.bfgs(s, eta, fraction * Bd):
             reset = True
         timing["bfgs"] += time.perf_counter() - t
-    core.close()
+    if getattr(engine, "_sqp_cache", None) is None:
+        core.close()
     message = EXIT_MODES.get(int(status), "mode %d" % status)
     if disp:
         print(message + "    (Exit mode " + str(int(status)) + ")")

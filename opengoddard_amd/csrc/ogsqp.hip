@@ -1284,7 +1284,7 @@ struct CoopPartial {
 
 struct CoopArgs {
     GiArgs g;
-    int G, width, astride;
+    int G, nslices, width, astride;   // G workgroups, the first nslices of them own a slice
     double* Q1s;        // G x qcap x width
     double* RIr;        // qcap slots x qcap, row-major: row slot[i] = row i of the upper-triangular R^-1
     double* apart;      // 2 x G x astride (one set per Gram-Schmidt pass): [a_0 .. a_{q-1} | nn, sp, zz, -]
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
     const GiArgs& g = c.g;
     GiState* st = g.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int w = blockIdx.x, G = c.G, width = c.width;
+    const int w = blockIdx.x, G = c.G, NS = c.nslices, width = c.width;
     const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
     const int mt = mg + 2 * nq;
     const int c0 = w * width;
@@ -1467,9 +1467,11 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
     double* rv = a2 + qcap;
     double* carried = av;
     double* diagc = zfull;
-    double* Q1s = c.Q1s + (long)w * qcap * width;
-    double* part[2] = {c.apart + (long)w * c.astride, c.apart + (long)(G + w) * c.astride};
-    const double* parts[2] = {c.apart, c.apart + (long)G * c.astride};
+    double* Q1s = c.Q1s + (long)(w < c.nslices ? w : 0) * qcap * width;
+    // partial vectors exist for the slice owners only (the others own no column of Q1)
+    const int wp = w < NS ? w : 0;
+    double* part[2] = {c.apart + (long)wp * c.astride, c.apart + (long)(NS + wp) * c.astride};
+    const double* parts[2] = {c.apart, c.apart + (long)NS * c.astride};
 
 #ifdef OGSQP_TRACE
     long long t_mark = __builtin_amdgcn_s_memtime();
@@ -1608,8 +1610,8 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
             // my slice of the normal; partial projections on my columns of Q1, |n|^2 and n.y
             if (tid < width) nsl[tid] = tid < cw ? psign * prow[tid] : 0.0;
             __syncthreads();
-            slice_project(Q1s, width, cw, q, nsl, part[0]);
-            {
+            if (w < NS) slice_project(Q1s, width, cw, q, nsl, part[0]);
+            if (w < NS) {
                 double pn = 0.0, py = 0.0;
                 if (tid < cw) {
                     pn = nsl[tid] * nsl[tid];
@@ -1625,7 +1627,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
             CMARK(2);   // projections 1
             if (!grid_barrier(c, epoch)) return;
             CMARK(3);   // barrier 2
-            gather_partials(parts[0], c.astride, G, q, qcap, av, scal);
+            gather_partials(parts[0], c.astride, NS, q, qcap, av, scal);
             const double nn = scal[0];
             const double sp = g.bval[p] + scal[1];
             // z = n - Q1 a on my coordinates; |z|^2 = |n|^2 - |a|^2 needs no further reduction
@@ -1637,8 +1639,8 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
             // Daniel-Gragg-Kaufman-Stewart: a second Gram-Schmidt pass only when the first one cancelled
             // more than half of |n|^2 (every workgroup takes the same branch: nn and a are the same bits)
             if (!(zz > 0.5 * nn)) {
-                slice_project(Q1s, width, cw, q, zsl, part[1]);
-                {
+                if (w < NS) slice_project(Q1s, width, cw, q, zsl, part[1]);
+                if (w < NS) {
                     double pz = tid < cw ? zsl[tid] * zsl[tid] : 0.0;
                     pz = block_sum(pz, red);
                     if (tid == 0) st_shared(part[1] + qcap + 2, pz);
@@ -1646,7 +1648,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
                 CMARK(6);   // projections 2
                 if (!grid_barrier(c, epoch)) return;
                 CMARK(7);   // barrier 3
-                gather_partials(parts[1], c.astride, G, q, qcap, a2, scal);
+                gather_partials(parts[1], c.astride, NS, q, qcap, a2, scal);
                 double corr_part = 0.0;
                 for (int j = tid; j < q; j += COOP_THREADS) {
                     av[j] += a2[j];
@@ -2015,7 +2017,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
     A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->csbuf, 2 * qc);
-    A(&qp->cpart, 64); A(&qp->bar, 1); A(&qp->abort_flag, 1); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
+    A(&qp->cpart, 256); A(&qp->bar, 1); A(&qp->abort_flag, 1); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
     A(&qp->isact, mt); A(&qp->act, qc); A(&qp->flag, 2);
@@ -2227,8 +2229,10 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     const int coop_width = nr <= 1024 ? 16 : 64;
     // workgroups beyond the ceil(nr / width) that own a slice only take part in the pricing
     const int coop_slices = nr > 0 ? (nr + coop_width - 1) / coop_width : 0;
-    // (64 in all: measured 15 % on C5, neutral below)
-    const int coop_G = std::max(coop_slices, 64);
+    // as many as it takes to bring the pricing (all of W, every change) down to ~256 KB per workgroup,
+    // between 64 and one per CU
+    const size_t pricing_bytes = (size_t)(mg + nq) * (size_t)nr * sizeof(double);
+    const int coop_G = std::max(coop_slices, (int)std::min<size_t>(256, std::max<size_t>(64, pricing_bytes / (256 * 1024))));
     const size_t coop_lds = (size_t)(4 * qp->qcap + 2 * coop_width + 2 * nr + COOP_THREADS) * sizeof(double) +
                             (size_t)3 * qp->qcap * sizeof(int) + (size_t)((mg + 2 * nq + 31) / 32 + 1) * sizeof(unsigned) + 64;
     const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 512);
@@ -2239,6 +2243,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         ca.g = ga;
         ca.g.Q1t = nullptr;
         ca.G = coop_G;
+        ca.nslices = coop_slices;
         ca.width = coop_width;
         ca.astride = qp->qcap + 8;
         ca.Q1s = qp->Q1t;

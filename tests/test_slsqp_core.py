@@ -304,9 +304,12 @@ def test_gpu_bfgs_update_matches_restatement():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("update", ["single", "coop"])
 @pytest.mark.parametrize("name,maxiter,ftol", [("goddard", 30, 1e-10), ("polar_tsto_shipped", 20, 1e-6)])
-def test_gpu_qp_replays_scipy_iterates(name, maxiter, ftol):
-    """SciPy's iterates reproduced with every QP subproblem solved by the HIP core."""
+def test_gpu_qp_replays_scipy_iterates(name, maxiter, ftol, update, monkeypatch):
+    """SciPy's iterates reproduced with every QP subproblem solved by the HIP core (either
+    active-set kernel)."""
+    monkeypatch.setenv("OGSQP_GI", update)
     cb = Callbacks(name)
     cores = {}
     ref, ours, trace = replay(cb, maxiter, ftol, qp=gpu_qp(cores))

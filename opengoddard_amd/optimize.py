@@ -394,6 +394,10 @@ class Problem:
         assert self.equality is not None, "It must be set equality function"
         assert self.inequality is not None, "It must be set inequality function"
 
+        core = options.pop("sqp_core", None) or os.environ.get("OG_SQP_CORE", DEFAULT_SQP_CORE)
+        if core not in ("scipy", "hip"):
+            raise ValueError("sqp_core must be 'scipy' or 'hip', got %r" % (core,))
+
         engine = (ENGINE_FACTORY or _default_engine)(self, obj)
         self._engine = engine
         lb = np.array([-np.inf if b[0] is None else b[0] for b in self.bounds], dtype=float)
@@ -426,9 +430,6 @@ class Problem:
 
         ftol = options.setdefault("ftol", 1e-6)
         maxiter = options.setdefault("maxiter", 25)
-        core = options.pop("sqp_core", None) or os.environ.get("OG_SQP_CORE", DEFAULT_SQP_CORE)
-        if core not in ("scipy", "hip"):
-            raise ValueError("sqp_core must be 'scipy' or 'hip', got %r" % (core,))
         if core == "hip":
             from . import sqp as _sqp
             user_gradient = None

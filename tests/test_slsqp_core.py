@@ -436,3 +436,23 @@ def test_gpu_first_subproblem_of_every_small_configuration(name, tol, update, mo
     assert np.max(np.abs(mult - np.concatenate([ref[1], ref[2]]))) <= 100 * tol * mscale
     core.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_environment_variable_selects_the_hip_core(monkeypatch, capsys):
+    """OG_SQP_CORE=hip: an unmodified script (no sqp_core argument) gets the GPU SQP core."""
+    monkeypatch.setenv("OG_SQP_CORE", "hip")
+    prob, obj = problems.build("brachistochrone")
+    prob.solve(obj)                                  # reference defaults: maxiter 25, restarts until converged
+    out = capsys.readouterr().out
+    assert "Optimization terminated successfully" in out and "---- iteration : 1 ----" in out
+    assert prob.sqp_timings and prob.last_result.status == 0
+    assert abs(prob.last_result.fun - 1.7724562) <= 2e-5
+    with pytest.raises(ValueError, match="sqp_core"):
+        prob.solve(obj, sqp_core="fortran")
+
+
+def test_unknown_sqp_core_is_rejected_before_any_work():
+    prob, obj = problems.build("brachistochrone")
+    with pytest.raises(ValueError, match="sqp_core"):
+        prob.solve(obj, sqp_core="cuda")

@@ -4,16 +4,19 @@
 // section 9).  Everything O(n^2) stays in HBM:
 //
 //   1. T = [C Z ; Z]  (TN GEMM on the FP64 matrix cores, reading the transposed FD Jacobian as
-//      the sweep kernel left it), then one orthogonal LQ sweep from the right: C Z Q = [L 0],
+//      the sweep kernel left it), then one orthogonal LQ sweep from the right in compact-WY
+//      panels of 8 reflectors (k_lq_panel / k_lq_apply_reg): C Z Q = [L 0],
 //      J = Z Q.  J is again a factor of B^-1, its trailing columns Y span the null space of C
 //      and are B-orthonormal, so the equality-constrained minimiser is two triangular solves
 //      and the inequality part becomes a least-distance problem  min |y|^2, W y + b >= 0  with
 //      W = [G;I] Y.
-//   2. Goldfarb-Idnani dual active set on the LDP, one launch per iteration: all workgroups
-//      evaluate the constraint values W y + b and elect the most violated row; the last
-//      workgroup to arrive performs the O(q nr) update (classical Gram-Schmidt with
-//      re-orthogonalisation against the active normals, explicit inverse triangular factor so
-//      that no triangular solve sits on the critical path).
+//   2. Goldfarb-Idnani dual active set on the LDP.  State: an orthonormal basis Q1 of the active
+//      normals (classical Gram-Schmidt with the DGKS re-orthogonalisation test), the triangular R
+//      and its explicit inverse (no triangular solve on the critical path), Givens chains for
+//      removals.  Two kernels: k_gi_iter - one launch per change, every workgroup prices, the last
+//      one to arrive does the update out of LDS; k_gi_coop - one cooperative launch per QP, the
+//      update itself spread over workgroups that each own a slice of the null space (used from a
+//      null space of 512 on; DESIGN.md section 9 has the measurements behind that threshold).
 //   3. Product-form BFGS on the factor: Z <- Z - s (v'Z)/alpha.
 //
 // Reductions run in a fixed order: results are bit-reproducible from run to run.

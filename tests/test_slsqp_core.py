@@ -456,3 +456,24 @@ def test_unknown_sqp_core_is_rejected_before_any_work():
     prob, obj = problems.build("brachistochrone")
     with pytest.raises(ValueError, match="sqp_core"):
         prob.solve(obj, sqp_core="cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("update", ["single", "coop"])
+def test_sqp_core_is_bit_reproducible_from_run_to_run(update, monkeypatch):
+    """All reductions of the SQP kernels run in a fixed order (the cooperative kernel's partial sums are
+    gathered in workgroup order, ties in the elections go to the lower index): two runs of the same solve
+    give the same bits."""
+    from opengoddard_amd import sqp
+    from opengoddard_amd.engine import HipEngine
+    monkeypatch.setenv("OGSQP_GI", update)
+    runs = []
+    for _ in range(2):
+        prob, obj = problems.build("polar_tsto_shipped")
+        eng = HipEngine(prob, obj)
+        lb, ub = np_path.bounds_arrays(prob)
+        res = sqp.minimize_slsqp_hip(eng, prob.p.copy(), lb, ub, ftol=1e-6, maxiter=12)
+        runs.append((res.x.copy(), res.fun, res.nfev, res.timing["qp_iterations"]))
+        eng.close()
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert runs[0][1:] == runs[1][1:]

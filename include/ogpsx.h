@@ -97,6 +97,16 @@ int og_fd_columns_dev(og_handle h, const double* d_x, const double* d_hstep,
                       int32_t col_lo, int32_t col_hi, double* d_JT, const double* d_F0,
                       void* hip_stream);
 
+/* ---- exact Jacobian (opt-in, changes the numbers SLSQP sees) ---
+ * Same layout as the sweep: JT[(j - col_lo) * m + r] = dF_r/dx_j, but by forward-mode
+ * differentiation of the traced callbacks (no step h, no subtraction, no FD noise; where a callback
+ * is not differentiable - np.where / maximum at the switch, a table knot - the derivative of the
+ * branch F(x) itself takes).  Replaces the same 3n+2 evaluations of `approx_derivative`
+ * (`scipy/optimize/_slsqp_py.py:299-313`) as og_fd_sweep; F0 as there. */
+int og_jacobian_exact(og_handle h, const double* x, int32_t col_lo, int32_t col_hi, double* JT, double* F0);
+int og_jacobian_exact_dev(og_handle h, const double* d_x, int32_t col_lo, int32_t col_hi, double* d_JT,
+                          double* d_F0, void* hip_stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 const char* og_last_error(void);
 int og_device_count(void);     /* HIP devices visible to the library (0 without a GPU) */

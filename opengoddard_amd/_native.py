@@ -44,6 +44,9 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_fd_columns_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_jacobian_exact": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p]),
+    "og_jacobian_exact_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "og_last_error": (C.c_char_p, []),
     "og_device_count": (C.c_int, []),
 }

@@ -65,7 +65,7 @@ def _core_sources():
 
 
 def _kernel_sources():
-    return [os.path.join(CSRC, f) for f in ("ogk_kernels.hip", "ogk.h", "og_math.h")]
+    return [os.path.join(CSRC, f) for f in ("ogk_kernels.hip", "ogk.h", "og_math.h", "og_dual.h")]
 
 
 def build_core(force=False):

@@ -529,7 +529,7 @@ class _Emitter:
             node = eg.nodes[e]
             tag = node[0]
             name = "t%d" % e
-            ctype = "const double"
+            ctype = "const S"
             if tag == "P":
                 rhs = "x(%s)" % self._idx(node[1], node[2], var)
             elif tag == "C":
@@ -595,7 +595,7 @@ class _Emitter:
             node = self.eg.nodes[e]
             name = "t%d" % e
             # Python's sum(): 0 + v[0] + v[1] + ... left to right
-            lines.append("%sdouble %s = 0.0;" % (pad, name))
+            lines.append("%sS %s = 0.0;" % (pad, name))
             for ln, body in node[1]:
                 if self._collect_sums([body]):
                     raise _tr.TraceError("nested sums are not supported")
@@ -613,7 +613,8 @@ class _Emitter:
         if grp.kind == "defect":
             # T_s = (tf-t0)/2 * f_s at node k; the defect is  y[s] - T_s
             lines = ["    template <class X> OG_HDI static void tail%d(const int k, const X& x, "
-                     "const double* cv, double* T) {" % gi,
+                     "const double* cv, typename X::scalar* T) {" % gi,
+                     "        typedef typename X::scalar S;",
                      "        (void)k; (void)cv;"]
             names = {}
             self._emit_sums(grp.tails, lines, names, 8)
@@ -622,23 +623,25 @@ class _Emitter:
                 lines.append("        T[%d] = %s;" % (s, names[e]))
             lines.append("    }")
             for si, e in enumerate(grp.tails):       # one state's term alone: a short chain
-                lines += ["    template <class X> OG_HDI static double tail%d_%d(const int k, "
+                lines += ["    template <class X> OG_HDI static typename X::scalar tail%d_%d(const int k, "
                           "const X& x, const double* cv) {" % (gi, si),
+                          "        typedef typename X::scalar S;",
                           "        (void)k; (void)cv;"]
                 nm = {}
                 self._emit_sums([e], lines, nm, 8)
                 self._emit_expr([e], "k", lines, nm, 8, {})
                 lines += ["        return %s;" % nm[e], "    }"]
             lines += ["    template <class X> OG_HDI static void group%d(const int k, const X& x, "
-                      "const double* y, const double* cv, double* out) {" % gi,
-                      "        double T[%d];" % len(grp.tails),
+                      "const typename X::scalar* y, const double* cv, typename X::scalar* out) {" % gi,
+                      "        typename X::scalar T[%d];" % len(grp.tails),
                       "        tail%d(k, x, cv, T);" % gi]
             for s in range(len(grp.tails)):
                 lines.append("        out[%d] = y[%d] - T[%d];" % (s, s, s))
             lines.append("    }")
             return lines
         lines = ["    template <class X> OG_HDI static void group%d(const int k, const X& x, "
-                 "const double* y, const double* cv, double* out) {" % gi,
+                 "const typename X::scalar* y, const double* cv, typename X::scalar* out) {" % gi,
+                 "        typedef typename X::scalar S;",
                  "        (void)k; (void)y; (void)cv;"]
         names = {}
         roots = [e for _, e in grp.outputs]
@@ -650,8 +653,9 @@ class _Emitter:
         return lines
 
     def operand_function(self):
-        lines = ["    template <class X> OG_HD static double mv_operand(const int slot, "
+        lines = ["    template <class X> OG_HD static typename X::scalar mv_operand(const int slot, "
                  "const int k, const X& x, const double* cv) {",
+                 "        typedef typename X::scalar S;",
                  "        (void)cv;",
                  "        switch (slot) {"]
         for si, slot in enumerate(self.P.mv):
@@ -786,15 +790,16 @@ def emit_header(P):
     L += em.operand_function()
     L.append("")
     L.append("    template <class X> OG_HDI static void defect_tail(const int g, const int k, "
-             "const X& x, const double* cv, double* T) {")
+             "const X& x, const double* cv, typename X::scalar* T) {")
     L.append("        switch (g) {")
     for gi, g in enumerate(P.groups):
         if g.kind == "defect":
             L.append("        case %d: tail%d(k, x, cv, T); break;" % (gi, gi))
     L += ["        default: break;", "        }", "    }", ""]
     # one J_T entry's worth of work: value of output o of group g at element k, and its row
-    L.append("    template <class X> OG_HDI static double item_value(const int g, const int o, "
+    L.append("    template <class X> OG_HDI static typename X::scalar item_value(const int g, const int o, "
              "const int k, const X& x, const double* y0, const double* cv, int* row) {")
+    L.append("        typedef typename X::scalar S;")
     L.append("        (void)o; (void)y0;")
     L.append("        switch (g) {")
     for gi, g in enumerate(P.groups):
@@ -802,27 +807,27 @@ def emit_header(P):
         if g.kind == "defect":
             L.append("            switch (o) {")
             for si in range(len(g.tails)):
-                L.append("            case %d: *row = %d + k; return y0[%d + k] - tail%d_%d(k, x, cv);"
+                L.append("            case %d: *row = %d + k; return S(y0[%d + k]) - tail%d_%d(k, x, cv);"
                          % (si, g.outputs[si][0], y0_off[g.mv_slots[si]], gi, si))
             L += ["            default: break;", "            }", "            break;"]
         else:
-            L += ["            double out[%d];" % len(g.outputs),
+            L += ["            S out[%d];" % len(g.outputs),
                   "            group%d(k, x, nullptr, cv, out);" % gi,
                   "            *row = %d + k; return out[0];" % g.outputs[0][0]]
             if len(g.outputs) != 1:
                 raise _tr.TraceError("row groups must have one output (OG_MAX_GROUP_OUTPUTS=1)")
         L.append("        }")
-    L += ["        default: break;", "        }", "        *row = 0;", "        return 0.0;", "    }", ""]
+    L += ["        default: break;", "        }", "        *row = 0;", "        return S(0.0);", "    }", ""]
     # the dynamics term of one collocation slot (one state) at node k
-    L.append("    template <class X> OG_HDI static double tail_one(const int slot, const int k, "
+    L.append("    template <class X> OG_HDI static typename X::scalar tail_one(const int slot, const int k, "
              "const X& x, const double* cv) {")
     L.append("        switch (slot) {")
     for gi, g in enumerate(P.groups):
         for si, sl in enumerate(g.mv_slots):
             L.append("        case %d: return tail%d_%d(k, x, cv);" % (sl, gi, si))
-    L += ["        default: return 0.0;", "        }", "    }", ""]
+    L += ["        default: return typename X::scalar(0.0);", "        }", "    }", ""]
     L.append("    template <class X> OG_HDI static void group_eval(const int g, const int k, "
-             "const X& x, const double* y, const double* cv, double* out) {")
+             "const X& x, const typename X::scalar* y, const double* cv, typename X::scalar* out) {")
     L.append("        switch (g) {")
     for gi in range(len(P.groups)):
         L.append("        case %d: group%d(k, x, y, cv, out); break;" % (gi, gi))

@@ -1,0 +1,111 @@
+// og_dual.h - first-order dual numbers for the exact-Jacobian mode.
+//
+// The generated callback code (codegen.emit_header) is written against `typename X::scalar`: with the
+// accessor types of the FD sweep the scalar is `double` and nothing changes, bit for bit; with an
+// accessor that returns `ogdual` (value, derivative along one decision variable) the very same
+// functions propagate exact first derivatives.  Every rule below is the textbook one; the value
+// parts use the same og_math.h functions as the FD path, so F(x) is identical in both modes.
+//
+// Same source for hipcc (device) and g++ (the CPU twin): GPU and twin derivatives agree bit for
+// bit, like the values do.
+#ifndef OG_DUAL_H
+#define OG_DUAL_H
+
+#include "og_math.h"
+
+struct ogdual {
+    double v, d;
+    OG_HDI ogdual() : v(0.0), d(0.0) {}
+    OG_HDI ogdual(const double value) : v(value), d(0.0) {}
+    OG_HDI ogdual(const double value, const double deriv) : v(value), d(deriv) {}
+};
+
+OG_HDI ogdual operator-(const ogdual a) { return ogdual(-a.v, -a.d); }
+OG_HDI ogdual operator+(const ogdual a, const ogdual b) { return ogdual(a.v + b.v, a.d + b.d); }
+OG_HDI ogdual operator-(const ogdual a, const ogdual b) { return ogdual(a.v - b.v, a.d - b.d); }
+OG_HDI ogdual operator*(const ogdual a, const ogdual b) { return ogdual(a.v * b.v, a.d * b.v + a.v * b.d); }
+OG_HDI ogdual operator/(const ogdual a, const ogdual b) {
+    const double q = a.v / b.v;
+    return ogdual(q, (a.d == 0.0 && b.d == 0.0) ? 0.0 : (a.d - q * b.d) / b.v);
+}
+OG_HDI ogdual operator+(const ogdual a, const double b) { return ogdual(a.v + b, a.d); }
+OG_HDI ogdual operator+(const double a, const ogdual b) { return ogdual(a + b.v, b.d); }
+OG_HDI ogdual operator-(const ogdual a, const double b) { return ogdual(a.v - b, a.d); }
+OG_HDI ogdual operator-(const double a, const ogdual b) { return ogdual(a - b.v, -b.d); }
+OG_HDI ogdual operator*(const ogdual a, const double b) { return ogdual(a.v * b, a.d * b); }
+OG_HDI ogdual operator*(const double a, const ogdual b) { return ogdual(a * b.v, a * b.d); }
+OG_HDI ogdual operator/(const ogdual a, const double b) { return ogdual(a.v / b, a.d / b); }
+OG_HDI ogdual operator/(const double a, const ogdual b) {
+    const double q = a / b.v;
+    return ogdual(q, -(q * b.d) / b.v);
+}
+
+#define OG_DUAL_CMP(op)                                                          \
+    OG_HDI bool operator op(const ogdual a, const ogdual b) { return a.v op b.v; } \
+    OG_HDI bool operator op(const ogdual a, const double b) { return a.v op b; }   \
+    OG_HDI bool operator op(const double a, const ogdual b) { return a op b.v; }
+OG_DUAL_CMP(<)
+OG_DUAL_CMP(<=)
+OG_DUAL_CMP(>)
+OG_DUAL_CMP(>=)
+OG_DUAL_CMP(==)
+OG_DUAL_CMP(!=)
+#undef OG_DUAL_CMP
+
+namespace ogm {
+
+// (a quantity that does not depend on the seeded variable keeps derivative 0 through a singular
+// rule - sqrt at 0, log at 0, asin at 1 - instead of 0/0; a forward difference sees 0 there too)
+OG_HDI ogdual sqrt_(const ogdual a) {
+    const double r = sqrt_(a.v);
+    return ogdual(r, a.d == 0.0 ? 0.0 : a.d / (2.0 * r));
+}
+OG_HDI ogdual exp_(const ogdual a) {
+    const double e = exp_(a.v);
+    return ogdual(e, a.d * e);
+}
+OG_HDI ogdual log_(const ogdual a) { return ogdual(log_(a.v), a.d == 0.0 ? 0.0 : a.d / a.v); }
+OG_HDI ogdual sin_(const ogdual a) { return ogdual(sin_(a.v), a.d * cos_(a.v)); }
+OG_HDI ogdual cos_(const ogdual a) { return ogdual(cos_(a.v), -(a.d * sin_(a.v))); }
+OG_HDI ogdual tan_(const ogdual a) {
+    const double t = tan_(a.v);
+    return ogdual(t, a.d * (1.0 + t * t));
+}
+OG_HDI ogdual fabs_(const ogdual a) {
+    // d|x|/dx = sign(x); 0 at the kink (NumPy's sign(0)), where a one-sided difference sees +-1
+    const double s = a.v > 0.0 ? 1.0 : (a.v < 0.0 ? -1.0 : 0.0);
+    return ogdual(fabs_(a.v), s * a.d);
+}
+OG_HDI ogdual atan_(const ogdual a) { return ogdual(atan_(a.v), a.d / (1.0 + a.v * a.v)); }
+OG_HDI ogdual asin_(const ogdual a) {
+    return ogdual(asin_(a.v), a.d == 0.0 ? 0.0 : a.d / sqrt_(1.0 - a.v * a.v));
+}
+OG_HDI ogdual acos_(const ogdual a) {
+    return ogdual(acos_(a.v), a.d == 0.0 ? 0.0 : -(a.d / sqrt_(1.0 - a.v * a.v)));
+}
+OG_HDI ogdual atan2_(const ogdual y, const ogdual x) {
+    return ogdual(atan2_(y.v, x.v),
+                  (y.d == 0.0 && x.d == 0.0) ? 0.0 : (x.v * y.d - y.v * x.d) / (x.v * x.v + y.v * y.v));
+}
+OG_HDI ogdual atan2_(const ogdual y, const double x) { return atan2_(y, ogdual(x)); }
+OG_HDI ogdual atan2_(const double y, const ogdual x) { return atan2_(ogdual(y), x); }
+
+// Piecewise-linear table: the derivative is the slope of the segment the value came from (the
+// segment to the right at a knot, like the forward difference sees it), 0 on the constant fills.
+OG_HD ogdual interp_linear(const double* xg, const double* yg, const int n, const int mode, const double fill_below,
+                           const double fill_above, const ogdual x) {
+    const double y = interp_linear(xg, yg, n, mode, fill_below, fill_above, x.v);
+    int lo = 0, hi = n;
+    while (lo < hi) {                         // first index with xg[index] > x  (right-hand segment at a knot)
+        const int mid = (lo + hi) >> 1;
+        if (xg[mid] <= x.v) lo = mid + 1; else hi = mid;
+    }
+    const int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    double slope = (yg[i] - yg[i - 1]) / (xg[i] - xg[i - 1]);
+    if (mode != 1 && (x.v < xg[0] || x.v > xg[n - 1])) slope = 0.0;
+    return ogdual(y, slope * x.d);
+}
+
+}  // namespace ogm
+
+#endif /* OG_DUAL_H */

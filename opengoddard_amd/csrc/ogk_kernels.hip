@@ -42,6 +42,7 @@
 // tools/gpu_probe.hip), identical to oracle/twin.cpp's loop.
 #include <hip/hip_runtime.h>
 #include "ogk.h"
+#include "og_dual.h"
 #include OG_GEN_HEADER
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -62,6 +63,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 namespace {
 
 struct XCol {
+    typedef double scalar;
     const double* x0;
     int j;          // perturbed index, -1 for none
     double xj;      // x0[j] + h[j]
@@ -221,6 +223,87 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
     } else {
         const int rid = id - defect_total;
         dense_rows_body(a, rid % row_blocks, rid / row_blocks);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mode 3, exact Jacobian: the generated callback code instantiated on
+// first-order dual numbers (og_dual.h) with a unit seed on decision variable j gives dF/dx_j without
+// a step, a subtraction or FD noise.  One thread per (column j, row item): a row-group element, or a
+// collocation node of a defect group, where the derivative of the product D.x~ is one column of D
+// times the derivative of the operand the seeded variable feeds (if it is a state of that phase).
+// F(x0) and the base products come from mode 0 (same stream, before).  Dense and simple: exactness
+// changes the numbers SLSQP sees (it removes the 1e-8 noise of the reference's differences), so this
+// is an opt-in mode next to the reference-faithful sweep, not a replacement for it.
+struct XDual {
+    typedef ogdual scalar;
+    const double* x0;
+    int j;
+    __device__ __forceinline__ ogdual operator()(const int i) const { return ogdual(x0[i], i == j ? 1.0 : 0.0); }
+};
+
+__device__ __forceinline__ double dfrag_entry(const ogk_args& a, const int phase, const int N, const int k,
+                                              const int l) {
+    const int KS = (N + 3) >> 2;
+    return a.dfrag[a.dfrag_off[phase] + ((long)(k >> 4) * KS + (l >> 2)) * 64 + (((l & 3) << 4) | (k & 15))];
+}
+
+__global__ __launch_bounds__(256) void ogk_exact(const ogk_args a, const int n_items) {
+    const int item = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int j = a.col_lo + (int)blockIdx.y;
+    if (item >= n_items || j >= a.col_hi) return;
+    // item -> (group, element): row-group items first (G_ITEM0 order), then the defect nodes
+    int g = 0, k = -1;
+    if (item < OgGen::N_ROW_ITEMS) {
+        for (; g < OgGen::N_GROUPS; ++g) {
+            if (OgGen::G_KIND(g) != 0) continue;
+            const int i0 = OgGen::G_ITEM0(g);
+            if (item >= i0 && item < i0 + OgGen::G_LEN(g)) {
+                k = item - i0;
+                break;
+            }
+        }
+    } else {
+        int rest = item - OgGen::N_ROW_ITEMS;
+        for (; g < OgGen::N_GROUPS; ++g) {
+            if (OgGen::G_KIND(g) != 1) continue;
+            if (rest < OgGen::G_LEN(g)) {
+                k = rest;
+                break;
+            }
+            rest -= OgGen::G_LEN(g);
+        }
+    }
+    if (k < 0) return;
+    const XDual xd{a.x0, j};
+    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+    ogdual out[OgGen::MAX_OUT > OgGen::MAX_NMV ? OgGen::MAX_OUT : OgGen::MAX_NMV];
+    const int nout = OgGen::G_NOUT(g);
+    if (OgGen::G_KIND(g) == 0) {
+        OgGen::group_eval(g, k, xd, (const ogdual*)nullptr, a.cvec, out);
+    } else {
+        const int N = OgGen::G_LEN(g), phase = OgGen::G_PHASE(g), mv0 = OgGen::G_MV0(g), nmv = OgGen::G_NMV(g);
+        ogdual y[OgGen::MAX_NMV];
+#pragma unroll
+        for (int s = 0; s < OgGen::MAX_NMV; ++s) {
+            y[s] = ogdual(0.0);
+            if (s < nmv) {
+                double dy = 0.0;
+                const int leaf = OgGen::MV_LEAF(mv0 + s);
+                if (j >= leaf && j < leaf + N) {        // x_j is node l of the state behind this product
+                    const int l = j - leaf;
+                    const ogdual op = OgGen::mv_operand(mv0 + s, l, xd, a.cvec);
+                    dy = __builtin_fma(op.d, dfrag_entry(a, phase, N, k, l), 0.0);
+                }
+                y[s] = ogdual(a.y0[OgGen::MV_Y0(mv0 + s) + k], dy);
+            }
+        }
+        OgGen::group_eval(g, k, xd, (const ogdual*)y, a.cvec, out);
+    }
+#pragma unroll
+    for (int o = 0; o < (OgGen::MAX_OUT > OgGen::MAX_NMV ? OgGen::MAX_OUT : OgGen::MAX_NMV); ++o) {
+        if (o >= nout) break;
+        jrow[OgGen::G_ROW(g, o) + k] = out[o].d;
     }
 }
 
@@ -709,6 +792,14 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         const int light_blocks = (ncols + LIGHT_COLS - 1) / LIGHT_COLS;
         hipLaunchKernelGGL(ogk_sweep, dim3(OGT_N_TILES + OgGen::N_HEAVY + light_blocks),
                            dim3(SWEEP_THREADS), sweep_lds_bytes(), stream, *args);
+        return (int)hipGetLastError();
+    }
+    if (mode == 3) {
+        int n_items = OgGen::N_ROW_ITEMS;
+        for (int g = 0; g < OgGen::N_GROUPS; ++g)
+            if (OgGen::G_KIND(g) == 1) n_items += OgGen::G_LEN(g);
+        if (n_items > 0)
+            hipLaunchKernelGGL(ogk_exact, dim3((n_items + 255) / 256, ncols), dim3(256), 0, stream, *args, n_items);
         return (int)hipGetLastError();
     }
     const int defect_total = ndef * ((ncols + 63) / 64);

@@ -346,6 +346,19 @@ int og_fd_columns_dev(og_handle p, const double* d_x, const double* d_h, int32_t
     return 0;
 }
 
+int og_jacobian_exact_dev(og_handle p, const double* d_x, int32_t lo, int32_t hi, double* d_JT, double* d_F0,
+                          void* hip_stream) {
+    if (!p || !d_x || !d_JT || !d_F0) return fail(1, "og_jacobian_exact_dev: null argument");
+    if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_jacobian_exact_dev: bad column range");
+    ogk_args a;
+    p->flag_slot ^= 1;
+    fill_args(p, &a, d_x, nullptr, d_F0, d_JT, lo, hi);
+    int rc = p->launch(&a, 0, hip_stream);          // F(x0) and the base collocation products
+    if (!rc) rc = p->launch(&a, 3, hip_stream);     // forward-mode derivatives, column by column
+    if (rc) return fail(100 + rc, std::string("og_jacobian_exact_dev: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
 int og_eval(og_handle p, const double* x, double* F) {
     if (!p || !x || !F) return fail(1, "og_eval: null argument");
     OG_HIP(hipSetDevice(p->device));
@@ -382,6 +395,31 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
         OG_HIP(hipMemcpyAsync(JT, p->d_jt, sizeof(double) * need, hipMemcpyDeviceToHost, p->stream));
     if (F0)
         OG_HIP(hipMemcpyAsync(F0, p->d_f0, sizeof(double) * p->m, hipMemcpyDeviceToHost, p->stream));
+    OG_HIP(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int og_jacobian_exact(og_handle p, const double* x, int32_t lo, int32_t hi, double* JT, double* F0) {
+    if (!p || !x || !JT) return fail(1, "og_jacobian_exact: null argument");
+    if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_jacobian_exact: bad column range");
+    OG_HIP(hipSetDevice(p->device));
+    const size_t need = (size_t)(hi - lo) * (size_t)p->m;
+    if (need == 0) {
+        if (!F0) return 0;
+        return og_eval(p, x, F0);
+    }
+    if (need > p->jt_capacity) {
+        if (p->d_jt) OG_HIP(hipFree(p->d_jt));
+        p->d_jt = nullptr;
+        p->jt_capacity = 0;
+        OG_HIP(hipMalloc(&p->d_jt, sizeof(double) * need));
+        p->jt_capacity = need;
+    }
+    OG_HIP(hipMemcpyAsync(p->d_x, x, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
+    int rc = og_jacobian_exact_dev(p, p->d_x, lo, hi, p->d_jt, p->d_f0, p->stream);
+    if (rc) return rc;
+    OG_HIP(hipMemcpyAsync(JT, p->d_jt, sizeof(double) * need, hipMemcpyDeviceToHost, p->stream));
+    if (F0) OG_HIP(hipMemcpyAsync(F0, p->d_f0, sizeof(double) * p->m, hipMemcpyDeviceToHost, p->stream));
     OG_HIP(hipStreamSynchronize(p->stream));
     return 0;
 }

@@ -94,6 +94,20 @@ class HipEngine:
                                             _native.dptr(F0)), "og_fd_sweep")
         return F0, JT
 
+    def exact_stacked(self, x, col_lo=0, col_hi=None):
+        """(F0, JT) with JT[(j - col_lo), r] = dF_r/dx_j by forward-mode differentiation on the GPU."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        col_hi = self.n if col_hi is None else int(col_hi)
+        F0 = np.empty(self.m)
+        JT = np.empty((col_hi - col_lo, self.m))
+        _native.check(self._lib.og_jacobian_exact(self._handle, _native.dptr(x), int(col_lo), col_hi,
+                                                  _native.dptr(JT), _native.dptr(F0)), "og_jacobian_exact")
+        return F0, JT
+
+    def exact_dev(self, d_x, col_lo, col_hi, d_JT, d_F0, stream=0):
+        _native.check(self._lib.og_jacobian_exact_dev(self._handle, d_x, int(col_lo), int(col_hi), d_JT, d_F0,
+                                                      stream), "og_jacobian_exact_dev")
+
     def eval_dev(self, d_x, d_F, stream=0):
         _native.check(self._lib.og_eval_dev(self._handle, d_x, d_F, stream), "og_eval_dev")
 

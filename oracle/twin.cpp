@@ -19,46 +19,65 @@
 #include <cstring>
 #include <vector>
 
+#include "og_dual.h"
 #include OG_GEN_HEADER
 
 namespace {
 
 struct XVec {
+    typedef double scalar;
     const double* x;
     double operator()(const int i) const { return x[i]; }
 };
 
-void eval_into(const double* x, const double* const* D, const double* cv, double* F) {
-    const XVec xa{x};
-    double out[OgGen::MAX_OUT];
+// one decision variable carries a unit derivative: F evaluated on it yields dF/dx_j exactly
+struct XDual {
+    typedef ogdual scalar;
+    const double* x;
+    int j;
+    ogdual operator()(const int i) const { return ogdual(x[i], i == j ? 1.0 : 0.0); }
+};
+
+inline double fma_chain(const double a, const double b, const double acc) { return __builtin_fma(a, b, acc); }
+inline ogdual fma_chain(const ogdual a, const double b, const ogdual acc) {
+    return ogdual(__builtin_fma(a.v, b, acc.v), __builtin_fma(a.d, b, acc.d));
+}
+
+template <class XA>
+void eval_generic(const XA& xa, const double* const* D, const double* cv, typename XA::scalar* F) {
+    typedef typename XA::scalar S;
+    S out[OgGen::MAX_OUT];
     for (int g = 0; g < OgGen::N_GROUPS; ++g) {
         const int L = OgGen::G_LEN(g), nout = OgGen::G_NOUT(g);
         if (OgGen::G_KIND(g) == 0) {
             for (int k = 0; k < L; ++k) {
-                OgGen::group_eval(g, k, xa, nullptr, cv, out);
+                OgGen::group_eval(g, k, xa, (const S*)nullptr, cv, out);
                 for (int o = 0; o < nout; ++o) F[OgGen::G_ROW(g, o) + k] = out[o];
             }
             continue;
         }
         const int phase = OgGen::G_PHASE(g), mv0 = OgGen::G_MV0(g), nmv = OgGen::G_NMV(g);
         const double* Dp = D[phase];
-        std::vector<double> operand((size_t)nmv * L), y((size_t)nmv * L);
+        std::vector<S> operand((size_t)nmv * L), y((size_t)nmv * L);
         for (int s = 0; s < nmv; ++s)
             for (int l = 0; l < L; ++l) operand[(size_t)s * L + l] = OgGen::mv_operand(mv0 + s, l, xa, cv);
         for (int s = 0; s < nmv; ++s)
             for (int k = 0; k < L; ++k) {
-                double acc = 0.0;
-                for (int l = 0; l < L; ++l)
-                    acc = __builtin_fma(operand[(size_t)s * L + l], Dp[(size_t)k * L + l], acc);
+                S acc = S(0.0);
+                for (int l = 0; l < L; ++l) acc = fma_chain(operand[(size_t)s * L + l], Dp[(size_t)k * L + l], acc);
                 y[(size_t)s * L + k] = acc;
             }
-        double yk[OgGen::MAX_NMV];
+        S yk[OgGen::MAX_NMV];
         for (int k = 0; k < L; ++k) {
             for (int s = 0; s < nmv; ++s) yk[s] = y[(size_t)s * L + k];
-            OgGen::group_eval(g, k, xa, yk, cv, out);
+            OgGen::group_eval(g, k, xa, (const S*)yk, cv, out);
             for (int o = 0; o < nout; ++o) F[OgGen::G_ROW(g, o) + k] = out[o];
         }
     }
+}
+
+void eval_into(const double* x, const double* const* D, const double* cv, double* F) {
+    eval_generic(XVec{x}, D, cv, F);
 }
 
 }  // namespace
@@ -89,6 +108,18 @@ void twin_sweep(const double* x, const double* h, const double* const* D, const 
         eval_into(x1.data(), D, cv, F1.data());
         for (int q = 0; q < m; ++q) JT[(size_t)r * m + q] = (F1[q] - F0[q]) / dx;
         x1[i] = x[i];
+    }
+}
+
+// Exact Jacobian (forward-mode derivatives of the same generated code): JT row r = dF/dx_{cols[r]}.
+void twin_exact(const double* x, const double* const* D, const double* cv, const int* cols, int ncols,
+                double* F0, double* JT) {
+    const int m = OgGen::M;
+    eval_into(x, D, cv, F0);
+    std::vector<ogdual> F1(m);
+    for (int r = 0; r < ncols; ++r) {
+        eval_generic(XDual{x, cols[r]}, D, cv, F1.data());
+        for (int q = 0; q < m; ++q) JT[(size_t)r * m + q] = F1[q].d;
     }
 }
 

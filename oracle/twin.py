@@ -25,7 +25,7 @@ def build_twin(header_source, digest=None, force=False):
     os.makedirs(BUILD, exist_ok=True)
     src = os.path.join(HERE, "twin.cpp")
     hsh = hashlib.sha256(header_source.encode())
-    for path in (src, os.path.join(CSRC, "og_math.h")):
+    for path in (src, os.path.join(CSRC, "og_math.h"), os.path.join(CSRC, "og_dual.h")):
         with open(path, "rb") as fh:
             hsh.update(fh.read())
     hsh.update(" ".join(CXX_FLAGS).encode())
@@ -80,4 +80,16 @@ class Twin:
         self.lib.twin_sweep(x.ctypes.data_as(_dp), h.ctypes.data_as(_dp), self._Dptr,
                             self._cv.ctypes.data_as(_dp), cols.ctypes.data_as(C.POINTER(C.c_int)),
                             int(cols.size), F0.ctypes.data_as(_dp), JT.ctypes.data_as(_dp))
+        return F0, JT
+
+    def exact(self, x, cols=None):
+        """(F0, JT) with JT[r] = dF/dx_cols[r]: forward-mode derivatives of the generated code."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        cols = np.arange(self.n, dtype=np.int32) if cols is None else \
+            np.ascontiguousarray(cols, dtype=np.int32)
+        F0 = np.empty(self.m)
+        JT = np.empty((cols.size, self.m))
+        self.lib.twin_exact(x.ctypes.data_as(_dp), self._Dptr, self._cv.ctypes.data_as(_dp),
+                            cols.ctypes.data_as(C.POINTER(C.c_int)), int(cols.size),
+                            F0.ctypes.data_as(_dp), JT.ctypes.data_as(_dp))
         return F0, JT

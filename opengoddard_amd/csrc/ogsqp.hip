@@ -52,8 +52,9 @@ int fail(int code, const std::string& msg) {
 
 constexpr double DEPENDENT = 1e-10;   // |projection| / |normal| below this: linearly dependent
 constexpr double FEASIBLE = 1e-12;    // rounding level of a normalised constraint value
-constexpr double SINGULAR_C = 1e-14;  // |L_kk| <= this * max(1, max |L_jj|): C rank deficient to rounding
-                                      // (lsei: ABS(C(I,I)) < EPMACH -> mode 6)
+constexpr double SINGULAR_C = 2.220446049250313e-16;  // lsei's own test: ABS(C(I,I)) < EPMACH -> mode 6.  Absolute,
+                                                      // like there: a rank deficiency that rounding leaves at 1e-14
+                                                      // passes (and yields the same wild step SciPy takes)
 constexpr int REFINE = 3;             // at most this many re-orthogonalisation passes (one is the rule)
 constexpr double REORTH = 1e-8;       // another pass while the last correction exceeds this, relative
 constexpr int GI_THREADS = 1024;
@@ -582,7 +583,8 @@ __global__ void k_check_diag(const double* diagL, int meq, int* flag) {
             mx = fmax(mx, red[w]);
             mn = fmin(mn, red2[w]);
         }
-        flag[0] = (meq > 0 && !(mn > SINGULAR_C * fmax(mx, 1.0))) ? 1 : 0;
+        (void)mx;
+        flag[0] = (meq > 0 && !(mn >= SINGULAR_C)) ? 1 : 0;
     }
 }
 

@@ -22,6 +22,8 @@ from . import _native, build, codegen
 
 
 class HipEngine:
+    jacobian_mode = "fd"        # "fd": SciPy's forward differences (the reference); "exact": forward-mode AD
+
     def __init__(self, prob, obj, device=0, program=None):
         lib = _native.lib()
         if _native.device_count() < 1:
@@ -137,8 +139,11 @@ class HipEngine:
         """((grad, J_eq, J_ineq), h) at ``p``; one sweep serves all three SLSQP requests."""
         key = np.asarray(p, dtype=np.float64).tobytes()
         if key != self._jac_key:
-            h = _native.fd_step(p, lb, ub)
-            F0, JT = self.sweep_stacked(p, h)
+            h = _native.fd_step(p, lb, ub)           # (also in exact mode: quirk Q13 needs the last step)
+            if self.jacobian_mode == "exact":
+                F0, JT = self.exact_stacked(p)
+            else:
+                F0, JT = self.sweep_stacked(p, h)
             J = JT.T
             self._jac = ((np.ascontiguousarray(J[0]), J[1:1 + self.m_eq], J[1 + self.m_eq:]), h)
             self._jac_key = key

@@ -380,7 +380,10 @@ class Problem:
     def solve(self, obj, display_func=_noop, **options):
         """Run the SLSQP restart loop (``optimize.py:649-755``) with GPU-evaluated callbacks.
 
-        Options honoured are the reference's: ``ftol`` (1e-6) and ``maxiter`` (25).  Cost,
+        Options honoured are the reference's: ``ftol`` (1e-6) and ``maxiter`` (25); two more select what
+        the reference does not have: ``sqp_core="hip"`` (QP subproblems on the GPU, sqp.py) and
+        ``jacobian="exact"`` (forward-mode derivatives of the traced callbacks instead of SciPy's
+        forward differences; same optimum, fewer iterations, no FD noise).  Cost,
         equality and inequality values come from a single-column launch of the sweep kernel;
         the three Jacobians SLSQP asks for at each major iteration come from one
         forward-difference sweep over all ``n`` decision-vector columns, with SciPy's step
@@ -398,8 +401,16 @@ class Problem:
         if core not in ("scipy", "hip"):
             raise ValueError("sqp_core must be 'scipy' or 'hip', got %r" % (core,))
 
+        jacobian = options.pop("jacobian", None) or os.environ.get("OG_JACOBIAN", "fd")
+        if jacobian not in ("fd", "exact"):
+            raise ValueError("jacobian must be 'fd' or 'exact', got %r" % (jacobian,))
+
         engine = (ENGINE_FACTORY or _default_engine)(self, obj)
         self._engine = engine
+        if jacobian == "exact":
+            if not hasattr(engine, "exact_stacked"):
+                raise ValueError("this engine has no exact-Jacobian mode")
+            engine.jacobian_mode = "exact"
         lb = np.array([-np.inf if b[0] is None else b[0] for b in self.bounds], dtype=float)
         ub = np.array([np.inf if b[1] is None else b[1] for b in self.bounds], dtype=float)
 

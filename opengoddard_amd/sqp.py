@@ -70,9 +70,13 @@ class DeviceJacobian:
         h = _native.fd_step(x, lb, ub)
         self.last_step = h
         self.d_x.copy_(torch.from_numpy(np.ascontiguousarray(x)))
-        self.d_h.copy_(torch.from_numpy(h))
-        self.engine.sweep_dev(self.d_x.data_ptr(), self.d_h.data_ptr(), 0, self.n, self.d_JT.data_ptr(),
-                              self.d_F0.data_ptr(), self.stream)
+        if getattr(self.engine, "jacobian_mode", "fd") == "exact":
+            self.engine.exact_dev(self.d_x.data_ptr(), 0, self.n, self.d_JT.data_ptr(), self.d_F0.data_ptr(),
+                                  self.stream)
+        else:
+            self.d_h.copy_(torch.from_numpy(h))
+            self.engine.sweep_dev(self.d_x.data_ptr(), self.d_h.data_ptr(), 0, self.n, self.d_JT.data_ptr(),
+                                  self.d_F0.data_ptr(), self.stream)
         return self.d_F0.cpu().numpy()
 
     @property

@@ -37,7 +37,7 @@ EXIT_MODES = {0: "Optimization terminated successfully",
 
 DEPENDENT = 1e-10        # |component outside the active normals| / |normal| below this -> dependent
 FEASIBLE = 1e-12         # normalised violation below this counts as satisfied
-SINGULAR_C = 1e-14       # |L_kk| <= this * max(1, max|L_jj|) -> rank deficient to rounding (lsei: ABS(C(I,I)) < EPMACH)
+SINGULAR_C = np.finfo(float).eps   # lsei: ABS(C(I,I)) < EPMACH -> mode 6 (an absolute test, as there)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -194,7 +194,7 @@ def qp_solve(Z, g, C, c, G, h, lb, ub):
     L = T[:meq, :meq]                                       # = R', lower triangular
     J = T[meq:]
     diag = np.abs(np.diag(L))
-    if meq and not diag.min() > SINGULAR_C * max(diag.max(), 1.0):
+    if meq and not diag.min() >= SINGULAR_C:
         return np.zeros(n), np.zeros(meq), np.zeros(G.shape[0]), 6, Z, info
     J1, Y = J[:, :meq], J[:, meq:]
     w1 = np.zeros(meq)

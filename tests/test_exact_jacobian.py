@@ -1,0 +1,117 @@
+"""Exact-Jacobian mode: forward-mode derivatives of the traced
+callbacks instead of SciPy's forward differences.
+
+CPU: the C++ twin (generated code instantiated on ``ogdual``) against an independent complex-step
+differentiation of the lowered program in NumPy (machine precision), and against the *reference's
+own* FD Jacobians in ``tests/golden`` (they must agree to the truncation error + noise of a forward
+difference on the smooth configurations).  GPU: ``og_jacobian_exact`` bit for bit against the twin,
+and the two SQP cores, fed noise-free Jacobians, walking the same path."""
+import numpy as np
+import pytest
+
+from opengoddard_amd import _native, codegen, problems
+from oracle import exact_jac, np_path, twin
+
+from conftest import inject_reference_lgl
+
+SMALL = ["brachistochrone", "goddard", "polar_tsto_shipped", "low_thrust_shipped", "table_ascent"]
+SMOOTH = ["brachistochrone", "goddard", "low_thrust_shipped"]      # no np.where / maximum / tables
+
+
+def _points(prob, lb, ub):
+    """The initial guess and a generic point next to it (away from the switches of where/maximum
+    that some initial guesses sit on exactly)."""
+    x0 = np.clip(prob.p, lb, ub)
+    rng = np.random.default_rng(3)
+    x1 = np.clip(x0 * (1.0 + 1e-3 * rng.standard_normal(x0.size)) + 1e-4 * rng.standard_normal(x0.size), lb, ub)
+    return x0, x1
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_twin_exact_jacobian_matches_complex_step(name):
+    prob, obj = problems.build(name)
+    P = codegen.trace_problem(prob, obj)
+    tw = twin.Twin(prob, obj, program=P)
+    lb, ub = np_path.bounds_arrays(prob)
+    cols = np.arange(tw.n, dtype=np.int32)
+    if tw.n > 400:
+        cols = np.unique(np.r_[np.arange(0, tw.n, 7), tw.n - 1]).astype(np.int32)
+    for x in _points(prob, lb, ub):
+        F0, JE = tw.exact(x, cols)
+        assert np.array_equal(F0, tw.values(x))                      # the value parts are the FD path's
+        JC = exact_jac.jacobian(P, prob, x, list(cols))
+        scale = np.maximum(1.0, np.abs(JC).max(axis=0))[None, :]
+        assert np.all(np.isfinite(JE))
+        assert np.max(np.abs(JE - JC) / scale) <= 1e-13
+
+
+@pytest.mark.parametrize("name", SMOOTH)
+def test_exact_jacobian_agrees_with_the_reference_fd_goldens(name, golden, lgl_golden):
+    """The reference's own Jacobians (SciPy forward differences through the reference's callbacks,
+    captured by tools/make_golden.py) equal the exact ones up to what a forward difference can
+    resolve: truncation O(h |f''|) plus the noise bound used for the FD parity tests."""
+    G = golden("cfg_" + name)
+    prob, obj = problems.build(name)
+    inject_reference_lgl(prob, lgl_golden)
+    tw = twin.Twin(prob, obj)
+    cols = G["cols"][:64]
+    for k in range(G["x"].shape[0]):
+        x, h = G["x"][k], G["h"][k]
+        _, JE = tw.exact(x, cols)
+        JTg = G["JT"][k][:64]
+        rowscale = np.maximum(1.0, np.abs(JTg).max(axis=0))[None, :]
+        assert np.max(np.abs(JE - JTg) / rowscale) <= 1e-5           # sqrt(eps)-step forward differences
+        # a structural zero of the FD Jacobian is a structural zero of the exact one
+        assert not np.any((JTg == 0.0) & (np.abs(JE) > 1e-7 * rowscale))
+
+
+def test_jacobian_option_is_validated():
+    prob, obj = problems.build("brachistochrone")
+    with pytest.raises(ValueError, match="jacobian"):
+        prob.solve(obj, jacobian="analytic")
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL + ["polar_tsto"])
+def test_gpu_exact_jacobian_is_bit_identical_to_the_twin(name):
+    from opengoddard_amd.engine import HipEngine
+    prob, obj = problems.build(name)
+    eng = HipEngine(prob, obj)
+    tw = twin.Twin(prob, obj, program=eng.program, header=eng.header)
+    lb, ub = np_path.bounds_arrays(prob)
+    for x in _points(prob, lb, ub):
+        F0, JE = eng.exact_stacked(x)
+        F0c, JEc = tw.exact(x)
+        assert np.array_equal(F0, F0c) and np.array_equal(F0, eng.eval_stacked(x))
+        assert np.array_equal(JE, JEc)
+        lo, hi = eng.n // 3, 2 * eng.n // 3 + 1
+        assert np.array_equal(eng.exact_stacked(x, lo, hi)[1], JEc[lo:hi])          # column ranges
+        # against the FD sweep: same numbers up to the resolution of a forward difference, except where
+        # the callbacks are not differentiable (checked on the smooth configurations only)
+        if name in SMOOTH:
+            _, JF = eng.sweep_stacked(x, _native.fd_step(x, lb, ub))
+            scale = np.maximum(1.0, np.abs(JE).max(axis=0))[None, :]
+            assert np.max(np.abs(JE - JF) / scale) <= 2e-6
+    assert eng.exact_stacked(x, 5, 5)[1].shape == (0, eng.m)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_with_exact_jacobians_both_sqp_cores_walk_the_same_path(capsys):
+    """Free-running (no replay): with noise-free Jacobians SciPy's Fortran core and the HIP core
+    take the same major iterations, the same line-search cuts, and stop at the same point.  With FD
+    Jacobians they cannot (a 1e-13 difference in x becomes 1e-5 in the Jacobian)."""
+    out = {}
+    for core in ("scipy", "hip"):
+        prob, obj = problems.build("goddard")
+        prob.maxIterator = 1
+        prob.solve(obj, maxiter=600, ftol=1e-10, sqp_core=core, jacobian="exact")
+        out[core] = prob.last_result
+    capsys.readouterr()
+    a, b = out["scipy"], out["hip"]
+    assert a.status == b.status == 0
+    assert (a.nit, a.nfev, a.njev) == (b.nit, b.nfev, b.njev)
+    assert abs(a.fun - b.fun) <= 1e-9
+    assert np.max(np.abs(a.x - b.x)) <= 1e-6
+    assert abs(b.fun + 1.01283) <= 2e-5

@@ -262,9 +262,9 @@ def test_gpu_qp_relaxed_incompatible_and_singular_cases(update, monkeypatch):
     assert np.max(np.abs(mult - np.concatenate([lam, mu]))) <= 1e-8 * max(1.0, np.abs(mu).max())
     assert np.array_equal(core.get_factor(), Z)                     # relaxed solves never touch the factor
     core.close()
-    # duplicated equality row: "Singular matrix C in LSQ subproblem"
-    C2 = np.vstack([C, C[:1]])
-    c2 = np.concatenate([c, c[:1]])
+    # an equality row without any gradient: "Singular matrix C in LSQ subproblem"
+    C2 = np.vstack([C, np.zeros((1, n))])
+    c2 = np.concatenate([c, [0.25]])
     assert slsqp_np.qp_solve(Z, g, C2, c2, G[:5], h[:5], lb, ub)[3] == 6
     core = _sqp_native.QpCore(n, meq + 1, 5)
     core.set_factor(Z)

@@ -1,3 +1,5 @@
+"""usage: python tools/exact_check.py <problem> [...]   (GPU box)
+Exact-Jacobian kernel against the CPU twin (bit for bit) and against the FD sweep, with its host-API time."""
 import numpy as np, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import np_path, twin

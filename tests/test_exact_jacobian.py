@@ -98,20 +98,31 @@ def test_gpu_exact_jacobian_is_bit_identical_to_the_twin(name):
 
 
 @pytest.mark.gpu
-def test_with_exact_jacobians_both_sqp_cores_walk_the_same_path(capsys):
+@pytest.mark.parametrize("name,maxiter,ftol,converges", [("goddard", 600, 1e-10, True),
+                                                         ("polar_tsto_shipped", 40, 1e-6, False)])
+def test_with_exact_jacobians_both_sqp_cores_walk_the_same_path(name, maxiter, ftol, converges, capsys):
     """Free-running (no replay): with noise-free Jacobians SciPy's Fortran core and the HIP core
-    take the same major iterations, the same line-search cuts, and stop at the same point.  With FD
-    Jacobians they cannot (a 1e-13 difference in x becomes 1e-5 in the Jacobian)."""
+    take the same major iterations, the same line-search cuts, and stop at the same point (C2, to
+    convergence), or are still side by side after 40 iterations that start from an inconsistent
+    linearisation (C3', relaxed QP).  With FD Jacobians they cannot: a 1e-13 difference in x becomes
+    1e-5 in the Jacobian."""
+    import warnings
     out = {}
     for core in ("scipy", "hip"):
-        prob, obj = problems.build("goddard")
+        prob, obj = problems.build(name)
         prob.maxIterator = 1
-        prob.solve(obj, maxiter=600, ftol=1e-10, sqp_core=core, jacobian="exact")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            prob.solve(obj, maxiter=maxiter, ftol=ftol, sqp_core=core, jacobian="exact")
         out[core] = prob.last_result
     capsys.readouterr()
     a, b = out["scipy"], out["hip"]
-    assert a.status == b.status == 0
+    assert a.status == b.status == (0 if converges else 9)
     assert (a.nit, a.nfev, a.njev) == (b.nit, b.nfev, b.njev)
-    assert abs(a.fun - b.fun) <= 1e-9
-    assert np.max(np.abs(a.x - b.x)) <= 1e-6
-    assert abs(b.fun + 1.01283) <= 2e-5
+    if converges:
+        assert abs(a.fun - b.fun) <= 1e-9
+        assert np.max(np.abs(a.x - b.x)) <= 1e-6
+        assert abs(b.fun + 1.01283) <= 2e-5
+    else:
+        assert abs(a.fun - b.fun) <= 1e-6 * max(1.0, abs(a.fun))
+        assert np.max(np.abs(a.x - b.x)) <= 1e-3

@@ -55,6 +55,8 @@ constexpr double FEASIBLE = 1e-12;    // rounding level of a normalised constrai
 constexpr double SINGULAR_C = 2.220446049250313e-16;  // lsei's own test: ABS(C(I,I)) < EPMACH -> mode 6.  Absolute,
                                                       // like there: a rank deficiency that rounding leaves at 1e-14
                                                       // passes (and yields the same wild step SciPy takes)
+constexpr double REDUNDANT = 1e-13;   // |L_kk| <= this * max |L_jj|: equality k is a combination of the ones before it
+constexpr double CONSISTENT = 1e-9;   // ... and redundant if its residual is below this * (1 + max |c|), else mode 6
 constexpr int REFINE = 3;             // at most this many re-orthogonalisation passes (one is the rule)
 constexpr double REORTH = 1e-8;       // another pass while the last correction exceeds this, relative
 constexpr int GI_THREADS = 1024;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256) void k_lq_apply_reg(double* __restrict__ Tc, d
 }
 
 // max |diag| / min |diag| test of the triangular factor -> flag[0] = 1 when singular
-__global__ void k_check_diag(const double* diagL, int meq, int* flag) {
+__global__ void k_check_diag(const double* diagL, int meq, int* flag, double* dthresh) {
     __shared__ double red[16];
     __shared__ double red2[16];
     double mx = 0.0, mn = INFINITY;
@@ -583,8 +585,10 @@ __global__ void k_check_diag(const double* diagL, int meq, int* flag) {
             mx = fmax(mx, red[w]);
             mn = fmin(mn, red2[w]);
         }
-        (void)mx;
-        flag[0] = (meq > 0 && !(mn >= SINGULAR_C)) ? 1 : 0;
+        // a vanishing pivot is not fatal by itself: k_trsv decides (redundant if consistent, mode 6 if not)
+        (void)mn;
+        flag[0] = 0;
+        dthresh[0] = fmax(REDUNDANT * mx, SINGULAR_C);
     }
 }
 
@@ -594,13 +598,26 @@ __global__ void k_check_diag(const double* diagL, int meq, int* flag) {
 // of LDS, the panel below (above) is a GEMV spread over all threads.
 __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, int ld, const double* __restrict__ diagL,
                                                int meq, int transposed, double scale_rhs, const double* __restrict__ rhs,
-                                               double* __restrict__ x) {
+                                               double* __restrict__ x, const double* __restrict__ dthresh,
+                                               int* __restrict__ flag) {
     extern __shared__ double lds[];
+    __shared__ double red[16];
     double* xs = lds;                 // meq
     double* blk = lds + meq;          // 64 x 65
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < meq; i += 1024) xs[i] = scale_rhs * rhs[i];
+    double biggest = 0.0;
+    for (int i = tid; i < meq; i += 1024) {
+        const double v = scale_rhs * rhs[i];
+        xs[i] = v;
+        biggest = fmax(biggest, fabs(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) biggest = fmax(biggest, __shfl_xor(biggest, off));
+    if (lane == 0) red[wave] = biggest;
     __syncthreads();
+    for (int w2 = 0; w2 < 16; ++w2) biggest = fmax(biggest, red[w2]);
+    // a vanishing pivot: the equality is a combination of earlier ones - dropped if its residual vanishes
+    // too (its component and its multiplier are zero), "singular matrix C" (flag 0) if it does not
+    const double tiny = dthresh[0], tol = CONSISTENT * (1.0 + biggest);
     const int nblk = (meq + 63) / 64;
     for (int bi = 0; bi < nblk; ++bi) {
         const int b = transposed ? nblk - 1 - bi : bi;
@@ -614,7 +631,10 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
             double xv = lane < bs ? xs[i0 + lane] : 0.0;
             if (!transposed) {
                 for (int c = 0; c < bs; ++c) {
-                    const double xc = __shfl(xv, c) / diagL[i0 + c];
+                    const double dc = diagL[i0 + c], num = __shfl(xv, c);
+                    const bool gone = !(fabs(dc) > tiny);
+                    if (gone && fabs(num) > tol && lane == 0) flag[0] = 1;
+                    const double xc = gone ? 0.0 : num / dc;
                     if (lane == c)
                         xv = xc;
                     else if (lane > c)
@@ -622,7 +642,8 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
                 }
             } else {
                 for (int c = bs - 1; c >= 0; --c) {
-                    const double xc = __shfl(xv, c) / diagL[i0 + c];
+                    const double dc = diagL[i0 + c];
+                    const double xc = !(fabs(dc) > tiny) ? 0.0 : __shfl(xv, c) / dc;
                     if (lane == c)
                         xv = xc;
                     else if (lane < c)
@@ -1930,7 +1951,7 @@ struct og_qp_s {
     double *w1 = nullptr, *t1 = nullptr, *xcat = nullptr, *deq = nullptr, *bG = nullptr;
     double *bval = nullptr, *scale = nullptr, *own = nullptr, *u = nullptr, *y = nullptr;
     double *R[2] = {nullptr, nullptr}, *RI[2] = {nullptr, nullptr}, *Q1t = nullptr;
-    double *apart = nullptr, *uact = nullptr, *csbuf = nullptr, *zg = nullptr;
+    double *apart = nullptr, *uact = nullptr, *csbuf = nullptr, *zg = nullptr, *dthresh = nullptr;
     CoopPartial* cpart = nullptr;
     unsigned* bar = nullptr;
     int* abort_flag = nullptr;
@@ -2021,7 +2042,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->diagL, qp->meq); A(&qp->Vp, (size_t)LQ_NB * n1); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
-    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->csbuf, 2 * qc);
+    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 1); A(&qp->csbuf, 2 * qc);
     A(&qp->cpart, 256); A(&qp->bar, 1); A(&qp->abort_flag, 1); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
@@ -2181,22 +2202,22 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         }
 #endif
         OG_STAGE("check diag");
-        hipLaunchKernelGGL(k_check_diag, dim3(1), dim3(1024), 0, s, qp->diagL, meq, qp->flag);
+        hipLaunchKernelGGL(k_check_diag, dim3(1), dim3(1024), 0, s, qp->diagL, meq, qp->flag, qp->dthresh);
     }
     OG_HIP(hipGetLastError());
-    int hflag[2] = {0, 0};
-    OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    OG_HIP(hipStreamSynchronize(s));
-    if (hflag[0]) {
-        *status = OG_QP_SINGULAR_C;
-        return 0;
-    }
     // ---- equality-constrained minimiser: L w1 = -c,  deq = J1 w1 - Y (Y'g)
     const size_t trsv_lds = (size_t)(meq + 64 * 65) * sizeof(double);
     OG_STAGE("trsv w1");
     if (meq)
         hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, n1, qp->diagL, meq, 0, -1.0, qp->c,
-                           qp->w1);
+                           qp->w1, qp->dthresh, qp->flag);
+    int hflag[2] = {0, 0};
+    OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    OG_HIP(hipStreamSynchronize(s));
+    if (hflag[0]) {                       // a dependent equality row that contradicts the others
+        *status = OG_QP_SINGULAR_C;
+        return 0;
+    }
     OG_STAGE("deq");
     if (nr > 0)
         hipLaunchKernelGGL(k_gemv_cols, dim3((nr + 63) / 64), dim3(1024), 0, s, qp->Jw + meq, (long)n1, nq, nr, qp->g,
@@ -2341,7 +2362,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         hipLaunchKernelGGL(k_gemv_cols, dim3((meq + 63) / 64), dim3(1024), 0, s, qp->Jw, (long)n1, nq, meq, qp->tvec,
                            qp->w1, qp->rhs);
         hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, n1, qp->diagL, meq, 1, 1.0, qp->rhs,
-                           qp->lam);
+                           qp->lam, qp->dthresh, qp->flag);
     }
     OG_HIP(hipGetLastError());
     OG_HIP(hipMemcpyAsync(d, qp->d, sizeof(double) * nq, hipMemcpyDeviceToHost, s));

@@ -38,6 +38,8 @@ EXIT_MODES = {0: "Optimization terminated successfully",
 DEPENDENT = 1e-10        # |component outside the active normals| / |normal| below this -> dependent
 FEASIBLE = 1e-12         # normalised violation below this counts as satisfied
 SINGULAR_C = np.finfo(float).eps   # lsei: ABS(C(I,I)) < EPMACH -> mode 6 (an absolute test, as there)
+REDUNDANT = 1e-13        # |L_kk| <= this * max|L_jj|: equality k is a combination of the ones before it ...
+CONSISTENT = 1e-9        # ... redundant if its residual is below this * (1 + max|c|), else mode 6
 
 
 # ----------------------------------------------------------------------------------------------
@@ -194,12 +196,20 @@ def qp_solve(Z, g, C, c, G, h, lb, ub):
     L = T[:meq, :meq]                                       # = R', lower triangular
     J = T[meq:]
     diag = np.abs(np.diag(L))
-    if meq and not diag.min() >= SINGULAR_C:
-        return np.zeros(n), np.zeros(meq), np.zeros(G.shape[0]), 6, Z, info
+    # a vanishing pivot: that equality is a combination of the earlier ones.  Redundant (dropped: zero
+    # component, zero multiplier) if its residual vanishes too, "singular matrix C" (mode 6) if not
+    tiny = max(REDUNDANT * (diag.max() if meq else 0.0), SINGULAR_C)
+    gone = ~(diag > tiny)
+    tol = CONSISTENT * (1.0 + (np.abs(c).max() if meq else 0.0))
     J1, Y = J[:, :meq], J[:, meq:]
     w1 = np.zeros(meq)
     for i in range(meq):                                    # L w1 = -c
-        w1[i] = (-c[i] - L[i, :i] @ w1[:i]) / L[i, i]
+        num = -c[i] - L[i, :i] @ w1[:i]
+        if gone[i]:
+            if abs(num) > tol:
+                return np.zeros(n), np.zeros(meq), np.zeros(G.shape[0]), 6, Z, info
+            continue
+        w1[i] = num / L[i, i]
     d_eq = J1 @ w1 - Y @ (Y.T @ g)
     has_lb, has_ub = np.isfinite(lb), np.isfinite(ub)
     GJ = G @ J
@@ -222,7 +232,8 @@ def qp_solve(Z, g, C, c, G, h, lb, ub):
     rhs = w1 + J1.T @ (g - G.T @ mu_g - ub_mult)
     lam = np.zeros(meq)
     for i in range(meq - 1, -1, -1):                        # L' lam = rhs
-        lam[i] = (rhs[i] - L[i + 1:, i] @ lam[i + 1:]) / L[i, i]
+        if not gone[i]:
+            lam[i] = (rhs[i] - L[i + 1:, i] @ lam[i + 1:]) / L[i, i]
     d = np.minimum(np.maximum(d, np.where(has_lb, lb, -np.inf)), np.where(has_ub, ub, np.inf))
     info["bound_multipliers"] = ub_mult
     return d, lam, mu_g, 1, J, info

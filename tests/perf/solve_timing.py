@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--max-restarts", type=int, default=None)
     ap.add_argument("--ftol", type=float, default=None)
     ap.add_argument("--maxiter", type=int, default=None)
+    ap.add_argument("--jacobian", default="fd", choices=["fd", "exact"],
+                    help="exact: forward-mode derivatives instead of SciPy's forward differences")
     ap.add_argument("--sqp-core", default="scipy", choices=["scipy", "hip"],
                     help="hip: QP subproblems on the GPU (include/ogsqp.h); needs --engine hip")
     a = ap.parse_args()
@@ -62,6 +64,7 @@ def main():
     if a.maxiter is not None:
         opts["maxiter"] = a.maxiter
     opts["sqp_core"] = a.sqp_core
+    opts["jacobian"] = a.jacobian
     buf = io.StringIO()
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(buf):
@@ -71,7 +74,7 @@ def main():
     if a.sqp_core == "hip":
         tm = prob.sqp_timings
         cb = sum(t["callbacks"] for t in tm)
-        print(json.dumps({"workload": a.workload, "engine": "hip", "sqp_core": "hip",
+        print(json.dumps({"workload": a.workload, "engine": "hip", "sqp_core": "hip", "jacobian": a.jacobian,
                           "n": int(prob.number_of_variables), "wall_s": wall, "t_callbacks_s": cb,
                           "t_qp_s": sum(t["qp"] for t in tm), "t_bfgs_s": sum(t["bfgs"] for t in tm),
                           "qp_solves": sum(t["qp_solves"] for t in tm),

@@ -268,7 +268,7 @@ constexpr int LQ_CPT_MAX = 16;   // panel columns per thread: rows of up to LQ_P
 template <int LQ_PT, int LQ_CPT>
 __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int ld, int meq, int nq, int k,
                                                    double* __restrict__ V, double* __restrict__ diagL,
-                                                   LqPanel* __restrict__ panel) {
+                                                   LqPanel* __restrict__ panel, double* __restrict__ dmaxbuf) {
     constexpr int NPAIR = LQ_NB * (LQ_NB - 1) / 2;
     __shared__ double red[(LQ_PT / 64) * NPAIR];
     const int tid = threadIdx.x;
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
     PMARK(0);   // load
     __shared__ double s_lower[LQ_NB][LQ_NB];
     __shared__ double s_diag[LQ_NB];
+    double dmax = dmaxbuf[0];           // largest pivot of the sweep so far
     double beta[LQ_NB];
 #pragma unroll
     for (int b = 0; b < LQ_NB; ++b) {
@@ -328,12 +329,16 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
             const double sigma2 = vals[b];
             const double x0 = s_col[b];
             const double sigma = sqrt(sigma2);
-            const double alpha = x0 >= 0.0 ? -sigma : sigma;
+            // what is left of a row that depends on the earlier ones is rounding noise: no reflector is built
+            // from it (it would rotate the null-space basis by that noise); its pivot is recorded as exactly 0
+            const bool live = sigma > REDUNDANT * dmax && sigma > 0.0;
+            dmax = fmax(dmax, sigma);
+            const double alpha = !live ? 0.0 : (x0 >= 0.0 ? -sigma : sigma);
             const double v0 = x0 - alpha;
             const double vv = sigma2 - x0 * x0 + v0 * v0;
-            const double bt = (sigma > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
+            const double bt = (live && vv > 0.0) ? 2.0 / vv : 0.0;
             beta[b] = bt;
-            if (tid == 0) s_diag[b] = sigma > 0.0 ? alpha : 0.0;
+            if (tid == 0) s_diag[b] = alpha;
             if (tid == b) P[b][0] = v0;
             // H_b on the panel rows below:  row . v_b = (row . row_b) - row[b] alpha
 #pragma unroll
@@ -399,6 +404,7 @@ __global__ __launch_bounds__(LQ_PT) void k_lq_panel(double* __restrict__ Tc, int
         for (int b = 0; b < LQ_NB; ++b) s_beta[b] = beta[b];
         panel->nb = nb;
         panel->pad = 0;
+        dmaxbuf[0] = dmax;
     }
     __syncthreads();
     if (tid < nb) {
@@ -2042,7 +2048,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->diagL, qp->meq); A(&qp->Vp, (size_t)LQ_NB * n1); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
-    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 1); A(&qp->csbuf, 2 * qc);
+    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 2); A(&qp->csbuf, 2 * qc);
     A(&qp->cpart, 256); A(&qp->bar, 1); A(&qp->abort_flag, 1); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
@@ -2157,13 +2163,14 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, n1,
                            nq, qp->Tc);
         OG_STAGE("lq sweep");
+        OG_HIP(hipMemsetAsync(qp->dthresh, 0, 2 * sizeof(double), s));
         for (int k = 0; k < meq; k += LQ_NB) {
             const int nb = std::min(LQ_NB, meq - k);
             const int nrows = (meq - k - nb) + nq;
             const int len = nq - k;                                // length of the panel rows
 #define OG_PANEL(PT, CPT)                                                                                      \
     hipLaunchKernelGGL((k_lq_panel<PT, CPT>), dim3(1), dim3(PT), 0, s, qp->Tc, n1, meq, nq, k, qp->Vp, qp->diagL, \
-                       qp->panel)
+                       qp->panel, qp->dthresh + 1)
             if (len <= PANEL_SMALL_PT * 4) OG_PANEL(PANEL_SMALL_PT, 4);
             else if (len <= PANEL_SMALL_PT * 8) OG_PANEL(PANEL_SMALL_PT, 8);
             else if (len <= PANEL_SMALL_PT * 12) OG_PANEL(PANEL_SMALL_PT, 12);

@@ -180,10 +180,15 @@ def qp_solve(Z, g, C, c, G, h, lb, ub):
         return np.zeros(n), np.zeros(meq), np.zeros(G.shape[0]), 2, Z, info
     # LQ of C Z with the same orthogonal transformations applied to Z
     T = np.vstack([C @ Z, Z])
+    dmax = 0.0
     for k in range(meq):
         row = T[k, k:]
         sigma = float(np.sqrt(row @ row))
-        if sigma == 0.0:
+        # what is left of a row that depends on the earlier ones is rounding noise: no reflector from it
+        live = sigma > REDUNDANT * dmax and sigma > 0.0
+        dmax = max(dmax, sigma)
+        if not live:
+            T[k, k] = 0.0
             continue
         alpha = -sigma if row[0] >= 0 else sigma
         v = row.copy()

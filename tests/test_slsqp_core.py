@@ -270,6 +270,27 @@ def test_gpu_qp_relaxed_incompatible_and_singular_cases(update, monkeypatch):
     core.set_factor(Z)
     assert core.solve(np.vstack([C2, G[:5]]), g, np.concatenate([c2, h[:5]]), lb, ub)[3] == _sqp_native.QP_SINGULAR_C
     core.close()
+    # an equality that repeats another one is dropped (zero component, zero multiplier): the step satisfies
+    # every constraint, the repeated one included, and costs no less than the QP without the repetition (the
+    # one null-space direction the dependency frees is not searched); a contradicting one is "singular C"
+    B = np.linalg.inv(Z @ Z.T)
+    for rhs_shift, expect in ((0.0, 1), (0.5, 6)):
+        C3 = np.vstack([C, 2.0 * C[2:3]])
+        c3 = np.concatenate([c, [2.0 * c[2] + rhs_shift]])
+        ref = slsqp_np.qp_solve(Z, g, C3, c3, G[:5], h[:5], lb, ub)
+        core = _sqp_native.QpCore(n, meq + 1, 5)
+        core.set_factor(Z)
+        dd, mult, bm, status, _ = core.solve(np.vstack([C3, G[:5]]), g, np.concatenate([c3, h[:5]]), lb, ub)
+        assert status == ref[3] == expect
+        if expect == 1:
+            assert np.max(np.abs(dd - ref[0])) <= 1e-10 * max(1.0, np.abs(ref[0]).max())
+            assert np.max(np.abs(C3 @ dd + c3)) <= 1e-10 and np.min(G[:5] @ dd + h[:5]) >= -1e-10
+            assert np.all(dd >= lb - 1e-12) and np.all(dd <= ub + 1e-12)
+            base = slsqp_np.qp_solve(Z, g, C, c, G[:5], h[:5], lb, ub)[0]
+            cost = lambda v: 0.5 * v @ B @ v + g @ v
+            assert cost(dd) >= cost(base) - 1e-9 * max(1.0, abs(cost(base)))
+            assert mult[meq] == 0.0
+        core.close()
     # no inequality at all, and no constraint at all
     for meq0 in (6, 0):
         core = _sqp_native.QpCore(n, meq0, 0)

@@ -312,6 +312,21 @@ def main():
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if world == 1 and rank == 0:
+        # exact-Jacobian mode (og_jacobian_exact_dev: evaluation + ogk_exact), same resident x0, same output buffer
+        d_jt = torch.empty((n, m), dtype=torch.float64, device=dev)
+        for _ in range(3):
+            eng.exact_dev(d_x.data_ptr(), 0, n, d_jt.data_ptr(), d_F0.data_ptr(), stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            eng.exact_dev(d_x.data_ptr(), 0, n, d_jt.data_ptr(), d_F0.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        result["exact_jacobian"] = {"ms_per_jacobian": e0.elapsed_time(e1) / reps, "kernel": "ogk_eval + ogk_exact",
+                                    "note": "forward-mode derivatives (opt-in mode, jacobian='exact'); dense kernel"}
+        del d_jt
     if world == 1 and rank == 0 and a.sqp_iterations > 0 and n <= 3000:
         result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations,
                                 a.sqp_reference_iterations if n <= 1600 else 0)

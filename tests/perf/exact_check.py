@@ -1,7 +1,7 @@
-"""usage: python tools/exact_check.py <problem> [...]   (GPU box)
+"""usage: python tests/perf/exact_check.py <problem> [...]   (GPU box)
 Exact-Jacobian kernel against the CPU twin (bit for bit) and against the FD sweep, with its host-API time."""
 import numpy as np, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import np_path, twin
 from opengoddard_amd import problems, _native
 from opengoddard_amd.engine import HipEngine

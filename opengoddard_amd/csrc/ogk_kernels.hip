@@ -307,6 +307,52 @@ __global__ __launch_bounds__(256) void ogk_exact(const ogk_args a, const int n_i
     }
 }
 
+// Mode 4, the same derivatives with the work lists of the structured sweep: a workgroup per column
+// zero-fills its row of J_T, then evaluates only the row items that read x_j (OGT_COL / OGT_ELEM) and,
+// when x_j is a collocated state, that state's defect rows: column l of D times the operand's derivative,
+// minus the dynamics term's derivative on the diagonal.  Same numbers as mode 3 (tests compare both with
+// the CPU twin), a fraction of the evaluations.
+__global__ __launch_bounds__(256) void ogk_exact_struct(const ogk_args a) {
+    const int j = a.col_lo + (int)blockIdx.x;
+    if (j >= a.col_hi) return;
+    const int tid = (int)threadIdx.x;
+    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+    for (int r = tid; r < OgGen::M; r += 256) jrow[r] = 0.0;
+    __syncthreads();
+    const XDual xd{a.x0, j};
+    const int4 rec = OGT_COL[j];
+    for (int e = rec.x + tid; e < rec.y; e += 256) {
+        const int4 it = OGT_ELEM[e];
+        int row;
+        const ogdual v = OgGen::item_value(it.x, it.y, it.z, xd, a.y0, a.cvec, &row);
+        jrow[row] = v.d;
+    }
+    const int own_lo = rec.z, own_hi = rec.w & 0x3fffffff;
+    if (own_hi > own_lo) {
+        // x_j is node l of the state behind one collocation product
+        int si = -1, l = 0;
+        for (int s = 0; s < OgGen::N_MV; ++s) {
+            const int leaf = OGT_SLOT[s].v[2], len = OGT_SLOT[s].v[0];
+            if (j >= leaf && j < leaf + len) {
+                si = s;
+                l = j - leaf;
+            }
+        }
+        if (si >= 0) {
+            const int N = OGT_SLOT[si].v[0], phase = OGT_SLOT[si].v[5], row0 = OGT_SLOT[si].v[3];
+            // bit 0: the dynamics term at node k reads the state at node k; bit 1: it reads the
+            // state's slice in some other way (every node then)
+            const int reads = OGT_SLOT[si].v[6];
+            const ogdual op = OgGen::mv_operand(si, l, xd, a.cvec);
+            for (int k = tid; k < N; k += 256) {
+                double v = __builtin_fma(op.d, dfrag_entry(a, phase, N, k, l), 0.0);
+                if ((reads & 2) || ((reads & 1) && k == l)) v = v - OgGen::tail_one(si, k, xd, a.cvec).d;
+                jrow[row0 + k] = v;
+            }
+        }
+    }
+}
+
 constexpr int SWEEP_THREADS = 512;   // ogk_sweep / ogk_eval workgroup: 8 wavefronts
 constexpr int SWEEP_WAVES = SWEEP_THREADS / 64;
 
@@ -792,6 +838,10 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         const int light_blocks = (ncols + LIGHT_COLS - 1) / LIGHT_COLS;
         hipLaunchKernelGGL(ogk_sweep, dim3(OGT_N_TILES + OgGen::N_HEAVY + light_blocks),
                            dim3(SWEEP_THREADS), sweep_lds_bytes(), stream, *args);
+        return (int)hipGetLastError();
+    }
+    if (mode == 4) {
+        hipLaunchKernelGGL(ogk_exact_struct, dim3(ncols), dim3(256), 0, stream, *args);
         return (int)hipGetLastError();
     }
     if (mode == 3) {

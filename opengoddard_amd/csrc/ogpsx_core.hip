@@ -82,6 +82,7 @@ struct og_problem_s {
     int* d_flags = nullptr;             // two non-finite-row counters used alternately
     int flag_slot = 0;
     int sweep_mode = 1;                 // 1 structured (default), 2 dense (OGPSX_SWEEP=dense)
+    int exact_mode = 4;                 // 4 structured (default), 3 dense (OGPSX_SWEEP=dense)
     hipStream_t stream = nullptr;
 };
 
@@ -274,7 +275,7 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMalloc(&p->d_flags, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 2 * sizeof(int));
     const char* mode_env = getenv("OGPSX_SWEEP");
-    if (mode_env && std::string(mode_env) == "dense") p->sweep_mode = 2;
+    if (mode_env && std::string(mode_env) == "dense") p->sweep_mode = 2, p->exact_mode = 3;
     if (e == hipSuccess) e = hipStreamCreate(&p->stream);
     if (e != hipSuccess) {
         og_problem_destroy(p);
@@ -354,7 +355,7 @@ int og_jacobian_exact_dev(og_handle p, const double* d_x, int32_t lo, int32_t hi
     p->flag_slot ^= 1;
     fill_args(p, &a, d_x, nullptr, d_F0, d_JT, lo, hi);
     int rc = p->launch(&a, 0, hip_stream);          // F(x0) and the base collocation products
-    if (!rc) rc = p->launch(&a, 3, hip_stream);     // forward-mode derivatives, column by column
+    if (!rc) rc = p->launch(&a, p->exact_mode, hip_stream);   // forward-mode derivatives, column by column
     if (rc) return fail(100 + rc, std::string("og_jacobian_exact_dev: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }

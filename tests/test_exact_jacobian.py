@@ -73,9 +73,14 @@ def test_jacobian_option_is_validated():
 
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["structured", "dense"])
 @pytest.mark.parametrize("name", SMALL + ["polar_tsto"])
-def test_gpu_exact_jacobian_is_bit_identical_to_the_twin(name):
+def test_gpu_exact_jacobian_is_bit_identical_to_the_twin(name, layout, monkeypatch):
+    """Both kernels: the one driven by the structured sweep's work lists (default) and the dense one
+    (every row item for every column, OGPSX_SWEEP=dense)."""
     from opengoddard_amd.engine import HipEngine
+    if layout == "dense":
+        monkeypatch.setenv("OGPSX_SWEEP", "dense")
     prob, obj = problems.build(name)
     eng = HipEngine(prob, obj)
     tw = twin.Twin(prob, obj, program=eng.program, header=eng.header)

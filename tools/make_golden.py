@@ -255,8 +255,12 @@ def golden_layout():
 # ------------------------------------------------------------------------------ G3 / G4
 EXAMPLES = {
     "ex01": "01_Brachistochrone_Problem.py",
+    "ex02": "02_Brachistochrone_TokyoOsaka.py",
+    "ex03": "03_2d_simple_rocket.py",
     "ex04": "04_Goddard_0knot.py",
     "ex05": "05_Goddard_1knot.py",
+    "ex06": "06_Rocket_Ascent_SingleStage.py",
+    "ex07": "07_Rocket_Ascent_TwoStage.py",
     "ex08": "08_Rocket_Ascent_Polar_SSTO.py",
     "ex09": "09_Rocket_Ascent_Polar_TSTO.py",
     "ex10": "10_Low_Thrust_Orbit_Transfer.py",

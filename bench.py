@@ -15,7 +15,8 @@ split in contiguous blocks (strong scaling - total work is fixed) and reassemble
 RCCL all-gather per step; timing is barrier + synchronize on both
 sides, max over ranks.
 
-Extra objects on the JSON line: ``roofline`` (dominant kernel ``ogk_sweep`` against the
+Extra objects on the JSON line: ``roofline`` (dominant kernel - ``ogk_fused``, evaluation + sweep in one
+launch, or ``ogk_sweep`` where the runtime uses two launches - against the
 HBM roofline, algorithmic bytes 8*[(n+1)n + m n + sum N_i^2] per launch, duration from HIP
 events on the launch stream) and ``cpu_baseline`` (the NumPy restatement of the reference path,
 ``oracle/np_path.py``, timed on this host for ~10 s; rank 0, N = 1 only).
@@ -207,9 +208,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(gather=True):
-        eng.eval_dev(d_x.data_ptr(), d_F0.data_ptr(), stream)
-        eng.columns_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, d_local.data_ptr(),
-                        d_F0.data_ptr(), stream)
+        # one pass of the hot path: F(x0) and this rank's FD columns (og_fd_sweep_dev: one launch, or two above
+        # 32 MB of Jacobian - og_sweep_mode)
+        eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, d_local.data_ptr(), d_F0.data_ptr(), stream)
         if collective and gather:
             dist.all_gather_into_tensor(d_full, d_local)
 
@@ -260,16 +261,22 @@ def main():
         return np.array([e0.elapsed_time(e1) / batch for e0, e1 in pairs])
 
     def launch_sweep():
+        eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, d_local.data_ptr(), d_F0.data_ptr(), stream)
+
+    def launch_columns():
         eng.columns_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, d_local.data_ptr(),
                         d_F0.data_ptr(), stream)
 
     def launch_eval():
         eng.eval_dev(d_x.data_ptr(), d_F0.data_ptr(), stream)
 
+    fused = eng.sweep_mode == "fused"
     launch_eval()
-    single = timed(launch_sweep, a.steps, 1)
-    batched = timed(launch_sweep, max(a.steps // 10, 5), 10)
+    single = timed(launch_sweep if fused else launch_columns, a.steps, 1)
+    batched = timed(launch_sweep if fused else launch_columns, max(a.steps // 10, 5), 10)
+    # the two kernels the fused launch replaces, for reference
     eval_ms_mean = float(np.mean(timed(launch_eval, max(a.steps // 10, 5), 10)))
+    columns_ms_mean = float(np.mean(timed(launch_columns, max(a.steps // 10, 5), 10)))
     kern_ms = float(np.median(batched))
     kern_ms_mean = float(np.mean(batched))
     kern_ms_single = float(np.mean(single))
@@ -298,7 +305,7 @@ def main():
             "n": n, "m_eq": eng.m_eq, "m_ineq": eng.m_ineq,
             "evals_per_step": 3 * n + 2,
             "parallelism": "fd-columns x%d%s" % (world, " + RCCL all-gather" if collective else "")},
-        "roofline": {"bound": "hbm", "kernel": "ogk_sweep", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "ogk_fused" if fused else "ogk_sweep", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": traffic["source"] if traffic else None,
@@ -306,7 +313,8 @@ def main():
                      "bytes_actually_written_per_launch": 8.0 * m * ncols,
                      "kernel_ms_mean": kern_ms_mean, "kernel_ms_median": kern_ms,
                      "kernel_ms_single_launch_events": kern_ms_single,
-                     "eval_kernel_ms_mean": eval_ms_mean,
+                     "split_eval_kernel_ms_mean": eval_ms_mean,
+                     "split_sweep_kernel_ms_mean": columns_ms_mean,
                      "frac_of_whole_step": alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
     }
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
@@ -324,8 +332,8 @@ def main():
             eng.exact_dev(d_x.data_ptr(), 0, n, d_jt.data_ptr(), d_F0.data_ptr(), stream)
         e1.record()
         torch.cuda.synchronize()
-        result["exact_jacobian"] = {"ms_per_jacobian": e0.elapsed_time(e1) / reps, "kernel": "ogk_eval + ogk_exact",
-                                    "note": "forward-mode derivatives (opt-in mode, jacobian='exact'); dense kernel"}
+        result["exact_jacobian"] = {"ms_per_jacobian": e0.elapsed_time(e1) / reps, "kernel": "ogk_eval + ogk_exact_struct",
+                                    "note": "forward-mode derivatives (opt-in mode, jacobian='exact')"}
         del d_jt
     if world == 1 and rank == 0 and a.sqp_iterations > 0 and n <= 3000:
         result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations,

@@ -36,6 +36,7 @@ SIGNATURES = {
     "og_problem_create": (C.c_int, [C.POINTER(OgDesc), C.POINTER(C.c_void_p)]),
     "og_problem_destroy": (None, [C.c_void_p]),
     "og_problem_dims": (C.c_int, [C.c_void_p, _c_int32_p, _c_int32_p, _c_int32_p, _c_int32_p]),
+    "og_sweep_mode": (C.c_int, [C.c_void_p]),
     "og_eval": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
     "og_fd_sweep": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_int32, C.c_int32,
                               _c_double_p, _c_double_p]),

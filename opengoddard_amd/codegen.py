@@ -28,6 +28,8 @@ from . import trace as _tr
 import os
 
 HEAVY_COLUMN_ELEMENTS = 32       # columns with more dependent elements get a whole workgroup
+LIGHT_COLS = 4                   # columns per workgroup otherwise (csrc/ogk_kernels.hip OGK_LIGHT_COLS)
+HPART_ITEMS = 256                # items of a heavy column per workgroup in the fused launch (half of SWEEP_THREADS)
 MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "1"))
 
 
@@ -639,12 +641,26 @@ class _Emitter:
                 lines.append("        out[%d] = y[%d] - T[%d];" % (s, s, s))
             lines.append("    }")
             return lines
+        roots = [e for _, e in grp.outputs]
+        if len(roots) == 1:
+            # value-returning form: no address-taken temporaries in the kernels that evaluate single items
+            lines = ["    template <class X> OG_HDI static typename X::scalar group%d_v(const int k, const X& x, "
+                     "const double* cv) {" % gi,
+                     "        typedef typename X::scalar S;",
+                     "        (void)k; (void)cv;"]
+            names = {}
+            self._emit_sums(roots, lines, names, 8)
+            self._emit_expr(roots, "k", lines, names, 8, {})
+            lines += ["        return %s;" % names[roots[0]], "    }",
+                      "    template <class X> OG_HDI static void group%d(const int k, const X& x, "
+                      "const typename X::scalar* y, const double* cv, typename X::scalar* out) {" % gi,
+                      "        (void)y;", "        out[0] = group%d_v(k, x, cv);" % gi, "    }"]
+            return lines
         lines = ["    template <class X> OG_HDI static void group%d(const int k, const X& x, "
                  "const typename X::scalar* y, const double* cv, typename X::scalar* out) {" % gi,
                  "        typedef typename X::scalar S;",
                  "        (void)k; (void)y; (void)cv;"]
         names = {}
-        roots = [e for _, e in grp.outputs]
         self._emit_sums(roots, lines, names, 8)
         self._emit_expr(roots, "k", lines, names, 8, {})
         for o, (_, e) in enumerate(grp.outputs):
@@ -694,6 +710,7 @@ def emit_header(P):
          "    static constexpr int M_INEQ = %d;" % P.m_ineq,
          "    static constexpr int N_PHASE = %d;" % len(P.nodes),
          "    static constexpr int N_MV = %d;" % len(P.mv),
+         "    static constexpr int MAX_NODES = %d;" % max(P.nodes),
          "    static constexpr int N_GROUPS = %d;" % len(P.groups),
          "    static constexpr int N_CVEC = %d;" % P.cvec.shape[0],
          "    static constexpr int MAX_OUT = %d;" % max_out,
@@ -763,8 +780,29 @@ def emit_header(P):
             elem_g.append(gi), elem_o.append(o), elem_k.append(k)
         col_ptr.append(len(elem_g))
     counts = np.diff(col_ptr)
-    heavy = [int(j) for j in np.nonzero(counts > HEAVY_COLUMN_ELEMENTS)[0]]
+    # the collocation tile (defect group, 16-node tile) a column's defect items live in: the fused launch
+    # gives a light workgroup the base products of exactly one such tile.  Columns whose defect items
+    # spread over more than one tile get a workgroup of their own (like the columns with many items).
+    col_tile = []
+    for j in range(P.n):
+        keys = {(gi, k >> 4) for gi, o, k in col_elems[j] if P.groups[gi].kind == "defect"}
+        col_tile.append(None if not keys else (next(iter(keys)) if len(keys) == 1 else "many"))
+    heavy = [int(j) for j in range(P.n) if counts[j] > HEAVY_COLUMN_ELEMENTS or col_tile[j] == "many"]
     heavy.sort(key=lambda j: -counts[j])
+    # light columns in runs of at most LIGHT_COLS neighbours that share a tile
+    light_groups, run, heavy_set = [], None, set(heavy)
+    for j in range(P.n):
+        if j in heavy_set:
+            run = None
+            continue
+        key = col_tile[j]
+        if run is not None and run[0] + run[1] == j and run[1] < LIGHT_COLS and \
+                (key is None or run[2] is None or run[2] == key):
+            run[1] += 1
+            run[2] = run[2] if run[2] is not None else key
+        else:
+            run = [j, 1, key]
+            light_groups.append(run)
     # rows of a J_T row written by the MFMA tiles (j inside a collocated state slice)
     own_lo, own_hi = [0] * P.n, [0] * P.n
     mv_diag, mv_generic = [], []
@@ -807,15 +845,13 @@ def emit_header(P):
         if g.kind == "defect":
             L.append("            switch (o) {")
             for si in range(len(g.tails)):
-                L.append("            case %d: *row = %d + k; return S(y0[%d + k]) - tail%d_%d(k, x, cv);"
+                L.append("            case %d: *row = %d + k; return S(x.ldy(y0 + %d + k)) - tail%d_%d(k, x, cv);"
                          % (si, g.outputs[si][0], y0_off[g.mv_slots[si]], gi, si))
             L += ["            default: break;", "            }", "            break;"]
         else:
-            L += ["            S out[%d];" % len(g.outputs),
-                  "            group%d(k, x, nullptr, cv, out);" % gi,
-                  "            *row = %d + k; return out[0];" % g.outputs[0][0]]
             if len(g.outputs) != 1:
                 raise _tr.TraceError("row groups must have one output (OG_MAX_GROUP_OUTPUTS=1)")
+            L += ["            *row = %d + k; return group%d_v(k, x, cv);" % (g.outputs[0][0], gi)]
         L.append("        }")
     L += ["        default: break;", "        }", "        *row = 0;", "        return S(0.0);", "    }", ""]
     # the dynamics term of one collocation slot (one state) at node k
@@ -833,7 +869,7 @@ def emit_header(P):
         L.append("        case %d: group%d(k, x, y, cv, out); break;" % (gi, gi))
     L += ["        default: break;", "        }", "    }", "};", ""]
     L += _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, slot_group,
-                        y0_off, mv_diag, mv_generic, g_dep0, g_ndep)
+                        y0_off, mv_diag, mv_generic, g_dep0, g_ndep, light_groups)
     return "\n".join(L)
 
 
@@ -841,7 +877,7 @@ SWEEP_WAVES = 8          # wavefronts per ogk_sweep workgroup (csrc/ogk_kernels.
 
 
 def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, slot_group, y0_off,
-                   mv_diag, mv_generic, g_dep0, g_ndep):
+                   mv_diag, mv_generic, g_dep0, g_ndep, light_groups):
     """Wide, aligned device tables so that a workgroup of the structured sweep learns everything
     about its column / item / MFMA tile from ONE load each (every dependent global load costs
     a few hundred cycles, and the sweep of a small problem is a chain of them)."""
@@ -874,8 +910,59 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
         if g.kind == "defect":
             for nt in range((g.length + 15) // 16):
                 evalblk.append([gi, nt, g.mv_slots[0], len(g.mv_slots)])
-    L = ["#if defined(__HIPCC__)", "struct ogt_int8 { int v[8]; };"]
+    L = ["#if defined(__HIPCC__)"]
     L += table("int4", "OGT_EVALBLK", evalblk)
+    L.append("static constexpr int OGT_N_EVALBLK = %d;" % len(evalblk))
+    # fused launch: {first column, columns, defect group or -1, node tile} per light workgroup; the first
+    # columns again as a host table (ogk_launch picks the groups a column range touches)
+    # (everything a workgroup needs about its tile in ONE record: index tables looked up with a runtime
+    # group number end up as stack copies in the kernel)
+    lgrp = []
+    for j0, cnt, key in light_groups:
+        ranges = []
+        for c in range(LIGHT_COLS):
+            ranges += [col_ptr[j0 + c], col_ptr[j0 + c + 1]] if c < cnt else [0, 0]
+        if key:
+            g = P.groups[key[0]]
+            lgrp.append([j0, cnt, y0_off[g.mv_slots[0]], key[1], g.mv_slots[0], len(g.mv_slots), g.length, g.phase])
+        else:
+            lgrp.append([j0, cnt, 0, 0, 0, 0, 0, 0])
+        lgrp.append(ranges)
+    # heavy columns of the fused launch: HPART_ITEMS items per workgroup (one lane pair each), the row's
+    # fill split evenly; each part lists the evaluation blocks (defect group, node tile) whose base
+    # products its items read (bit 16: first block of its group in the list -> stage that group's operands)
+    eb_index = {(r[0], r[1]): i for i, r in enumerate(evalblk)}
+    hpart, hpart_eb = [], []
+    for j in heavy:
+        e0, e1 = col_ptr[j], col_ptr[j + 1]
+        nparts = max(1, -(-(e1 - e0) // HPART_ITEMS))
+        for pi in range(nparts):
+            a0, a1 = e0 + pi * HPART_ITEMS, min(e1, e0 + (pi + 1) * HPART_ITEMS)
+            need = sorted({eb_index[(elem_g[e], elem_k[e] >> 4)] for e in range(a0, a1)
+                           if P.groups[elem_g[e]].kind == "defect"})
+            first, seen = len(hpart_eb), set()
+            for eb in need:
+                gi, nt_, mv0_, nmv_ = evalblk[eb]
+                hpart_eb.append([mv0_, nmv_, P.groups[gi].length, P.groups[gi].phase, y0_off[mv0_], nt_,
+                                 0 if gi in seen else 1, 0])
+                seen.add(gi)
+            r0 = (P.m * pi // nparts) & ~1
+            r1 = P.m if pi == nparts - 1 else (P.m * (pi + 1) // nparts) & ~1
+            hpart.append([j, a0, a1, first, len(hpart_eb), r0, r1, len(hpart)])
+    L += ["struct ogt_int8 { int v[8]; };",
+          "static __device__ const ogt_int8 OGT_HPART[%d] = {" % max(len(hpart), 1),
+          ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (hpart or [[0] * 8])),
+          "};",
+          "static constexpr int OGT_N_HPART = %d;" % len(hpart),
+          "static __device__ const ogt_int8 OGT_HPART_EB[%d] = {" % max(len(hpart_eb), 1),
+          ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (hpart_eb or [[0] * 8])),
+          "};",
+          "static __device__ const ogt_int8 OGT_LGRP[%d] = {    // two records per group" % max(len(lgrp), 1),
+          ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (lgrp or [[0] * 8])),
+          "};"]
+    L += ["static constexpr int OGT_N_LGRP = %d;" % len(light_groups),
+          "static const int OGH_LGRP_J[%d] = {%s};" % (len(light_groups) + 1, ", ".join(
+              [str(r[0]) for r in light_groups] + [str(P.n)]))]
     L += table("int4", "OGT_ROWWAVE", rowwaves)
     L.append("static constexpr int OGT_N_ROWWAVES = %d;" % len(rowwaves))
     L += table("int4", "OGT_COL", col)

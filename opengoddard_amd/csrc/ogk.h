@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define OGK_ABI 5
+#define OGK_ABI 7
 #define OGK_MAX_PHASE 32
 
 // MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
@@ -30,6 +30,8 @@ typedef struct ogk_info {
     int32_t n_phase, n_mv, n_groups, n_cvec;
     int32_t n_y0;           // doubles of scratch for the unperturbed collocation products
     int32_t phase_nodes[OGK_MAX_PHASE];
+    int32_t n_eval_blocks;  // evaluation workgroups of one launch (what the mode-5 ticket counts)
+    int32_t n_heavy;        // columns that get a workgroup of their own (mode 5 scratch: 2 * n_y0 doubles each)
 } ogk_info;
 
 typedef struct ogk_args {
@@ -44,6 +46,9 @@ typedef struct ogk_args {
     double* z;              // [m] F0 - F0: 0, or NaN for non-finite rows (written by mode 0)
     int* nonfinite;         // number of non-finite rows of F(x0): counted by mode 0, read by mode 1
     int* nonfinite_next;    // the slot the *next* evaluation counts into (mode 0 zeroes it)
+    unsigned* ready;        // mode 5: ticket the evaluation workgroups count into (never reset) ...
+    unsigned ready_target;  // ... and the value it has once all of THIS launch's have
+    double* hscr;           // mode 5: [n_heavy][2][n_y0] private operands / base products of the heavy columns
     double* jt;             // [(col_hi-col_lo) * m] transposed Jacobian rows (mode 1)
     int32_t col_lo, col_hi; // FD columns handled by this launch
     int64_t dfrag_off[OGK_MAX_PHASE];
@@ -56,6 +61,7 @@ extern "C" {
 int ogk_get_info(ogk_info* out);
 // mode 0: evaluate F(x0) into f0 (+ scratch y0/t0/z).  mode 1: structured FD sweep over
 // [col_lo, col_hi) into jt (needs mode 0's outputs at the same x0).  mode 2: dense FD sweep.
+// mode 3 / 4: exact Jacobian, dense / structured (needs mode 0).  mode 5: modes 0 + 1 in one launch.
 // Only enqueues kernels on `stream`; returns a hipError_t value (0 = success).
 int ogk_launch(const ogk_args* args, int mode, void* stream);
 #ifdef __cplusplus

@@ -71,6 +71,25 @@ struct XCol {
         const double v = x0[i];
         return i == j ? xj : v;
     }
+    // base collocation product y0[slot offset + node]: from the scratch an evaluation left in memory
+    __device__ __forceinline__ double ldy(const double* p) const { return *p; }
+};
+
+// the same, for a workgroup of the fused launch that keeps the base products of its node tile in LDS
+// (an LDS read must not be a flat load through the y0 pointer: a flat load waits for every outstanding
+// store of the wavefront, i.e. for the fill that is supposed to drain underneath the item chains)
+struct XColL {
+    typedef double scalar;
+    const double* x0;
+    int j;
+    double xj;
+    const double* y0_first;     // &y0[offset of the group's first slot]
+    const double* yl;           // LDS: [state][N]
+    __device__ __forceinline__ double operator()(const int i) const {
+        const double v = x0[i];
+        return i == j ? xj : v;
+    }
+    __device__ __forceinline__ double ldy(const double* p) const { return yl[(int)(p - y0_first)]; }
 };
 
 constexpr int ROWS_COLS_PER_THREAD = 8;
@@ -240,6 +259,7 @@ struct XDual {
     const double* x0;
     int j;
     __device__ __forceinline__ ogdual operator()(const int i) const { return ogdual(x0[i], i == j ? 1.0 : 0.0); }
+    __device__ __forceinline__ double ldy(const double* p) const { return *p; }
 };
 
 __device__ __forceinline__ double dfrag_entry(const ogk_args& a, const int phase, const int N, const int k,
@@ -363,13 +383,17 @@ constexpr int SWEEP_WAVES = SWEEP_THREADS / 64;
 // dynamics term (a short dependent chain each, run concurrently).  Row workgroups: one
 // wavefront per 64 elements of one traced output.
 // ------------------------------------------------------------------------------------------
+template <bool FUSED>
 __device__ __forceinline__ void publish_row(const ogk_args& a, const int row, const double val) {
     const double zz = val - val;
     a.f0[row] = val;
-    a.z[row] = zz;
+    // fused launch: z may be read by other workgroups of the same kernel (non-finite rows only)
+    if (FUSED) __hip_atomic_store(&a.z[row], zz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else a.z[row] = zz;
     if (zz != zz) atomicAdd(a.nonfinite, 1);
 }
 
+template <bool FUSED>
 __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx, double* lds) {
     const int4 blk = OGT_EVALBLK[bx];                   // {group, node tile, first slot, #slots}
     const int nt = blk.y, mv0 = blk.z, nmv = blk.w;
@@ -440,12 +464,13 @@ __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx
         const double y = ybuf[s * 16 + lane];
         const double T = OgGen::tail_one(mv0 + s, k, base, a.cvec);
         const int row = rec.v[3] + k;
-        publish_row(a, row, y - T);
+        publish_row<FUSED>(a, row, y - T);
         a.t0[row] = T;
         a.y0[rec.v[4] + k] = y;
     }
 }
 
+template <bool FUSED>
 __device__ __forceinline__ void eval_rows_body(const ogk_args& a, const int bx) {
     const int w = bx * SWEEP_WAVES + ((int)threadIdx.x >> 6);
     if (w >= OGT_N_ROWWAVES) return;
@@ -455,7 +480,7 @@ __device__ __forceinline__ void eval_rows_body(const ogk_args& a, const int bx) 
     const XCol base{a.x0, -1, 0.0};
     int row;
     const double v = OgGen::item_value(rw.x, 0, k, base, a.y0, a.cvec, &row);
-    publish_row(a, row, v);
+    publish_row<FUSED>(a, row, v);
 }
 
 __global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, const int ndef) {
@@ -464,8 +489,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, cons
     // the evaluation after this one counts into the other slot: clear it now (stream order
     // makes this visible to the next launch)
     if (id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
-    if (id < ndef) eval_defect_body(a, id, lds);
-    else eval_rows_body(a, id - ndef);
+    if (id < ndef) eval_defect_body<false>(a, id, lds);
+    else eval_rows_body<false>(a, id - ndef);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -499,7 +524,8 @@ __device__ __forceinline__ bool marked(const unsigned* bits, const int r) {
 
 __device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const unsigned* bits,
                                          const int own_lo, const int own_hi, const int first,
-                                         const int stride, const bool all_finite) {
+                                         const int stride, const bool all_finite,
+                                         const bool z_from_this_launch = false) {
     if (OGK_EXP & 16) return;
     if (all_finite) {
         // every row of F(x0) is finite: (F0-F0)/dx is plain zero.  16-byte stores on the aligned
@@ -521,7 +547,9 @@ __device__ __forceinline__ void fill_row(const ogk_args& a, double* jrow, const 
         if (a0 && first == 0 && !(0 >= own_lo && 0 < own_hi) && !marked(bits, 0)) jrow[0] = 0.0;
     } else {                        // z carries NaN for the non-finite rows
         for (int r = first; r < OgGen::M; r += stride)
-            if ((r < own_lo || r >= own_hi) && !marked(bits, r)) jrow[r] = a.z[r];
+            if ((r < own_lo || r >= own_hi) && !marked(bits, r))
+                jrow[r] = z_from_this_launch ? __hip_atomic_load(&a.z[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                             : a.z[r];
     }
 }
 
@@ -766,6 +794,438 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Mode 5 (ogk_fused): modes 0 and 1 as ONE launch.  The first workgroups of the grid are the
+// evaluation workgroups (they produce F(x0) for the caller, as in mode 0); the sweep workgroups
+// that follow do not consume anything from them on the way: what a difference quotient needs of
+// the base point - the base value of a row item, the base collocation products of a node tile -
+// is recomputed by the workgroup that uses it, with the same device functions and the same MFMA
+// chain, hence the same bits.  A kernel boundary (drain, cache write-back / invalidate, dispatch)
+// between the evaluation and the sweep costs a third of a step at the sizes of this engine; loads
+// from another workgroup's results inside one kernel would have to bypass the (per-XCD, mutually
+// incoherent) L2s and queue behind the J_T write stream, which is slower still (both measured).
+//   fz_light_body   a run of <= LIGHT_COLS neighbouring columns whose defect items lie in one
+//                   (defect group, 16-node tile): the whole workgroup stages the group's operands
+//                   in LDS, one wavefront runs the tile's MFMA chain while the others stream the
+//                   zero fill, then lane = column, wavefront = item slot as in mode 1.
+//   fz_heavy_body   a column with many items, or items in several tiles: all base products, into
+//                   a private global scratch (same CU: coherent through the shared L1/L2 path).
+//   fz_tile_body    as tile_body, with a second accumulator for the unperturbed operand.
+// Only one thing still depends on the evaluation: when F(x0) has non-finite rows the fill is NaN
+// there, not 0.  The evaluation workgroups count themselves into a ticket; the wavefront of a
+// sweep workgroup that runs out of work first polls it (by then it is complete) and the non-finite
+// counter, and in that rare case the workgroup rewrites its fill from z.
+// ------------------------------------------------------------------------------------------
+// Timing experiments only (tools/fz_exp.sh): -DOGK_FZ=<mask> removes pieces of ogk_fused - 1 = no verdict
+// poll, 2 = no base-product chain in the light workgroups, 4 = no operand staging there, 16 = evaluation
+// workgroups do nothing, 32 = heavy columns skipped, 64 = mode 1's tile body, 2048 = no light items.
+// Results are wrong with any bit set.
+#ifndef OGK_FZ
+#define OGK_FZ 0
+#endif
+#ifndef OGK_SPIN_LIMIT
+#define OGK_SPIN_LIMIT (1u << 22)       // polls before a waiting wavefront gives up (seconds)
+#endif
+
+// barrier that orders LDS traffic only: the global stores of the fill keep draining underneath
+// (__syncthreads() would wait for them)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ void signal_ready(const ogk_args& a) {
+    __builtin_amdgcn_s_waitcnt(0);          // this wavefront's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(a.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one wavefront: true when F(x0) of THIS launch has a non-finite row
+__device__ __forceinline__ bool wave_nonfinite_verdict(const ogk_args& a) {
+    if (OGK_FZ & 1) return false;
+    unsigned polls = 0;
+    while ((int)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_target) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++polls > OGK_SPIN_LIMIT) __builtin_trap();     // never on a healthy device: fail loudly, do not hang
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    return __hip_atomic_load(a.nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// base collocation products of one (defect group, node tile) on one wavefront: states are the rows of the
+// A operand (xt[state][NP] in LDS or global), D^T panel straight from the operand image.  The k-ordered
+// chain of ogk_eval.  store(state, node, value) for the live entries.
+template <class Store>
+__device__ __forceinline__ void base_products_tile(const double* panel, const int N, const int nt,
+                                                   const int nmv, const double* xt, const int xstride,
+                                                   const Store& store) {
+    const int lane = (int)threadIdx.x & 63, lk = lane >> 4, srow = lane & 15;
+    const int KS = (N + 3) >> 2;
+    const double* bsrc = panel + lane;                  // the tile's [KS][64] operand panel
+    const bool live = srow < nmv;
+    const double* xrow = xt + (live ? srow : 0) * xstride;
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    constexpr int CH = 8;
+    for (int ks0 = 0; ks0 < KS; ks0 += CH) {
+        double bv[CH], av[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int ks = ks0 + u;
+            const int l = ks * 4 + lk;
+            bv[u] = ks < KS ? bsrc[ks * 64] : 0.0;
+            av[u] = (ks < KS && live && l < N) ? xrow[l] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (ks0 + u < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    // C/D layout: node = lane & 15, state = (lane >> 4) + 4 * reg
+    const int k = nt * 16 + (lane & 15);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int st = lk + 4 * reg;
+        if (st < nmv && k < N) store(st, k, acc[reg]);
+    }
+}
+
+// (F(x0 + h e_j) - F(x0)) / dx for one row item, with the base value from the partner lane (LIGHT_COLS further on, same item, unperturbed x)
+template <class XA>
+__device__ __forceinline__ void eval_item_paired(const ogk_args& a, const int4 item, const XA& xa, const bool base_role,
+                                                 const double dx, double* jrow) {
+    int row;
+    const double v = OgGen::item_value(item.x, item.y, item.z, xa, a.y0, a.cvec, &row);
+    const double v0 = __shfl_down(v, LIGHT_COLS);
+    if (!base_role) jrow[row] = (v - v0) / dx;
+}
+
+constexpr int FZ_MAXN = OgGen::MAX_NODES;                      // longest phase
+constexpr int FZ_NP = ((FZ_MAXN + 3) / 4) * 4;
+constexpr int FZ_BITS_WORDS = (LIGHT_COLS * ROW_WORDS + 3) & ~3;
+constexpr int FZ_ITEM_WAVES = SWEEP_WAVES - 1;                 // item slots of a light workgroup (the last wavefront
+                                                               // runs the MFMA chain instead)
+// LDS of a light workgroup: bitmaps | D panel of the tile [KS][64] | operands [state][NP] | base products [state][N]
+constexpr size_t FZ_LDS_BYTES = (size_t)FZ_BITS_WORDS * sizeof(unsigned) +
+                                ((size_t)(FZ_NP / 4) * 64 + (size_t)OgGen::MAX_NMV * (FZ_NP + FZ_MAXN)) * sizeof(double);
+constexpr int HPART_PAIRS = SWEEP_THREADS / 2;                 // codegen.HPART_ITEMS
+
+// flags a service wavefront raises in LDS for the other wavefronts of its workgroup (no s_barrier: a barrier
+// after the fill would make every wavefront wait until the slowest one has got its stores accepted)
+__device__ __forceinline__ void lds_flag_raise(int* flag, const int value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    *reinterpret_cast<volatile int*>(flag) = value;
+}
+__device__ __forceinline__ int lds_flag_wait(int* flag) {
+    int v;
+    while ((v = *reinterpret_cast<volatile int*>(flag)) == 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    return v;
+}
+
+__device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, unsigned* bits) {
+    __shared__ int s_flags[2];          // [0] base products ready, [1] verdict: 1 finite, 2 non-finite rows
+    // {first column, columns, y0 offset of the tile's first slot, node tile, first slot, slots (0: no defect
+    //  items), nodes, phase}
+    const ogt_int8 grp = OGT_LGRP[2 * b];
+    const ogt_int8 rng = OGT_LGRP[2 * b + 1];   // {items begin, end} of each column (saves the OGT_COL round trip)
+    const int first_j = grp.v[0], cnt = grp.v[1], y0_first = grp.v[2], nt = grp.v[3];
+    const int mv0 = grp.v[4], nmv = grp.v[5], N = grp.v[6], phase = grp.v[7];
+    const int KS = (N + 3) >> 2, NP = KS << 2;
+    const bool has_tile = nmv > 0;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool service = wave == SWEEP_WAVES - 1;   // no fill, no items: the tile's MFMA chain and the verdict
+    // items: lanes 0..LIGHT_COLS-1 evaluate at x0 + h e_j, the next LIGHT_COLS lanes the same items at x0 -
+    // one instruction stream, so the base value of a row item costs no time; wavefront = item slot
+    const int cl = lane % LIGHT_COLS;
+    const bool base_role = lane >= LIGHT_COLS;
+    const int ji = first_j + cl;
+    const bool item_on = !service && lane < 2 * LIGHT_COLS && cl < cnt && ji >= a.col_lo && ji < a.col_hi;
+    int4 coli = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < LIGHT_COLS; ++c)
+        if (cl == c) coli = make_int4(rng.v[2 * c], rng.v[2 * c + 1], 0, 0);
+    const double xb = a.x0[item_on ? ji : first_j];
+    const double hh = a.h[item_on ? ji : first_j];
+    int4 item = make_int4(0, 0, 0, 0);
+    const bool has_item = item_on && coli.x + wave < coli.y;
+    if (has_item) item = OGT_ELEM[coli.x + wave];
+    int own_lo[LIGHT_COLS], own_hi[LIGHT_COLS];     // the fill's view of each row: rows the MFMA tiles write
+#pragma unroll
+    for (int c = 0; c < LIGHT_COLS; ++c) {
+        const int4 cc = OGT_COL[first_j + (c < cnt ? c : 0)];
+        own_lo[c] = cc.z;
+        own_hi[c] = cc.w & ~HEAVY_FLAG;
+    }
+
+    double* dpanel = reinterpret_cast<double*>(bits + FZ_BITS_WORDS);
+    double* xt = dpanel + (FZ_NP / 4) * 64;                        // [state][NP] operands
+    double* yb = xt + OgGen::MAX_NMV * FZ_NP;                      // [state][N] base products (one tile of it)
+    const XCol xbase{a.x0, -1, 0.0};
+    if (has_tile && !(OGK_FZ & 4)) {
+        const double* src = a.dfrag + a.dfrag_off[phase] + (long)nt * KS * 64;
+        for (int i = tid; i < KS * 64; i += SWEEP_THREADS) dpanel[i] = src[i];
+        for (int s = wave; s < nmv; s += SWEEP_WAVES)              // a slot per wavefront: no divergence
+            for (int l = lane; l < NP; l += 64)
+                xt[s * NP + l] = l < N ? OgGen::mv_operand(mv0 + s, l, xbase, a.cvec) : 0.0;
+    }
+    for (int w = tid; w < LIGHT_COLS * ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
+    if (tid < 2) s_flags[tid] = 0;
+    __syncthreads();
+    if (has_item && !base_role) {
+        unsigned* mine = bits + cl * ROW_WORDS;
+        atomicOr(&mine[item.w >> 5], 1u << (item.w & 31));
+        for (int e = coli.x + wave + FZ_ITEM_WAVES; e < coli.y; e += FZ_ITEM_WAVES) {
+            const int r = OGT_ELEM[e].w;
+            atomicOr(&mine[r >> 5], 1u << (r & 31));
+        }
+    }
+    __syncthreads();
+    if (service) {
+        // the last barrier of this workgroup is behind us: from here on the wavefronts only meet through flags
+        if (has_tile && !(OGK_FZ & 2))
+            base_products_tile(dpanel, N, nt, nmv, xt, NP,
+                               [&](const int st, const int k, const double v) { yb[st * N + k] = v; });
+        if (lane == 0) lds_flag_raise(&s_flags[0], 1);
+        const bool nonfinite = wave_nonfinite_verdict(a);          // no stores in this wavefront's queue: the poll
+        if (lane == 0) lds_flag_raise(&s_flags[1], nonfinite ? 2 : 1);   // returns when the evaluation has
+        return;
+    }
+    // zeros (the verdict on non-finite rows comes at the end); drains while everything below runs
+#pragma unroll
+    for (int c = 0; c < LIGHT_COLS; ++c) {
+        const int jf = first_j + c;
+        if (c < cnt && jf >= a.col_lo && jf < a.col_hi)
+            fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],
+                     tid, 64 * FZ_ITEM_WAVES, true);
+    }
+    if (has_item && !(OGK_FZ & 2048)) {
+        lds_flag_wait(&s_flags[0]);
+        const double xj = xb + hh;
+        const double dx = xj - xb;
+        double* jrow = a.jt + (long)(ji - a.col_lo) * OgGen::M;
+        // item_value indexes y0 by slot offset + node; the accessor turns that into the LDS tile
+        const XColL xa{a.x0, base_role ? -1 : ji, xj, a.y0 + y0_first, yb};
+        eval_item_paired(a, item, xa, base_role, dx, jrow);
+        for (int e = coli.x + wave + FZ_ITEM_WAVES; e < coli.y; e += FZ_ITEM_WAVES)
+            eval_item_paired(a, OGT_ELEM[e], xa, base_role, dx, jrow);
+    }
+    if (lds_flag_wait(&s_flags[1]) == 2) {
+#pragma unroll
+        for (int c = 0; c < LIGHT_COLS; ++c) {
+            const int jf = first_j + c;
+            if (c < cnt && jf >= a.col_lo && jf < a.col_hi)
+                fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],
+                         tid, 64 * FZ_ITEM_WAVES, false, true);
+        }
+    }
+}
+
+// One part of a heavy column: HPART_PAIRS of its items (thread t < HPART_PAIRS at x0 + h e_j, thread
+// t + HPART_PAIRS the same item at x0), its share of the row's fill, and the base products of the node
+// tiles those items read - operands and products in a private global scratch (written and read by this
+// workgroup only: coherent through the CU's own cache path after a workgroup barrier).
+__device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx, unsigned* bits) {
+    __shared__ int s_nonfinite;
+    const ogt_int8 rec = OGT_HPART[pidx];      // {column, items begin, end, block list begin, end, fill rows begin, end}
+    const int j = rec.v[0];
+    if (j < a.col_lo || j >= a.col_hi) return;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int4 col = OGT_COL[j];
+    const int own_lo = col.z, own_hi = col.w & ~HEAVY_FLAG;
+    const double xb = a.x0[j];
+    const double xj = xb + a.h[j];
+    const double dx = xj - xb;
+    double* hx = a.hscr + (long)pidx * 2 * OgGen::N_Y0;            // operands of the collocation slots (as y0 is laid out)
+    double* hy = hx + OgGen::N_Y0;                                 // their base products
+    double* vbase = reinterpret_cast<double*>(bits + ((ROW_WORDS + 3) & ~3));    // [HPART_PAIRS] base values
+    const XCol xbase{a.x0, -1, 0.0};
+    for (int i = rec.v[3]; i < rec.v[4]; ++i) {
+        const ogt_int8 blk = OGT_HPART_EB[i];      // {first slot, slots, nodes, phase, y0 offset, node tile, first of its group}
+        if (!blk.v[6]) continue;                                   // this group's operands are staged already
+        const int N = blk.v[2];
+        for (int s = wave; s < blk.v[1]; s += SWEEP_WAVES)         // slots of a group are consecutive in the scratch
+            for (int l = lane; l < N; l += 64)
+                hx[blk.v[4] + s * N + l] = OgGen::mv_operand(blk.v[0] + s, l, xbase, a.cvec);
+    }
+    for (int w = tid; w < ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
+    if (tid == 0) s_nonfinite = 0;
+    __syncthreads();
+    // positions written by ANY part of this column are not filled
+    for (int e = col.x + tid; e < col.y; e += SWEEP_THREADS) {
+        const int r = OGT_ELEM[e].w;
+        atomicOr(&bits[r >> 5], 1u << (r & 31));
+    }
+    for (int i = rec.v[3] + wave; i < rec.v[4]; i += SWEEP_WAVES) {
+        const ogt_int8 blk = OGT_HPART_EB[i];
+        const int N = blk.v[2], KS = (N + 3) >> 2, nt = blk.v[5], off = blk.v[4];
+        // row s of the A operand starts N further on
+        base_products_tile(a.dfrag + a.dfrag_off[blk.v[3]] + (long)nt * KS * 64, N, nt, blk.v[1], hx + off, N,
+                           [&](const int st, const int k, const double v) { hy[off + st * N + k] = v; });
+    }
+    __syncthreads();
+    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+    const int r0 = rec.v[5], r1 = rec.v[6];
+    for (int r = r0 + tid; r < r1; r += SWEEP_THREADS)
+        if ((r < own_lo || r >= own_hi) && !marked(bits, r)) jrow[r] = 0.0;
+    const bool base_role = tid >= HPART_PAIRS;
+    const XCol xa{a.x0, base_role ? -1 : j, xj};
+    for (int e0 = rec.v[1]; e0 < rec.v[2]; e0 += HPART_PAIRS) {
+        const int e = e0 + (tid & (HPART_PAIRS - 1));
+        const bool on = e < rec.v[2];
+        int row = 0;
+        double v = 0.0;
+        if (on) {
+            const int4 it = OGT_ELEM[e];
+            v = OgGen::item_value(it.x, it.y, it.z, xa, hy, a.cvec, &row);
+            if (base_role) vbase[tid - HPART_PAIRS] = v;
+        }
+        lds_barrier();
+        if (on && !base_role) jrow[row] = (v - vbase[tid]) / dx;
+        if (e0 + HPART_PAIRS < rec.v[2]) lds_barrier();            // vbase is reused by the next round
+    }
+    if (wave == SWEEP_WAVES - 1 && wave_nonfinite_verdict(a) && lane == 0) s_nonfinite = 1;
+    lds_barrier();
+    if (s_nonfinite)
+        for (int r = r0 + tid; r < r1; r += SWEEP_THREADS)
+            if ((r < own_lo || r >= own_hi) && !marked(bits, r))
+                jrow[r] = __hip_atomic_load(&a.z[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, double* xt) {
+    const int4 tile = OGT_TILE[bx];                    // {slot, tile group, node tile}
+    const int slot = tile.x, nt = tile.z;
+    const ogt_int8 rec = OGT_SLOT[slot];
+    const int N = rec.v[0], leaf = rec.v[2], row0 = rec.v[3];
+    const bool diag = rec.v[6] & 1, generic = rec.v[6] & 2;
+    const int dep0 = rec.v[7] >> 12, ndep = rec.v[7] & 0xfff;
+    const int KS = (N + 3) >> 2;
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
+    // the slot's operand vector once per workgroup (eight column tiles share it)
+    const XCol xbase{a.x0, -1, 0.0};
+    for (int l = tid; l < KS * 4; l += SWEEP_THREADS)
+        xt[l] = l < N ? OgGen::mv_operand(slot, l, xbase, a.cvec) : 0.0;
+    __syncthreads();
+    const int l0 = (tile.y * SWEEP_WAVES + wave) * 16;  // first slice offset of this wave's tile
+    if (l0 >= N || leaf + l0 >= a.col_hi || leaf + l0 + 16 <= a.col_lo) return;
+    const int k = nt * 16 + (lane & 15);                // output node of this lane
+    const int la = l0 + (lane & 15);                    // A-operand row of this lane
+
+    const double* bsrc = a.dfrag + a.dfrag_off[rec.v[5]] + (long)nt * KS * 64 + lane;
+    constexpr int CH = 10;                              // k-steps per chunk
+    double bv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) bv[u] = (u < KS) ? bsrc[u * 64] : 0.0;
+    const bool a_on = la < N;
+    const double xa_b = a.x0[a_on ? leaf + la : leaf];
+    const double xa_h = a.h[a_on ? leaf + la : leaf];
+    const bool k_on = k < N;
+    const int row = row0 + (k_on ? k : 0);
+    double xbv[4], hv[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int lc = l0 + lk + 4 * reg;
+        const int jj = leaf + ((k_on && lc < N) ? lc : 0);
+        xbv[reg] = a.x0[jj];
+        hv[reg] = a.h[jj];
+    }
+    // dynamics terms (base, and perturbed on the diagonal): their chains run while the loads are in flight
+    const double t_base = k_on ? OgGen::tail_one(slot, k, xbase, a.cvec) : 0.0;
+    double t_diag = t_base;
+    bool have_diag = false;
+    {
+        const int lc = k;                                // column whose perturbed node is k
+        const int reg = (lc - l0 - lk) >> 2;
+        have_diag = diag && k_on && lc >= l0 + lk && ((lc - l0 - lk) & 3) == 0 && reg < 4 && lc < N &&
+                    leaf + lc >= a.col_lo && leaf + lc < a.col_hi;
+        if (have_diag) {
+            const int jd = leaf + lc;
+            const double xbd = a.x0[jd];
+            const XCol xd{a.x0, jd, xbd + a.h[jd]};
+            t_diag = OgGen::tail_one(slot, k, xd, a.cvec);
+        }
+    }
+    double hit_v = 0.0;
+    if (a_on) {
+        const XCol xa{a.x0, leaf + la, xa_b + xa_h};
+        hit_v = OgGen::mv_operand(slot, la, xa, a.cvec);
+    }
+    // acc: 16 perturbed columns x 16 nodes; accb: the unperturbed operand in every row (the base product)
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0};
+    for (int ks0 = 0; ks0 < KS; ks0 += CH) {
+        double bn[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int ks = ks0 + CH + u;
+            bn[u] = (ks < KS) ? bsrc[ks * 64] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int ks = ks0 + u;
+            if (ks < KS) {
+                const double base_op = xt[ks * 4 + lk];
+                const double aop = (ks * 4 + lk == la) ? hit_v : base_op;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bv[u], acc, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f64_16x16x4f64(base_op, bv[u], accb, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) bv[u] = bn[u];
+    }
+    if (!k_on) return;
+    const double f_base = accb[0] - t_base;             // every row of accb holds the base product of node k
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int lc = l0 + lk + 4 * reg;
+        const int j = leaf + lc;
+        if (lc >= N || j < a.col_lo || j >= a.col_hi) continue;
+        const double xj = xbv[reg] + hv[reg];
+        const double dx = xj - xbv[reg];
+        double t = (have_diag && lc == k) ? t_diag : t_base;
+        if (generic) {
+            bool reads = diag && k == lc;
+            for (int d = dep0; d < dep0 + ndep; ++d) {
+                const int kind = OgGen::DEP_KIND(d), base_d = OgGen::DEP_BASE(d);
+                reads = reads || (kind == 1 ? (base_d + k == j)
+                                            : (j >= base_d && j < base_d + OgGen::DEP_CNT(d)));
+            }
+            if (reads) {
+                const XCol xg{a.x0, j, xj};
+                t = OgGen::tail_one(slot, k, xg, a.cvec);
+            }
+        }
+        const double val = acc[reg] - t;
+        a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - f_base) / dx;
+    }
+}
+
+__global__ __launch_bounds__(SWEEP_THREADS) void ogk_fused(const ogk_args a, const int ndef, const int n_eval,
+                                                           const int group_lo) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int id = (int)blockIdx.x;
+    if (id < n_eval) {
+        if (id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
+        if (!(OGK_FZ & 16)) {
+            if (id < ndef) eval_defect_body<true>(a, id, lds);
+            else eval_rows_body<true>(a, id - ndef);
+        }
+        signal_ready(a);
+        return;
+    }
+    id -= n_eval;
+    if (id < OGT_N_TILES) {
+        if (OGK_FZ & 64) tile_body(a, id);
+        else fz_tile_body(a, id, lds);
+    } else if (id < OGT_N_TILES + OGT_N_HPART) {
+        if (!(OGK_FZ & 32)) fz_heavy_part(a, id - OGT_N_TILES, reinterpret_cast<unsigned*>(lds));
+    } else {
+        fz_light_body(a, group_lo + id - OGT_N_TILES - OGT_N_HPART, reinterpret_cast<unsigned*>(lds));
+    }
+}
+
 __global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
@@ -807,6 +1267,8 @@ size_t sweep_lds_bytes() { return (size_t)LIGHT_COLS * ROW_WORDS * sizeof(unsign
 
 extern "C" int ogk_get_info(ogk_info* out) {
     out->abi = OGK_ABI;
+    out->n_eval_blocks = defect_blocks() + (OGT_N_ROWWAVES + SWEEP_WAVES - 1) / SWEEP_WAVES;
+    out->n_heavy = OGT_N_HPART;
     out->n = OgGen::N_VAR;
     out->m = OgGen::M;
     out->m_eq = OgGen::M_EQ;
@@ -838,6 +1300,19 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         const int light_blocks = (ncols + LIGHT_COLS - 1) / LIGHT_COLS;
         hipLaunchKernelGGL(ogk_sweep, dim3(OGT_N_TILES + OgGen::N_HEAVY + light_blocks),
                            dim3(SWEEP_THREADS), sweep_lds_bytes(), stream, *args);
+        return (int)hipGetLastError();
+    }
+    if (mode == 5) {
+        const int eval_row_blocks = (OGT_N_ROWWAVES + SWEEP_WAVES - 1) / SWEEP_WAVES;
+        // light workgroups whose columns touch [col_lo, col_hi)
+        int glo = 0, ghi = OGT_N_LGRP;
+        while (glo < ghi && OGH_LGRP_J[glo + 1] <= args->col_lo) ++glo;
+        while (ghi > glo && OGH_LGRP_J[ghi - 1] >= args->col_hi) --ghi;
+        size_t lds_bytes = defect_lds_bytes() > FZ_LDS_BYTES ? defect_lds_bytes() : FZ_LDS_BYTES;
+        const size_t heavy_lds = (size_t)((ROW_WORDS + 3) & ~3) * sizeof(unsigned) + HPART_PAIRS * sizeof(double);
+        if (heavy_lds > lds_bytes) lds_bytes = heavy_lds;
+        hipLaunchKernelGGL(ogk_fused, dim3(ndef + eval_row_blocks + OGT_N_TILES + OGT_N_HPART + (ghi - glo)),
+                           dim3(SWEEP_THREADS), lds_bytes, stream, *args, ndef, ndef + eval_row_blocks, glo);
         return (int)hipGetLastError();
     }
     if (mode == 4) {

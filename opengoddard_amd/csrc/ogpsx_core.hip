@@ -79,9 +79,15 @@ struct og_problem_s {
     double* d_xop = nullptr;
     double* d_t0 = nullptr;
     double* d_z = nullptr;
-    int* d_flags = nullptr;             // two non-finite-row counters used alternately
-    int flag_slot = 0;
-    int sweep_mode = 1;                 // 1 structured (default), 2 dense (OGPSX_SWEEP=dense)
+    double* d_hscr = nullptr;           // fused launch: private base products of the heavy-column workgroups
+    int* d_flags = nullptr;             // two non-finite-row counters used alternately, then the ticket of the
+    int flag_slot = 0;                  // fused launch (evaluation workgroups that have finished, ever)
+    int n_eval_blocks = 0;
+    unsigned fused_launches = 0;
+    // how og_fd_sweep_dev runs: 5 evaluation + structured sweep in one launch (default), 1 the same as two
+    // launches (OGPSX_SWEEP=split), 2 evaluation + dense sweep (OGPSX_SWEEP=dense).  og_fd_columns_dev (the
+    // sweep alone, F(x0) supplied) uses 1 or 2.
+    int sweep_mode = 5;
     int exact_mode = 4;                 // 4 structured (default), 3 dense (OGPSX_SWEEP=dense)
     hipStream_t stream = nullptr;
 };
@@ -101,6 +107,9 @@ void fill_args(const og_problem_s* p, ogk_args* a, const double* x, const double
     a->z = p->d_z;
     a->nonfinite = p->d_flags + p->flag_slot;
     a->nonfinite_next = p->d_flags + (p->flag_slot ^ 1);
+    a->ready = reinterpret_cast<unsigned*>(p->d_flags + 2);
+    a->ready_target = 0;
+    a->hscr = p->d_hscr;
     a->jt = jt;
     a->col_lo = lo;
     a->col_hi = hi;
@@ -272,10 +281,20 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMalloc(&p->d_xop, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_t0, sizeof(double) * (size_t)p->m);
     if (e == hipSuccess) e = hipMalloc(&p->d_z, sizeof(double) * (size_t)p->m);
-    if (e == hipSuccess) e = hipMalloc(&p->d_flags, 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 2 * sizeof(int));
+    if (e == hipSuccess)
+        e = hipMalloc(&p->d_hscr, sizeof(double) * 2 * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1) *
+                                      (size_t)(info.n_heavy > 0 ? info.n_heavy : 1));
+    if (e == hipSuccess) e = hipMalloc(&p->d_flags, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(int));
+    p->n_eval_blocks = info.n_eval_blocks;
     const char* mode_env = getenv("OGPSX_SWEEP");
+    // one launch while the Jacobian is small (the kernel boundary is a third of the step there); measured
+    // cross-over between C3 (22 MB: fused 9% faster) and C4 (48 MB: split 6% faster)
+    p->sweep_mode = (double)p->n * (double)p->m * sizeof(double) <= 32.0e6 ? 5 : 1;
     if (mode_env && std::string(mode_env) == "dense") p->sweep_mode = 2, p->exact_mode = 3;
+    if (mode_env && std::string(mode_env) == "split") p->sweep_mode = 1;
+    if (mode_env && std::string(mode_env) == "fused") p->sweep_mode = 5;
+    if (p->n_eval_blocks <= 0 && p->sweep_mode == 5) p->sweep_mode = 1;
     if (e == hipSuccess) e = hipStreamCreate(&p->stream);
     if (e != hipSuccess) {
         og_problem_destroy(p);
@@ -300,9 +319,12 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_t0);
     hipFree(p->d_z);
     hipFree(p->d_flags);
+    hipFree(p->d_hscr);
     if (p->module) dlclose(p->module);
     delete p;
 }
+
+int og_sweep_mode(og_handle p) { return p ? p->sweep_mode : 0; }
 
 int og_problem_dims(og_handle p, int32_t* n, int32_t* m, int32_t* m_eq, int32_t* m_ineq) {
     if (!p) return fail(1, "og_problem_dims: null handle");
@@ -330,8 +352,16 @@ int og_fd_sweep_dev(og_handle p, const double* d_x, const double* d_h, int32_t l
     ogk_args a;
     p->flag_slot ^= 1;
     fill_args(p, &a, d_x, d_h, d_F0, d_JT, lo, hi);
-    int rc = p->launch(&a, 0, hip_stream);          // F(x0) first: the sweep subtracts it
-    if (!rc) rc = p->launch(&a, p->sweep_mode, hip_stream);
+    int rc;
+    if (p->sweep_mode == 5 && hi > lo) {
+        // one launch: the evaluation workgroups count into a ticket that is never reset
+        p->fused_launches += 1;
+        a.ready_target = p->fused_launches * (unsigned)p->n_eval_blocks;
+        rc = p->launch(&a, 5, hip_stream);
+    } else {
+        rc = p->launch(&a, 0, hip_stream);          // F(x0) first: the sweep subtracts it
+        if (!rc) rc = p->launch(&a, p->sweep_mode == 5 ? 1 : p->sweep_mode, hip_stream);
+    }
     if (rc) return fail(100 + rc, std::string("og_fd_sweep_dev: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
@@ -342,7 +372,7 @@ int og_fd_columns_dev(og_handle p, const double* d_x, const double* d_h, int32_t
     if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_fd_columns_dev: bad column range");
     ogk_args a;
     fill_args(p, &a, d_x, d_h, const_cast<double*>(d_F0), d_JT, lo, hi);
-    int rc = p->launch(&a, p->sweep_mode, hip_stream);
+    int rc = p->launch(&a, p->sweep_mode == 5 ? 1 : p->sweep_mode, hip_stream);
     if (rc) return fail(100 + rc, std::string("og_fd_columns_dev: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }

@@ -106,6 +106,11 @@ class HipEngine:
                                                   _native.dptr(JT), _native.dptr(F0)), "og_jacobian_exact")
         return F0, JT
 
+    @property
+    def sweep_mode(self):
+        """How ``sweep_dev`` runs (``og_sweep_mode``): "fused" (one launch), "split" or "dense"."""
+        return {5: "fused", 1: "split", 2: "dense"}[self._lib.og_sweep_mode(self._handle)]
+
     def exact_dev(self, d_x, col_lo, col_hi, d_JT, d_F0, stream=0):
         _native.check(self._lib.og_jacobian_exact_dev(self._handle, d_x, int(col_lo), int(col_hi), d_JT, d_F0,
                                                       stream), "og_jacobian_exact_dev")

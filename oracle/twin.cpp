@@ -28,6 +28,7 @@ struct XVec {
     typedef double scalar;
     const double* x;
     double operator()(const int i) const { return x[i]; }
+    double ldy(const double* p) const { return *p; }          // base collocation product (scratch of the evaluation)
 };
 
 // one decision variable carries a unit derivative: F evaluated on it yields dF/dx_j exactly
@@ -36,6 +37,7 @@ struct XDual {
     const double* x;
     int j;
     ogdual operator()(const int i) const { return ogdual(x[i], i == j ? 1.0 : 0.0); }
+    double ldy(const double* p) const { return *p; }
 };
 
 inline double fma_chain(const double a, const double b, const double acc) { return __builtin_fma(a, b, acc); }

@@ -102,20 +102,30 @@ def test_column_sharding_is_bitwise_invariant(name, golden):
 
 @pytest.mark.parametrize("name", ALL)
 def test_structured_sweep_equals_dense_sweep(name, golden, monkeypatch):
-    """The default sweep skips (row, column) pairs without a data dependency; the literal dense
-    sweep (OGPSX_SWEEP=dense) evaluates everything.  They must agree entry for entry, and the
-    structural zeros must be exact zeros in both."""
+    """The structured sweep skips (row, column) pairs without a data dependency.  It runs either as ONE
+    launch together with the evaluation of F(x0) (ogk_fused, where every sweep workgroup recomputes the
+    base values it needs; the default up to 32 MB of Jacobian) or as two launches (ogk_eval, ogk_sweep);
+    the literal dense sweep (OGPSX_SWEEP=dense) evaluates everything.  They must agree entry for entry,
+    and the structural zeros must be exact zeros in all of them."""
     G = golden("cfg_" + name)
     x, h = G["x"][-1], G["h"][-1]
-    prob, obj, eng, tw = _engine_and_twin(name)
-    F_s, JT_s = eng.sweep_stacked(x, h)
-    eng.close()
-    monkeypatch.setenv("OGPSX_SWEEP", "dense")
-    prob, obj, eng, tw = _engine_and_twin(name)
-    F_d, JT_d = eng.sweep_stacked(x, h)
-    eng.close()
-    assert np.array_equal(F_s, F_d)
-    assert np.array_equal(JT_s, JT_d)
+    out = {}
+    for layout in ("fused", "split", "dense"):
+        monkeypatch.setenv("OGPSX_SWEEP", layout)
+        prob, obj, eng, tw = _engine_and_twin(name)
+        assert eng.sweep_mode == layout
+        out[layout] = eng.sweep_stacked(x, h)
+        if layout == "fused":                        # back to back on one handle: the ticket advances
+            for _ in range(3):
+                again = eng.sweep_stacked(x, h)
+                assert np.array_equal(again[0], out[layout][0]) and np.array_equal(again[1], out[layout][1])
+            lo, hi = eng.n // 4, eng.n // 2
+            assert np.array_equal(eng.sweep_stacked(x, h, lo, hi)[1], out[layout][1][lo:hi])
+        eng.close()
+    F_s, JT_s = out["fused"]
+    for layout in ("split", "dense"):
+        assert np.array_equal(F_s, out[layout][0])
+        assert np.array_equal(JT_s, out[layout][1])
     assert (JT_s != 0).mean() < 0.2
 
 
@@ -160,24 +170,37 @@ def test_full_size_jacobian_has_the_pseudospectral_structure(name, golden):
     eng.close()
 
 
-def test_non_finite_rows_propagate_like_dense_fd():
+@pytest.mark.parametrize("layout", ["fused", "split"])
+@pytest.mark.parametrize("name,state", [("goddard", 2), ("polar_tsto", 4)])
+def test_non_finite_rows_propagate_like_dense_fd(name, state, layout, monkeypatch):
     """A row that is NaN/inf at x0 makes its whole Jacobian row NaN in SciPy's dense FD
-    ((NaN - NaN)/dx); the structured sweep must reproduce that, not write zeros."""
+    ((NaN - NaN)/dx); the structured sweep must reproduce that, not write zeros.  (In the fused launch
+    this is the one thing the sweep workgroups take from the evaluation workgroups of the same kernel:
+    they fill with zeros first and rewrite the fill when the ticket says there are non-finite rows.)"""
     from opengoddard_amd.engine import HipEngine
     from oracle import np_path, twin
-    prob, obj = problems.build("goddard")
+    monkeypatch.setenv("OGPSX_SWEEP", layout)
+    prob, obj = problems.build(name)
     lb, ub = np_path.bounds_arrays(prob)
     x = np.clip(prob.p, lb, ub)
-    x[prob.index_states(2, 0, 7)] = 0.0          # mass = 0 at one node -> division by zero
+    x[prob.index_states(state, 0, 7)] = 0.0      # mass = 0 at one node -> division by zero
     eng = HipEngine(prob, obj)
+    assert eng.sweep_mode == layout
     tw = twin.Twin(prob, obj, program=eng.program, header=eng.header)
     h = _native.fd_step(x, lb, ub)
-    F0, JT = eng.sweep_stacked(x, h)
     F0c, JTc = tw.sweep(x, h)
-    assert not np.isfinite(F0).all()
-    assert np.array_equal(F0, F0c, equal_nan=True)
-    assert np.array_equal(np.isnan(JT), np.isnan(JTc))
-    assert np.array_equal(JT, JTc, equal_nan=True)
+    assert not np.isfinite(F0c).all()
+    for _ in range(2):
+        F0, JT = eng.sweep_stacked(x, h)
+        assert np.array_equal(F0, F0c, equal_nan=True)
+        assert np.array_equal(np.isnan(JT), np.isnan(JTc))
+        assert np.array_equal(JT, JTc, equal_nan=True)
+    # and back to a finite point on the same handle: no NaN may linger in the fill
+    x2 = np.clip(prob.p, lb, ub)
+    h2 = _native.fd_step(x2, lb, ub)
+    F0, JT = eng.sweep_stacked(x2, h2)
+    F0c, JTc = tw.sweep(x2, h2)
+    assert np.array_equal(F0, F0c) and np.array_equal(JT, JTc)
     eng.close()
 
 

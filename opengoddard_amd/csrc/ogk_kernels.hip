@@ -963,16 +963,30 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
     double* xt = dpanel + (FZ_NP / 4) * 64;                        // [state][NP] operands
     double* yb = xt + OgGen::MAX_NMV * FZ_NP;                      // [state][N] base products (one tile of it)
     const XCol xbase{a.x0, -1, 0.0};
-    if (has_tile && !(OGK_FZ & 4)) {
+    // the service wavefront's inputs (D^T panel of the tile, the group's operands) are requested now by everybody
+    // and parked in LDS only before the second barrier: by then they have arrived, nobody waits for them
+    constexpr int ST_D = (FZ_NP / 4 * 64 + SWEEP_THREADS - 1) / SWEEP_THREADS;
+    constexpr int ST_S = (OgGen::MAX_NMV + SWEEP_WAVES - 1) / SWEEP_WAVES, ST_L = (FZ_NP + 63) / 64;
+    double st_d[ST_D], st_x[ST_S * ST_L];
+    const bool staging = has_tile && !(OGK_FZ & 4);
+    if (staging) {
         const double* src = a.dfrag + a.dfrag_off[phase] + (long)nt * KS * 64;
-        for (int i = tid; i < KS * 64; i += SWEEP_THREADS) dpanel[i] = src[i];
-        for (int s = wave; s < nmv; s += SWEEP_WAVES)              // a slot per wavefront: no divergence
-            for (int l = lane; l < NP; l += 64)
-                xt[s * NP + l] = l < N ? OgGen::mv_operand(mv0 + s, l, xbase, a.cvec) : 0.0;
+#pragma unroll
+        for (int u = 0; u < ST_D; ++u) {
+            const int i = tid + u * SWEEP_THREADS;
+            st_d[u] = i < KS * 64 ? src[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < ST_S; ++u)                             // a slot per wavefront: no divergence
+#pragma unroll
+            for (int q = 0; q < ST_L; ++q) {
+                const int sl = wave + u * SWEEP_WAVES, l = lane + q * 64;
+                st_x[u * ST_L + q] = (sl < nmv && l < N) ? OgGen::mv_operand(mv0 + sl, l, xbase, a.cvec) : 0.0;
+            }
     }
     for (int w = tid; w < LIGHT_COLS * ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
     if (tid < 2) s_flags[tid] = 0;
-    __syncthreads();
+    lds_barrier();            // (only LDS data crosses this workgroup's barriers: loads in flight stay in flight)
     if (has_item && !base_role) {
         unsigned* mine = bits + cl * ROW_WORDS;
         atomicOr(&mine[item.w >> 5], 1u << (item.w & 31));
@@ -981,7 +995,21 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
             atomicOr(&mine[r >> 5], 1u << (r & 31));
         }
     }
-    __syncthreads();
+    if (staging) {
+#pragma unroll
+        for (int u = 0; u < ST_D; ++u) {
+            const int i = tid + u * SWEEP_THREADS;
+            if (i < KS * 64) dpanel[i] = st_d[u];
+        }
+#pragma unroll
+        for (int u = 0; u < ST_S; ++u)
+#pragma unroll
+            for (int q = 0; q < ST_L; ++q) {
+                const int sl = wave + u * SWEEP_WAVES, l = lane + q * 64;
+                if (sl < nmv && l < NP) xt[sl * NP + l] = st_x[u * ST_L + q];
+            }
+    }
+    lds_barrier();
     if (service) {
         // the last barrier of this workgroup is behind us: from here on the wavefronts only meet through flags
         if (has_tile && !(OGK_FZ & 2))
@@ -1042,6 +1070,8 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
     double* hy = hx + OgGen::N_Y0;                                 // their base products
     double* vbase = reinterpret_cast<double*>(bits + ((ROW_WORDS + 3) & ~3));    // [HPART_PAIRS] base values
     const XCol xbase{a.x0, -1, 0.0};
+    const int e_first = rec.v[1] + (tid & (HPART_PAIRS - 1));
+    const int4 it_first = OGT_ELEM[e_first < rec.v[2] ? e_first : rec.v[1]];   // requested now, used after the chains
     for (int i = rec.v[3]; i < rec.v[4]; ++i) {
         const ogt_int8 blk = OGT_HPART_EB[i];      // {first slot, slots, nodes, phase, y0 offset, node tile, first of its group}
         if (!blk.v[6]) continue;                                   // this group's operands are staged already
@@ -1078,7 +1108,7 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
         int row = 0;
         double v = 0.0;
         if (on) {
-            const int4 it = OGT_ELEM[e];
+            const int4 it = e0 == rec.v[1] ? it_first : OGT_ELEM[e];
             v = OgGen::item_value(it.x, it.y, it.z, xa, hy, a.cvec, &row);
             if (base_role) vbase[tid - HPART_PAIRS] = v;
         }

@@ -76,8 +76,8 @@ def cpu_baseline(name, seconds=10.0):
     return out
 
 
-def measured_traffic(workload):
-    """HBM-side bytes per ogk_sweep launch from the committed rocprofv3 --pmc passes
+def measured_traffic(workload, kernel="ogk_sweep"):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/rNN_traffic.json, made by tools/summarize_profiles.py; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  None when this workload was not profiled."""
     import glob
@@ -85,7 +85,7 @@ def measured_traffic(workload):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
         try:
             with open(path) as fh:
-                entry = json.load(fh).get(workload, {}).get("ogk_sweep")
+                entry = json.load(fh).get(workload, {}).get(kernel)
         except (OSError, ValueError):
             continue
         if entry and entry.get("hbm_bytes_per_launch"):
@@ -286,7 +286,7 @@ def main():
     alg_bytes = 8.0 * ((ncols + 1) * n + m * ncols + sumN2)
     achieved = alg_bytes / (kern_ms_mean * 1e-3) / 1e9
 
-    traffic = measured_traffic(a.workload) if world == 1 else None
+    traffic = measured_traffic(a.workload, "ogk_fused" if fused else "ogk_sweep") if world == 1 else None
     result = {
         "metric": "NLP-callback evals/sec (cost+constr+FD-Jacobian)",
         "value": (3 * n + 2) * a.steps / elapsed,

@@ -842,16 +842,23 @@ __device__ __forceinline__ void signal_ready(const ogk_args& a) {
         __hip_atomic_fetch_add(a.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one wavefront: true when F(x0) of THIS launch has a non-finite row
+// one wavefront: true when F(x0) of THIS launch has a non-finite row.  The two non-finite counters and the
+// ticket share one 16-byte line ({nonfinite[0], nonfinite[1], ticket, -}, ogpsx_core.hip) and are read with ONE
+// agent-scope load: a workgroup's count of non-finite rows is performed before its ticket, both at the memory
+// side, so a line that shows the complete ticket shows the complete count - no second round trip.
 __device__ __forceinline__ bool wave_nonfinite_verdict(const ogk_args& a) {
     if (OGK_FZ & 1) return false;
+    const int* line = reinterpret_cast<const int*>(a.ready) - 2;
+    const int slot = (int)(a.nonfinite - line);
     unsigned polls = 0;
-    while ((int)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_target) < 0) {
-        __builtin_amdgcn_s_sleep(4);
+    int4 v;
+    for (;;) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(line) : "memory");
+        if ((int)((unsigned)v.z - a.ready_target) >= 0) break;
+        __builtin_amdgcn_s_sleep(2);
         if (++polls > OGK_SPIN_LIMIT) __builtin_trap();     // never on a healthy device: fail loudly, do not hang
     }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    return __hip_atomic_load(a.nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    return (slot == 0 ? v.x : v.y) != 0;
 }
 
 // base collocation products of one (defect group, node tile) on one wavefront: states are the rows of the

@@ -56,9 +56,12 @@ namespace ogm {
 
 // (a quantity that does not depend on the seeded variable keeps derivative 0 through a singular
 // rule - sqrt at 0, log at 0, asin at 1 - instead of 0/0; a forward difference sees 0 there too)
+// (at r == 0 the slope is taken as 0 as well: where the dynamics contain V |V|-like terms, V^2 underflows to 0
+// for |V| < 1e-154 while dV^2 = 2V is still non-zero, and 2V / (2 * 0) would put an inf - then 0 * inf = NaN
+// - into a Jacobian whose composite entry is 0; a bare sqrt(x) at x = 0 has no finite derivative in any mode)
 OG_HDI ogdual sqrt_(const ogdual a) {
     const double r = sqrt_(a.v);
-    return ogdual(r, a.d == 0.0 ? 0.0 : a.d / (2.0 * r));
+    return ogdual(r, (a.d == 0.0 || r == 0.0) ? 0.0 : a.d / (2.0 * r));
 }
 OG_HDI ogdual exp_(const ogdual a) {
     const double e = exp_(a.v);

@@ -2268,7 +2268,10 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     const int coop_G = std::max(coop_slices, (int)std::min<size_t>(256, std::max<size_t>(64, pricing_bytes / (256 * 1024))));
     const size_t coop_lds = (size_t)(4 * qp->qcap + 2 * coop_width + 2 * nr + COOP_THREADS) * sizeof(double) +
                             (size_t)3 * qp->qcap * sizeof(int) + (size_t)((mg + 2 * nq + 31) / 32 + 1) * sizeof(unsigned) + 64;
-    const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 512);
+    // measured (tests/perf/solve_timing.py, OGSQP_GI=single|coop): the cooperative kernel wins from C2's size
+    // (46 free directions: 0.43 vs 0.47 s) through C4' (395: 2.4 vs 3.2 s) and C3 (467: 0.49 vs 0.67 s per 25
+    // iterations) to C5; the single-workgroup kernel stays for the trivial sizes and as the fallback
+    const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 32);
     bool coop_done = false;
     if (nr > 0 && use_coop && coop_slices <= 64 && coop_lds <= LDS_LIMIT) {
         // the whole active-set loop in one cooperative launch

@@ -2268,10 +2268,15 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     const int coop_G = std::max(coop_slices, (int)std::min<size_t>(256, std::max<size_t>(64, pricing_bytes / (256 * 1024))));
     const size_t coop_lds = (size_t)(4 * qp->qcap + 2 * coop_width + 2 * nr + COOP_THREADS) * sizeof(double) +
                             (size_t)3 * qp->qcap * sizeof(int) + (size_t)((mg + 2 * nq + 31) / 32 + 1) * sizeof(unsigned) + 64;
-    // measured (tests/perf/solve_timing.py, OGSQP_GI=single|coop): the cooperative kernel wins from C2's size
-    // (46 free directions: 0.43 vs 0.47 s) through C4' (395: 2.4 vs 3.2 s) and C3 (467: 0.49 vs 0.67 s per 25
-    // iterations) to C5; the single-workgroup kernel stays for the trivial sizes and as the fallback
-    const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 32);
+    // measured (tests/perf/solve_timing.py, OGSQP_GI=single|coop): per active-set change the cooperative kernel
+    // wins from C2's size on (C3: 40 vs 72 us; the first 25 major iterations of C3, 300-400 changes per
+    // subproblem, take 0.49 instead of 0.67 s), but its launch costs 0.15-0.3 ms more than the first batch of
+    // single-workgroup launches and late in a solve a subproblem moves a handful of rows: over whole solves the
+    // time per subproblem is the same within 4 % below 512 free directions (C2 1.60 / 1.77, C3' 1.50 / 1.65, C3
+    // 7.96 / 8.28 ms, single / cooperative).  The single-workgroup kernel is also the one whose sums run in the
+    // restatement's order (with exact Jacobians it walks SciPy's path iteration for iteration), so it stays the
+    // default there; from 512 on (C4, C5) the cooperative kernel is 1.5-3x faster per subproblem.
+    const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 512);
     bool coop_done = false;
     if (nr > 0 && use_coop && coop_slices <= 64 && coop_lds <= LDS_LIMIT) {
         // the whole active-set loop in one cooperative launch

@@ -313,8 +313,12 @@ def main():
                      "bytes_actually_written_per_launch": 8.0 * m * ncols,
                      "kernel_ms_mean": kern_ms_mean, "kernel_ms_median": kern_ms,
                      "kernel_ms_single_launch_events": kern_ms_single,
+                     # the two-launch form of the same step (og_fd_sweep above 32 MB of Jacobian, OGPSX_SWEEP=split),
+                     # timed in this run: the FD sweep kernel on its own, and evaluation + sweep as a step
                      "split_eval_kernel_ms_mean": eval_ms_mean,
                      "split_sweep_kernel_ms_mean": columns_ms_mean,
+                     "split_sweep_kernel_frac": alg_bytes / (columns_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "split_step_frac": alg_bytes / ((columns_ms_mean + eval_ms_mean) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "frac_of_whole_step": alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
     }
     if world == 1 and rank == 0 and not a.no_cpu_baseline:

@@ -934,6 +934,12 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
     __shared__ int s_flags[2];          // [0] base products ready, [1] verdict: 1 finite, 2 non-finite rows
     // {first column, columns, y0 offset of the tile's first slot, node tile, first slot, slots (0: no defect
     //  items), nodes, phase}
+#if OGK_TRACE                           // tools/trace_fused.py: phase stamps instead of results
+    long long tr[6] = {(long long)__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0};
+#define FZ_STAMP(i) tr[i] = (long long)__builtin_amdgcn_s_memrealtime()
+#else
+#define FZ_STAMP(i) do { } while (0)
+#endif
     const ogt_int8 grp = OGT_LGRP[2 * b];
     const ogt_int8 rng = OGT_LGRP[2 * b + 1];   // {items begin, end} of each column (saves the OGT_COL round trip)
     const int first_j = grp.v[0], cnt = grp.v[1], y0_first = grp.v[2], nt = grp.v[3];
@@ -1017,14 +1023,24 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
             }
     }
     lds_barrier();
+    FZ_STAMP(1);
     if (service) {
         // the last barrier of this workgroup is behind us: from here on the wavefronts only meet through flags
         if (has_tile && !(OGK_FZ & 2))
             base_products_tile(dpanel, N, nt, nmv, xt, NP,
                                [&](const int st, const int k, const double v) { yb[st * N + k] = v; });
+        FZ_STAMP(2);
         if (lane == 0) lds_flag_raise(&s_flags[0], 1);
         const bool nonfinite = wave_nonfinite_verdict(a);          // no stores in this wavefront's queue: the poll
         if (lane == 0) lds_flag_raise(&s_flags[1], nonfinite ? 2 : 1);   // returns when the evaluation has
+#if OGK_TRACE
+        FZ_STAMP(5);
+        if (lane == 0 && first_j >= a.col_lo && first_j < a.col_hi) {
+            double* t = a.jt + (long)(first_j - a.col_lo) * OgGen::M + 8 * wave;
+            t[0] = 3.0e6; t[1] = (double)tr[0]; t[2] = (double)tr[1]; t[3] = (double)tr[2]; t[4] = 0.0; t[5] = 0.0;
+            t[6] = (double)tr[5]; t[7] = 0.0;
+        }
+#endif
         return;
     }
     // zeros (the verdict on non-finite rows comes at the end); drains while everything below runs
@@ -1035,8 +1051,10 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
             fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],
                      tid, 64 * FZ_ITEM_WAVES, true);
     }
+    FZ_STAMP(2);
     if (has_item && !(OGK_FZ & 2048)) {
         lds_flag_wait(&s_flags[0]);
+        FZ_STAMP(3);
         const double xj = xb + hh;
         const double dx = xj - xb;
         double* jrow = a.jt + (long)(ji - a.col_lo) * OgGen::M;
@@ -1046,6 +1064,20 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
         for (int e = coli.x + wave + FZ_ITEM_WAVES; e < coli.y; e += FZ_ITEM_WAVES)
             eval_item_paired(a, OGT_ELEM[e], xa, base_role, dx, jrow);
     }
+    FZ_STAMP(4);
+#if OGK_TRACE
+    {
+        const int verdict = lds_flag_wait(&s_flags[1]);
+        FZ_STAMP(5);
+        if (lane == 0 && first_j >= a.col_lo && first_j < a.col_hi) {
+            __builtin_amdgcn_s_waitcnt(0);
+            double* t = a.jt + (long)(first_j - a.col_lo) * OgGen::M + 8 * wave;
+            t[0] = 1.0e6 + (has_item ? 1 : 0); t[1] = (double)tr[0]; t[2] = (double)tr[1]; t[3] = (double)tr[2];
+            t[4] = (double)tr[3]; t[5] = (double)tr[4]; t[6] = (double)tr[5]; t[7] = (double)verdict;
+        }
+        return;
+    }
+#endif
     if (lds_flag_wait(&s_flags[1]) == 2) {
 #pragma unroll
         for (int c = 0; c < LIGHT_COLS; ++c) {

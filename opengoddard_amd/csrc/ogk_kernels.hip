@@ -1380,6 +1380,12 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         size_t lds_bytes = defect_lds_bytes() > FZ_LDS_BYTES ? defect_lds_bytes() : FZ_LDS_BYTES;
         const size_t heavy_lds = (size_t)((ROW_WORDS + 3) & ~3) * sizeof(unsigned) + HPART_PAIRS * sizeof(double);
         if (heavy_lds > lds_bytes) lds_bytes = heavy_lds;
+        if (lds_bytes > 64 * 1024) {
+            // a tile's panel and operands do not fit the default LDS window (hundreds of nodes x 16 states):
+            // the same work as two launches
+            const int rc0 = ogk_launch(args, 0, stream_);
+            return rc0 ? rc0 : ogk_launch(args, 1, stream_);
+        }
         hipLaunchKernelGGL(ogk_fused, dim3(ndef + eval_row_blocks + OGT_N_TILES + OGT_N_HPART + (ghi - glo)),
                            dim3(SWEEP_THREADS), lds_bytes, stream, *args, ndef, ndef + eval_row_blocks, glo);
         return (int)hipGetLastError();

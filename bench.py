@@ -319,7 +319,13 @@ def main():
                      "split_sweep_kernel_ms_mean": columns_ms_mean,
                      "split_sweep_kernel_frac": alg_bytes / (columns_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "split_step_frac": alg_bytes / ((columns_ms_mean + eval_ms_mean) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "frac_of_whole_step": alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
+                     "frac_of_whole_step": alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
+                     "note": ("ogk_fused = evaluation of F(x0) + the FD sweep in ONE launch: its duration contains the "
+                              "evaluation's latency chain, so its fraction is a whole-step figure; the FD sweep kernel on "
+                              "its own (ogk_sweep, two-launch form, timed in this run) is split_sweep_kernel_frac, and the "
+                              "two launches as a step split_step_frac") if fused else
+                             "two launches per step (ogk_eval, ogk_sweep): frac is the sweep kernel's, frac_of_whole_step "
+                             "includes the evaluation"},
     }
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)

@@ -19,9 +19,10 @@ for _ in range(5):
     F0, JT = eng.sweep_stacked(x, h)
 flat = JT.ravel()
 def records(tag_lo, tag_hi, width):
+    """rows: the stamps of one wavefront, with the J_T row (= first column of its workgroup) appended"""
     idx = np.nonzero((flat >= tag_lo) & (flat <= tag_hi))[0]
     idx = idx[idx + width < flat.size]
-    recs = np.array([flat[i:i + width] for i in idx])
+    recs = np.array([np.r_[flat[i:i + width], i // JT.shape[1]] for i in idx])
     return recs[recs[:, 1] > 1e6] if len(recs) else recs
 item = records(1.0e6, 1.0e6 + 1, 8)
 serv = records(3.0e6, 3.0e6, 8)
@@ -35,3 +36,10 @@ line("start", item[:, 1]); line("after barrier 2", item[:, 2]); line("fill issue
 w = item[item[:, 0] == 1.0e6 + 1]
 line("base products flag seen", w[:, 4]); line("items done", w[:, 5]); line("end (verdict seen)", item[:, 6])
 line("service: chain done", serv[:, 3]); line("service: verdict", serv[:, 6])
+# which workgroups are the late ones?  second barrier by position in the grid (first column of the workgroup)
+order = np.argsort(serv[:, -1])
+b2 = (serv[order, 2] - t0) * 0.01
+st = (serv[order, 1] - t0) * 0.01
+print("   second barrier / start by tenth of the grid (first to last light workgroup):")
+for part, (x, y) in enumerate(zip(np.array_split(b2, 10), np.array_split(st, 10))):
+    print("      tenth %d: start p50 %5.2f  barrier 2 p50 %5.2f  max %5.2f" % (part, np.median(y), np.median(x), x.max()))

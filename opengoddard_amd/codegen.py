@@ -29,6 +29,17 @@ import os
 
 HEAVY_COLUMN_ELEMENTS = 32       # columns with more dependent elements get a whole workgroup
 LIGHT_COLS = 4                   # columns per workgroup otherwise (csrc/ogk_kernels.hip OGK_LIGHT_COLS)
+
+
+def fused_cols(n):
+    """Columns per light workgroup of the fused launch.  Measured (bench step, MI355X): 8 beats 4 once there
+    are enough columns to keep every CU busy with one workgroup (C3 14.6 -> 13.6 us, C4 30.6 -> 28.9 us: half as
+    many light workgroups share a CU with an MFMA-tile workgroup), 4 beats 8 on small problems (C2 5.6 vs 6.6
+    us), 16 loses everywhere (C3 18.8 us).  ``OG_FUSED_COLS`` overrides (timing experiments)."""
+    env = os.environ.get("OG_FUSED_COLS")
+    return int(env) if env else (8 if n >= 1024 else 4)
+
+
 HPART_ITEMS = 256                # items of a heavy column per workgroup in the fused launch (half of SWEEP_THREADS)
 MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "1"))
 
@@ -796,7 +807,7 @@ def emit_header(P):
             run = None
             continue
         key = col_tile[j]
-        if run is not None and run[0] + run[1] == j and run[1] < LIGHT_COLS and \
+        if run is not None and run[0] + run[1] == j and run[1] < fused_cols(P.n) and \
                 (key is None or run[2] is None or run[2] == key):
             run[1] += 1
             run[2] = run[2] if run[2] is not None else key
@@ -917,17 +928,15 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     # columns again as a host table (ogk_launch picks the groups a column range touches)
     # (everything a workgroup needs about its tile in ONE record: index tables looked up with a runtime
     # group number end up as stack copies in the kernel)
-    lgrp = []
+    lgrp, lrng = [], []
     for j0, cnt, key in light_groups:
-        ranges = []
-        for c in range(LIGHT_COLS):
-            ranges += [col_ptr[j0 + c], col_ptr[j0 + c + 1]] if c < cnt else [0, 0]
+        for c in range(fused_cols(P.n)):
+            lrng.append([col_ptr[j0 + c], col_ptr[j0 + c + 1], 0, 0] if c < cnt else [0, 0, 0, 0])
         if key:
             g = P.groups[key[0]]
             lgrp.append([j0, cnt, y0_off[g.mv_slots[0]], key[1], g.mv_slots[0], len(g.mv_slots), g.length, g.phase])
         else:
             lgrp.append([j0, cnt, 0, 0, 0, 0, 0, 0])
-        lgrp.append(ranges)
     # heavy columns of the fused launch: HPART_ITEMS items per workgroup (one lane pair each), the row's
     # fill split evenly; each part lists the evaluation blocks (defect group, node tile) whose base
     # products its items read (bit 16: first block of its group in the list -> stage that group's operands)
@@ -957,9 +966,11 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
           "static __device__ const ogt_int8 OGT_HPART_EB[%d] = {" % max(len(hpart_eb), 1),
           ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (hpart_eb or [[0] * 8])),
           "};",
-          "static __device__ const ogt_int8 OGT_LGRP[%d] = {    // two records per group" % max(len(lgrp), 1),
+          "static constexpr int OGT_LGRP_COLS = %d;" % fused_cols(P.n),
+          "static __device__ const ogt_int8 OGT_LGRP[%d] = {" % max(len(lgrp), 1),
           ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (lgrp or [[0] * 8])),
           "};"]
+    L += table("int4", "OGT_LRNG", lrng)      # {items begin, end} per (group, column)
     L += ["static constexpr int OGT_N_LGRP = %d;" % len(light_groups),
           "static const int OGH_LGRP_J[%d] = {%s};" % (len(light_groups) + 1, ", ".join(
               [str(r[0]) for r in light_groups] + [str(P.n)]))]

@@ -897,19 +897,20 @@ __device__ __forceinline__ void base_products_tile(const double* panel, const in
     }
 }
 
-// (F(x0 + h e_j) - F(x0)) / dx for one row item, with the base value from the partner lane (LIGHT_COLS further on, same item, unperturbed x)
+constexpr int FZ_COLS = OGT_LGRP_COLS;          // columns of a light workgroup of the fused launch (tracer)
+// (F(x0 + h e_j) - F(x0)) / dx for one row item, with the base value from the partner lane (FZ_COLS further on, same item, unperturbed x)
 template <class XA>
 __device__ __forceinline__ void eval_item_paired(const ogk_args& a, const int4 item, const XA& xa, const bool base_role,
                                                  const double dx, double* jrow) {
     int row;
     const double v = OgGen::item_value(item.x, item.y, item.z, xa, a.y0, a.cvec, &row);
-    const double v0 = __shfl_down(v, LIGHT_COLS);
+    const double v0 = __shfl_down(v, FZ_COLS);
     if (!base_role) jrow[row] = (v - v0) / dx;
 }
 
 constexpr int FZ_MAXN = OgGen::MAX_NODES;                      // longest phase
 constexpr int FZ_NP = ((FZ_MAXN + 3) / 4) * 4;
-constexpr int FZ_BITS_WORDS = (LIGHT_COLS * ROW_WORDS + 3) & ~3;
+constexpr int FZ_BITS_WORDS = (FZ_COLS * ROW_WORDS + 3) & ~3;
 constexpr int FZ_ITEM_WAVES = SWEEP_WAVES - 1;                 // item slots of a light workgroup (the last wavefront
                                                                // runs the MFMA chain instead)
 // LDS of a light workgroup: bitmaps | D panel of the tile [KS][64] | operands [state][NP] | base products [state][N]
@@ -940,8 +941,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
 #else
 #define FZ_STAMP(i) do { } while (0)
 #endif
-    const ogt_int8 grp = OGT_LGRP[2 * b];
-    const ogt_int8 rng = OGT_LGRP[2 * b + 1];   // {items begin, end} of each column (saves the OGT_COL round trip)
+    const ogt_int8 grp = OGT_LGRP[b];
     const int first_j = grp.v[0], cnt = grp.v[1], y0_first = grp.v[2], nt = grp.v[3];
     const int mv0 = grp.v[4], nmv = grp.v[5], N = grp.v[6], phase = grp.v[7];
     const int KS = (N + 3) >> 2, NP = KS << 2;
@@ -949,24 +949,21 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const bool service = wave == SWEEP_WAVES - 1;   // no fill, no items: the tile's MFMA chain and the verdict
-    // items: lanes 0..LIGHT_COLS-1 evaluate at x0 + h e_j, the next LIGHT_COLS lanes the same items at x0 -
+    // items: lanes 0..FZ_COLS-1 evaluate at x0 + h e_j, the next FZ_COLS lanes the same items at x0 -
     // one instruction stream, so the base value of a row item costs no time; wavefront = item slot
-    const int cl = lane % LIGHT_COLS;
-    const bool base_role = lane >= LIGHT_COLS;
+    const int cl = lane % FZ_COLS;
+    const bool base_role = lane >= FZ_COLS;
     const int ji = first_j + cl;
-    const bool item_on = !service && lane < 2 * LIGHT_COLS && cl < cnt && ji >= a.col_lo && ji < a.col_hi;
-    int4 coli = make_int4(0, 0, 0, 0);
-#pragma unroll
-    for (int c = 0; c < LIGHT_COLS; ++c)
-        if (cl == c) coli = make_int4(rng.v[2 * c], rng.v[2 * c + 1], 0, 0);
+    const bool item_on = !service && lane < 2 * FZ_COLS && cl < cnt && ji >= a.col_lo && ji < a.col_hi;
+    const int4 coli = OGT_LRNG[b * FZ_COLS + cl];   // {items begin, end} of this lane's column (no OGT_COL round trip)
     const double xb = a.x0[item_on ? ji : first_j];
     const double hh = a.h[item_on ? ji : first_j];
     int4 item = make_int4(0, 0, 0, 0);
     const bool has_item = item_on && coli.x + wave < coli.y;
     if (has_item) item = OGT_ELEM[coli.x + wave];
-    int own_lo[LIGHT_COLS], own_hi[LIGHT_COLS];     // the fill's view of each row: rows the MFMA tiles write
+    int own_lo[FZ_COLS], own_hi[FZ_COLS];     // the fill's view of each row: rows the MFMA tiles write
 #pragma unroll
-    for (int c = 0; c < LIGHT_COLS; ++c) {
+    for (int c = 0; c < FZ_COLS; ++c) {
         const int4 cc = OGT_COL[first_j + (c < cnt ? c : 0)];
         own_lo[c] = cc.z;
         own_hi[c] = cc.w & ~HEAVY_FLAG;
@@ -997,7 +994,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
                 st_x[u * ST_L + q] = (sl < nmv && l < N) ? OgGen::mv_operand(mv0 + sl, l, xbase, a.cvec) : 0.0;
             }
     }
-    for (int w = tid; w < LIGHT_COLS * ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
+    for (int w = tid; w < FZ_COLS * ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
     if (tid < 2) s_flags[tid] = 0;
     lds_barrier();            // (only LDS data crosses this workgroup's barriers: loads in flight stay in flight)
     if (has_item && !base_role) {
@@ -1045,7 +1042,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
     }
     // zeros (the verdict on non-finite rows comes at the end); drains while everything below runs
 #pragma unroll
-    for (int c = 0; c < LIGHT_COLS; ++c) {
+    for (int c = 0; c < FZ_COLS; ++c) {
         const int jf = first_j + c;
         if (c < cnt && jf >= a.col_lo && jf < a.col_hi)
             fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],
@@ -1080,7 +1077,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
 #endif
     if (lds_flag_wait(&s_flags[1]) == 2) {
 #pragma unroll
-        for (int c = 0; c < LIGHT_COLS; ++c) {
+        for (int c = 0; c < FZ_COLS; ++c) {
             const int jf = first_j + c;
             if (c < cnt && jf >= a.col_lo && jf < a.col_hi)
                 fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],

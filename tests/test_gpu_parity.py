@@ -129,6 +129,19 @@ def test_structured_sweep_equals_dense_sweep(name, golden, monkeypatch):
     assert (JT_s != 0).mean() < 0.2
 
 
+def test_launch_form_is_chosen_by_size(monkeypatch):
+    """og_fd_sweep runs as one fused launch up to 32 MB of Jacobian and as two launches above
+    (include/ogpsx.h og_sweep_mode); OGPSX_SWEEP overrides."""
+    from opengoddard_amd.engine import HipEngine
+    monkeypatch.delenv("OGPSX_SWEEP", raising=False)
+    for name, expect in (("goddard", "fused"), ("polar_tsto", "fused"), ("low_thrust", "split")):
+        prob, obj = problems.build(name)
+        eng = HipEngine(prob, obj)
+        assert (eng.n * eng.m * 8 <= 32e6) == (expect == "fused")
+        assert eng.sweep_mode == expect
+        eng.close()
+
+
 @pytest.mark.parametrize("name", ["polar_tsto", "low_thrust", "launch4"])
 def test_full_size_jacobian_has_the_pseudospectral_structure(name, golden):
     """Size-independent properties of the equality Jacobian at BASELINE.json's full sizes

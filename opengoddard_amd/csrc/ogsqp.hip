@@ -602,6 +602,13 @@ __global__ void k_check_diag(const double* diagL, int meq, int* flag, double* dt
 // L x = rhs (transposed = 0) or L' x = rhs (transposed = 1); L = strictly lower part of Tc with
 // diagL on the diagonal.  One workgroup; 64 x 64 diagonal blocks are solved by one wavefront out
 // of LDS, the panel below (above) is a GEMV spread over all threads.
+// value of v in lane `src` (uniform): two v_readlane_b32 instead of the LDS round trip of __shfl
+__device__ __forceinline__ double readlane_f64(const double v, const int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, int ld, const double* __restrict__ diagL,
                                                int meq, int transposed, double scale_rhs, const double* __restrict__ rhs,
                                                double* __restrict__ x, const double* __restrict__ dthresh,
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
             double xv = lane < bs ? xs[i0 + lane] : 0.0;
             if (!transposed) {
                 for (int c = 0; c < bs; ++c) {
-                    const double dc = diagL[i0 + c], num = __shfl(xv, c);
+                    const double dc = diagL[i0 + c], num = readlane_f64(xv, c);
                     const bool gone = !(fabs(dc) > tiny);
                     if (gone && fabs(num) > tol && lane == 0) flag[0] = 1;
                     const double xc = gone ? 0.0 : num / dc;
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
             } else {
                 for (int c = bs - 1; c >= 0; --c) {
                     const double dc = diagL[i0 + c];
-                    const double xc = !(fabs(dc) > tiny) ? 0.0 : __shfl(xv, c) / dc;
+                    const double xc = !(fabs(dc) > tiny) ? 0.0 : readlane_f64(xv, c) / dc;
                     if (lane == c)
                         xv = xc;
                     else if (lane < c)

@@ -209,7 +209,7 @@ def main():
 
     def step(gather=True):
         # one pass of the hot path: F(x0) and this rank's FD columns (og_fd_sweep_dev: one launch, or two above
-        # 32 MB of Jacobian - og_sweep_mode)
+        # 100 MB of Jacobian - og_sweep_mode)
         eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, d_local.data_ptr(), d_F0.data_ptr(), stream)
         if collective and gather:
             dist.all_gather_into_tensor(d_full, d_local)
@@ -313,7 +313,7 @@ def main():
                      "bytes_actually_written_per_launch": 8.0 * m * ncols,
                      "kernel_ms_mean": kern_ms_mean, "kernel_ms_median": kern_ms,
                      "kernel_ms_single_launch_events": kern_ms_single,
-                     # the two-launch form of the same step (og_fd_sweep above 32 MB of Jacobian, OGPSX_SWEEP=split),
+                     # the two-launch form of the same step (og_fd_sweep above 100 MB of Jacobian, OGPSX_SWEEP=split),
                      # timed in this run: the FD sweep kernel on its own, and evaluation + sweep as a step
                      "split_eval_kernel_ms_mean": eval_ms_mean,
                      "split_sweep_kernel_ms_mean": columns_ms_mean,

@@ -288,9 +288,10 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(int));
     p->n_eval_blocks = info.n_eval_blocks;
     const char* mode_env = getenv("OGPSX_SWEEP");
-    // one launch while the Jacobian is small (the kernel boundary is a third of the step there); measured
-    // cross-over between C3 (22 MB: fused 9% faster) and C4 (48 MB: split 6% faster)
-    p->sweep_mode = (double)p->n * (double)p->m * sizeof(double) <= 32.0e6 ? 5 : 1;
+    // one launch while the kernel boundary is a noticeable part of the step.  Measured (bench step, fused /
+    // split, us): 1 MB 5.7 / 8.6, 5 MB 11.1 / 13.8, 19 MB (C3) 13.6 / 16.3, 43 MB 20.3 / 24.1, 48 MB (C4) 29.2 /
+    // 28.5, 77 MB 26.6 / 28.5, 171 MB 41.5 / 38.5, 304 MB (C5) 68.5 / 66.8
+    p->sweep_mode = (double)p->n * (double)p->m * sizeof(double) <= 100.0e6 ? 5 : 1;
     if (mode_env && std::string(mode_env) == "dense") p->sweep_mode = 2, p->exact_mode = 3;
     if (mode_env && std::string(mode_env) == "split") p->sweep_mode = 1;
     if (mode_env && std::string(mode_env) == "fused") p->sweep_mode = 5;

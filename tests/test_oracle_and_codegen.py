@@ -196,3 +196,63 @@ def test_tracer_rejects_untraceable_callbacks():
         np.sum(p[0:4])
     with pytest.raises(tr.TraceError):
         float(p[0])
+
+
+def _table(src, name):
+    """rows of a generated `static __device__ const <type> NAME[n] = {...};` table as lists of ints"""
+    import re
+    m = re.search(r"%s\[\d+\] = \{(.*?)\n\};" % name, src, re.S)
+    assert m, name
+    return [[int(v) for v in re.findall(r"-?\d+", row)] for row in re.findall(r"\{+([^{}]*)\}+", m.group(1))]
+
+
+@pytest.mark.parametrize("name", ["goddard", "polar_tsto_shipped", "polar_tsto", "low_thrust", "launch4", "table_ascent"])
+def test_fused_launch_work_lists_partition_the_sweep(name):
+    """The work lists of the fused launch (codegen._sweep_records): every column is either heavy or in exactly
+    one light group; a light group is a run of neighbouring columns whose defect items all lie in the group's
+    (defect group, 16-node tile); the parts of a heavy column take each of its items once, split the fill of
+    its row without gap or overlap, and list exactly the evaluation blocks their defect items read."""
+    import re
+    from opengoddard_amd import codegen, problems
+    prob, obj = problems.build(name)
+    P = codegen.trace_problem(prob, obj)
+    src = codegen.emit_header(P)
+    col, elem = _table(src, "OGT_COL"), _table(src, "OGT_ELEM")
+    lgrp, lrng = _table(src, "OGT_LGRP"), _table(src, "OGT_LRNG")
+    hpart, heb, evalblk = _table(src, "OGT_HPART"), _table(src, "OGT_HPART_EB"), _table(src, "OGT_EVALBLK")
+    cols = int(re.search(r"OGT_LGRP_COLS = (\d+)", src).group(1))
+    assert cols == codegen.fused_cols(P.n) and len(lrng) == len(lgrp) * cols
+    heavy = {j for j in range(P.n) if col[j][3] & (1 << 30)}
+    owner = {}
+    for b, (j0, cnt, y0off, nt, mv0, nmv, N, phase) in enumerate(lgrp):
+        assert 1 <= cnt <= cols
+        for c in range(cnt):
+            j = j0 + c
+            assert j not in heavy and j not in owner
+            owner[j] = b
+            assert lrng[b * cols + c][:2] == col[j][:2]
+            for g, o, k, row in elem[col[j][0]:col[j][1]]:
+                if P.groups[g].kind == "defect":
+                    assert nmv > 0 and P.groups[g].mv_slots[0] == mv0 and len(P.groups[g].mv_slots) == nmv
+                    assert k >> 4 == nt and P.groups[g].length == N and P.groups[g].phase == phase
+    assert set(owner) | heavy == set(range(P.n))
+    seen, fill = {}, {}
+    for j, e0, e1, b0, b1, r0, r1, idx in hpart:
+        assert j in heavy and 0 < e1 - e0 <= codegen.HPART_ITEMS
+        seen.setdefault(j, []).append((e0, e1))
+        fill.setdefault(j, []).append((r0, r1))
+        need = {(g, k >> 4) for g, o, k, row in elem[e0:e1] if P.groups[g].kind == "defect"}
+        listed = set()
+        for mv0, nmv, N, phase, y0off, nt, first, _ in heb[b0:b1]:
+            g = next(i for i, gr in enumerate(P.groups) if gr.kind == "defect" and gr.mv_slots[0] == mv0)
+            listed.add((g, nt))
+        assert listed == need
+        firsts = [r[6] for r in heb[b0:b1]]
+        assert sum(firsts) == len({r[0] for r in heb[b0:b1]})          # one staging pass per group
+    for j in heavy:
+        spans = sorted(seen[j])
+        assert spans[0][0] == col[j][0] and spans[-1][1] == col[j][1]
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        rows = sorted(fill[j])
+        assert rows[0][0] == 0 and rows[-1][1] == P.m and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    assert evalblk                                                       # (used by the heavy parts' lists)

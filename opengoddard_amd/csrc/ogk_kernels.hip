@@ -1269,7 +1269,7 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
 }
 
 __global__ __launch_bounds__(SWEEP_THREADS) void ogk_fused(const ogk_args a, const int ndef, const int n_eval,
-                                                           const int group_lo) {
+                                                           const int group_lo, const int n_light) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int id = (int)blockIdx.x;
     if (id < n_eval) {
@@ -1282,13 +1282,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_fused(const ogk_args a, con
         return;
     }
     id -= n_eval;
-    if (id < OGT_N_TILES) {
-        if (OGK_FZ & 64) tile_body(a, id);
-        else fz_tile_body(a, id, lds);
-    } else if (id < OGT_N_TILES + OGT_N_HPART) {
-        if (!(OGK_FZ & 32)) fz_heavy_part(a, id - OGT_N_TILES, reinterpret_cast<unsigned*>(lds));
+    // the light workgroups carry the J_T stream and have the longest life: dispatched right behind the
+    // evaluation workgroups (which must come first: the service wavefronts poll their ticket)
+    if (id < n_light) {
+        fz_light_body(a, group_lo + id, reinterpret_cast<unsigned*>(lds));
+    } else if (id < n_light + OGT_N_HPART) {
+        if (!(OGK_FZ & 32)) fz_heavy_part(a, id - n_light, reinterpret_cast<unsigned*>(lds));
     } else {
-        fz_light_body(a, group_lo + id - OGT_N_TILES - OGT_N_HPART, reinterpret_cast<unsigned*>(lds));
+        if (OGK_FZ & 64) tile_body(a, id - n_light - OGT_N_HPART);
+        else fz_tile_body(a, id - n_light - OGT_N_HPART, lds);
     }
 }
 
@@ -1384,7 +1386,7 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
             return rc0 ? rc0 : ogk_launch(args, 1, stream_);
         }
         hipLaunchKernelGGL(ogk_fused, dim3(ndef + eval_row_blocks + OGT_N_TILES + OGT_N_HPART + (ghi - glo)),
-                           dim3(SWEEP_THREADS), lds_bytes, stream, *args, ndef, ndef + eval_row_blocks, glo);
+                           dim3(SWEEP_THREADS), lds_bytes, stream, *args, ndef, ndef + eval_row_blocks, glo, ghi - glo);
         return (int)hipGetLastError();
     }
     if (mode == 4) {

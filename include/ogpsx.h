@@ -104,6 +104,22 @@ int og_fd_columns_dev(og_handle h, const double* d_x, const double* d_hstep,
                       int32_t col_lo, int32_t col_hi, double* d_JT, const double* d_F0,
                       void* hip_stream);
 
+/* ---- persistent-zero output buffers ------------------------------------------------------------
+ * Most of J_T is structurally zero (a row of F reads a handful of decision variables; the pattern is
+ * fixed by the traced callbacks), and SciPy's dense loop recomputes those zeros as (F0 - F0)/dx for
+ * every column of every sweep (scipy:_numdiff.py:592-620).  A caller that keeps ONE output buffer per
+ * block of columns can register it: og_jt_register_dev zero-fills d_JT ((col_hi-col_lo)*m doubles,
+ * enqueued on hip_stream) and from then on og_fd_sweep_dev / og_fd_columns_dev / og_jacobian_exact_dev
+ * called with exactly (d_JT, col_lo, col_hi) write only the entries that can be non-zero.  The result
+ * in the buffer is the same matrix, entry for entry, as without registration - including sweeps at
+ * points where F(x) has non-finite rows (those rows become NaN in every column, as dense differencing
+ * makes them; the library re-cleans the buffer on the next sweep by itself).  Contract: between
+ * sweeps the caller only reads the buffer; work on it must be stream-ordered after the registration.
+ * At most 63 registrations per handle; the host-pointer entry points register their own staging
+ * buffer.  No reference counterpart (the reference allocates a fresh dense array per sweep). */
+int og_jt_register_dev(og_handle h, double* d_JT, int32_t col_lo, int32_t col_hi, void* hip_stream);
+int og_jt_unregister_dev(og_handle h, double* d_JT);
+
 /* ---- exact Jacobian (opt-in, changes the numbers SLSQP sees) ---
  * Same layout as the sweep: JT[(j - col_lo) * m + r] = dF_r/dx_j, but by forward-mode
  * differentiation of the traced callbacks (no step h, no subtraction, no FD noise; where a callback

@@ -45,6 +45,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_fd_columns_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_jt_register_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "og_jt_unregister_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "og_jacobian_exact": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p]),
     "og_jacobian_exact_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define OGK_ABI 7
+#define OGK_ABI 8
 #define OGK_MAX_PHASE 32
 
 // MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
@@ -50,6 +50,15 @@ typedef struct ogk_args {
     unsigned ready_target;  // ... and the value it has once all of THIS launch's have
     double* hscr;           // mode 5: [n_heavy][2][n_y0] private operands / base products of the heavy columns
     double* jt;             // [(col_hi-col_lo) * m] transposed Jacobian rows (mode 1)
+    // Persistent-zero output (og_jt_register_dev, include/ogpsx.h).  jt_sparse != 0: the structural zeros of
+    // `jt` are known to hold zeros already, so the sweep writes ONLY the positions that can be non-zero (row
+    // items and collocation tiles).  The exception is kept on the device, because the asynchronous entry
+    // points never learn it: a sweep whose F(x0) has non-finite rows fills its rows completely (NaN where
+    // dense FD gives NaN) and stores its own generation number into *jt_state; the next sweep into the same
+    // buffer finds *jt_state == jt_gen - 1 and fills completely once more (zeros), which cleans it.
+    int32_t jt_sparse;
+    uint32_t jt_gen;        // number of this launch among the launches into this registered buffer (1, 2, ...)
+    uint32_t* jt_state;     // generation of the last launch into the buffer that left NaN fill behind
     int32_t col_lo, col_hi; // FD columns handled by this launch
     int64_t dfrag_off[OGK_MAX_PHASE];
 } ogk_args;

@@ -92,6 +92,18 @@ struct XColL {
     __device__ __forceinline__ double ldy(const double* p) const { return yl[(int)(p - y0_first)]; }
 };
 
+// Persistent-zero output (ogk.h: jt_sparse / jt_gen / jt_state).  A buffer that is known to hold zeros at
+// its structural zeros is only written where something can be non-zero; the fill is needed when the
+// buffer is not registered, or when the previous launch into it left a NaN fill behind.
+__device__ __forceinline__ bool jt_needs_fill(const ogk_args& a) {
+    const unsigned st = *a.jt_state;            // written by an earlier kernel (agent scope): plain load
+    return !a.jt_sparse | (st == a.jt_gen - 1u);
+}
+// this launch fills with NaN: the next launch into the buffer must clean up
+__device__ __forceinline__ void jt_mark_nan_fill(const ogk_args& a) {
+    if (a.jt_sparse) __hip_atomic_store(a.jt_state, a.jt_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int ROWS_COLS_PER_THREAD = 8;
 
 __device__ __forceinline__ int defect_block_to_group(int bx, int* nt_out) {
@@ -237,6 +249,8 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
                                                  const int defect_total, const int row_blocks) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
+    // every entry is written: a registered buffer only has to learn about a NaN fill
+    if (id == 0 && threadIdx.x == 0 && *a.nonfinite != 0) jt_mark_nan_fill(a);
     if (id < defect_total) {
         dense_defect_body(a, id % ndef, id / ndef, lds);
     } else {
@@ -337,8 +351,10 @@ __global__ __launch_bounds__(256) void ogk_exact_struct(const ogk_args a) {
     if (j >= a.col_hi) return;
     const int tid = (int)threadIdx.x;
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    for (int r = tid; r < OgGen::M; r += 256) jrow[r] = 0.0;
-    __syncthreads();
+    if (jt_needs_fill(a)) {                     // (a registered buffer keeps its structural zeros)
+        for (int r = tid; r < OgGen::M; r += 256) jrow[r] = 0.0;
+        __syncthreads();
+    }
     const XDual xd{a.x0, j};
     const int4 rec = OGT_COL[j];
     for (int e = rec.x + tid; e < rec.y; e += 256) {
@@ -570,15 +586,19 @@ __device__ __forceinline__ void heavy_column_body(const ogk_args& a, const int j
     const double xj = xb + a.h[j];
     const double dx = xj - xb;
     const bool all_finite = *a.nonfinite == 0;
-    for (int w = tid; w < ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
-    __syncthreads();
-    for (int e = col.x + tid; e < col.y; e += SWEEP_THREADS) {
-        const int r = OGT_ELEM[e].w;
-        atomicOr(&bits[r >> 5], 1u << (r & 31));
-    }
-    __syncthreads();
+    const bool fill = !all_finite | jt_needs_fill(a);      // workgroup-uniform
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    fill_row(a, jrow, bits, own_lo, own_hi, tid, SWEEP_THREADS, all_finite);
+    if (fill) {
+        for (int w = tid; w < ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
+        __syncthreads();
+        for (int e = col.x + tid; e < col.y; e += SWEEP_THREADS) {
+            const int r = OGT_ELEM[e].w;
+            atomicOr(&bits[r >> 5], 1u << (r & 31));
+        }
+        __syncthreads();
+        fill_row(a, jrow, bits, own_lo, own_hi, tid, SWEEP_THREADS, all_finite);
+        if (!all_finite && tid == 0) jt_mark_nan_fill(a);
+    }
     const XCol xa{a.x0, j, xj};
     for (int e = col.x + tid; e < ((OGK_EXP & 8) ? 0 : col.y); e += SWEEP_THREADS)
         eval_item(a, OGT_ELEM[e], xa, dx, jrow);
@@ -609,24 +629,28 @@ __device__ __forceinline__ void light_columns_body(const ogk_args& a, const int 
     const bool has_item = col_live && coli.x + wave < coli.y;
     if (has_item) item = OGT_ELEM[coli.x + wave];
 
-    // ---- mark the positions the items will write
-    for (int w = tid; w < LIGHT_COLS * ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
-    __syncthreads();
-    if (has_item) {
-        unsigned* mine = bits + lane * ROW_WORDS;
-        atomicOr(&mine[item.w >> 5], 1u << (item.w & 31));
-        for (int e = coli.x + wave + SWEEP_WAVES; e < coli.y; e += SWEEP_WAVES) {
-            const int r = OGT_ELEM[e].w;
-            atomicOr(&mine[r >> 5], 1u << (r & 31));
+    // ---- a registered (persistent-zero) buffer needs no fill while F(x0) is finite: straight to the items
+    if (!all_finite | jt_needs_fill(a)) {                        // workgroup-uniform
+        // ---- mark the positions the items will write
+        for (int w = tid; w < LIGHT_COLS * ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
+        __syncthreads();
+        if (has_item) {
+            unsigned* mine = bits + lane * ROW_WORDS;
+            atomicOr(&mine[item.w >> 5], 1u << (item.w & 31));
+            for (int e = coli.x + wave + SWEEP_WAVES; e < coli.y; e += SWEEP_WAVES) {
+                const int r = OGT_ELEM[e].w;
+                atomicOr(&mine[r >> 5], 1u << (r & 31));
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- fill around them (heavy columns are filled by their own workgroup); the stores drain
-    //      while the item chains below run
-    if (fill_on && !(colf.w & HEAVY_FLAG))
-        fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + cf * ROW_WORDS, colf.z,
-                 colf.w, (wave % WPR) * 64 + lane, 64 * WPR, all_finite);
+        // ---- fill around them (heavy columns are filled by their own workgroup); the stores drain
+        //      while the item chains below run
+        if (fill_on && !(colf.w & HEAVY_FLAG))
+            fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + cf * ROW_WORDS, colf.z,
+                     colf.w, (wave % WPR) * 64 + lane, 64 * WPR, all_finite);
+        if (!all_finite && tid == 0) jt_mark_nan_fill(a);
+    }
 #if OGK_TRACE
     const long long t_filled = __builtin_amdgcn_s_memtime();
 #endif
@@ -956,6 +980,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
     const int ji = first_j + cl;
     const bool item_on = !service && lane < 2 * FZ_COLS && cl < cnt && ji >= a.col_lo && ji < a.col_hi;
     const int4 coli = OGT_LRNG[b * FZ_COLS + cl];   // {items begin, end} of this lane's column (no OGT_COL round trip)
+    const bool zero_fill = jt_needs_fill(a);        // false for a registered (persistent-zero) buffer in good state
     const double xb = a.x0[item_on ? ji : first_j];
     const double hh = a.h[item_on ? ji : first_j];
     int4 item = make_int4(0, 0, 0, 0);
@@ -1041,12 +1066,14 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
         return;
     }
     // zeros (the verdict on non-finite rows comes at the end); drains while everything below runs
+    if (zero_fill) {
 #pragma unroll
-    for (int c = 0; c < FZ_COLS; ++c) {
-        const int jf = first_j + c;
-        if (c < cnt && jf >= a.col_lo && jf < a.col_hi)
-            fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],
-                     tid, 64 * FZ_ITEM_WAVES, true);
+        for (int c = 0; c < FZ_COLS; ++c) {
+            const int jf = first_j + c;
+            if (c < cnt && jf >= a.col_lo && jf < a.col_hi)
+                fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],
+                         tid, 64 * FZ_ITEM_WAVES, true);
+        }
     }
     FZ_STAMP(2);
     if (has_item && !(OGK_FZ & 2048)) {
@@ -1076,6 +1103,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
     }
 #endif
     if (lds_flag_wait(&s_flags[1]) == 2) {
+        if (tid == 0) jt_mark_nan_fill(a);
 #pragma unroll
         for (int c = 0; c < FZ_COLS; ++c) {
             const int jf = first_j + c;
@@ -1134,8 +1162,9 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
     __syncthreads();
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
     const int r0 = rec.v[5], r1 = rec.v[6];
-    for (int r = r0 + tid; r < r1; r += SWEEP_THREADS)
-        if ((r < own_lo || r >= own_hi) && !marked(bits, r)) jrow[r] = 0.0;
+    if (jt_needs_fill(a))
+        for (int r = r0 + tid; r < r1; r += SWEEP_THREADS)
+            if ((r < own_lo || r >= own_hi) && !marked(bits, r)) jrow[r] = 0.0;
     const bool base_role = tid >= HPART_PAIRS;
     const XCol xa{a.x0, base_role ? -1 : j, xj};
     for (int e0 = rec.v[1]; e0 < rec.v[2]; e0 += HPART_PAIRS) {
@@ -1154,6 +1183,7 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
     }
     if (wave == SWEEP_WAVES - 1 && wave_nonfinite_verdict(a) && lane == 0) s_nonfinite = 1;
     lds_barrier();
+    if (s_nonfinite && tid == 0) jt_mark_nan_fill(a);
     if (s_nonfinite)
         for (int r = r0 + tid; r < r1; r += SWEEP_THREADS)
             if ((r < own_lo || r >= own_hi) && !marked(bits, r))

@@ -90,11 +90,23 @@ struct og_problem_s {
     int sweep_mode = 5;
     int exact_mode = 4;                 // 4 structured (default), 3 dense (OGPSX_SWEEP=dense)
     hipStream_t stream = nullptr;
+    // persistent-zero output buffers (og_jt_register_dev): the sweep writes only what can be non-zero.  Each
+    // registration owns one word of d_state (ogk.h: jt_state); word 0 is the stand-in for unregistered buffers.
+    struct jt_reg {
+        double* ptr;
+        int lo, hi;
+        int slot;
+        unsigned launches;
+    };
+    std::vector<jt_reg> regs;
+    int last_reg = -1;                  // registration the most recent fill_args matched (-1: none)
+    uint32_t* d_state = nullptr;
 };
+static const int OG_MAX_JT_REGS = 63;
 
 namespace {
 
-void fill_args(const og_problem_s* p, ogk_args* a, const double* x, const double* h, double* f0,
+void fill_args(og_problem_s* p, ogk_args* a, const double* x, const double* h, double* f0,
                double* jt, int lo, int hi) {
     a->x0 = x;
     a->h = h;
@@ -113,7 +125,48 @@ void fill_args(const og_problem_s* p, ogk_args* a, const double* x, const double
     a->jt = jt;
     a->col_lo = lo;
     a->col_hi = hi;
+    // a registered buffer (exactly this block of columns at this address) is written sparsely
+    a->jt_sparse = 0;
+    a->jt_gen = 1;
+    a->jt_state = p->d_state;
+    p->last_reg = -1;
+    if (jt)
+        for (size_t i = 0; i < p->regs.size(); ++i) {
+            auto& r = p->regs[i];
+            if (r.ptr == jt && r.lo == lo && r.hi == hi) {
+                a->jt_sparse = 1;
+                a->jt_gen = ++r.launches;
+                a->jt_state = p->d_state + r.slot;
+                p->last_reg = (int)i;
+                break;
+            }
+        }
     memcpy(a->dfrag_off, p->dfrag_off, sizeof(a->dfrag_off));
+}
+
+// a launch that was not accepted has not happened as far as the buffer's generation count goes
+int launch_failed(og_problem_s* p, int rc, const char* where) {
+    if (p->last_reg >= 0) p->regs[(size_t)p->last_reg].launches -= 1;
+    return fail(100 + rc, std::string(where) + ": " + hipGetErrorString((hipError_t)rc));
+}
+
+// the handle's own Jacobian buffer (host-pointer entry points): sized for this block of columns and
+// registered as a persistent-zero buffer, so that every sweep into it writes the non-zeros only
+int own_jt(og_problem_s* p, int lo, int hi) {
+    const size_t need = (size_t)(hi - lo) * (size_t)p->m;
+    if (need > p->jt_capacity) {
+        if (p->d_jt) {
+            og_jt_unregister_dev(p, p->d_jt);
+            OG_HIP(hipFree(p->d_jt));
+        }
+        p->d_jt = nullptr;
+        p->jt_capacity = 0;
+        OG_HIP(hipMalloc(&p->d_jt, sizeof(double) * need));
+        p->jt_capacity = need;
+    }
+    for (auto& r : p->regs)
+        if (r.ptr == p->d_jt && r.lo == lo && r.hi == hi) return 0;
+    return og_jt_register_dev(p, p->d_jt, lo, hi, p->stream);
 }
 
 }  // namespace
@@ -286,6 +339,8 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
                                       (size_t)(info.n_heavy > 0 ? info.n_heavy : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_flags, 4 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&p->d_state, (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(p->d_state, 0xff, (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
     p->n_eval_blocks = info.n_eval_blocks;
     const char* mode_env = getenv("OGPSX_SWEEP");
     // one launch while the kernel boundary is a noticeable part of the step.  Measured (bench step, fused /
@@ -320,12 +375,50 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_t0);
     hipFree(p->d_z);
     hipFree(p->d_flags);
+    hipFree(p->d_state);
     hipFree(p->d_hscr);
     if (p->module) dlclose(p->module);
     delete p;
 }
 
 int og_sweep_mode(og_handle p) { return p ? p->sweep_mode : 0; }
+
+int og_jt_register_dev(og_handle p, double* d_JT, int32_t lo, int32_t hi, void* hip_stream) {
+    if (!p || !d_JT) return fail(1, "og_jt_register_dev: null argument");
+    if (lo < 0 || hi > p->n || lo >= hi) return fail(1, "og_jt_register_dev: bad column range");
+    OG_HIP(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    og_problem_s::jt_reg* reg = nullptr;
+    for (auto& r : p->regs)
+        if (r.ptr == d_JT) reg = &r;
+    if (!reg) {
+        if ((int)p->regs.size() >= OG_MAX_JT_REGS)
+            return fail(6, "og_jt_register_dev: too many registered buffers on this handle");
+        // a free state word
+        std::vector<char> used(OG_MAX_JT_REGS + 1, 0);
+        for (auto& r : p->regs) used[r.slot] = 1;
+        int slot = 1;
+        while (used[slot]) ++slot;
+        p->regs.push_back({d_JT, lo, hi, slot, 0u});
+        reg = &p->regs.back();
+    }
+    reg->lo = lo;
+    reg->hi = hi;
+    reg->launches = 0;
+    OG_HIP(hipMemsetAsync(d_JT, 0, sizeof(double) * (size_t)(hi - lo) * (size_t)p->m, s));
+    OG_HIP(hipMemsetAsync(p->d_state + reg->slot, 0xff, sizeof(uint32_t), s));
+    return 0;
+}
+
+int og_jt_unregister_dev(og_handle p, double* d_JT) {
+    if (!p) return fail(1, "og_jt_unregister_dev: null handle");
+    for (size_t i = 0; i < p->regs.size(); ++i)
+        if (p->regs[i].ptr == d_JT) {
+            p->regs.erase(p->regs.begin() + (long)i);
+            return 0;
+        }
+    return fail(1, "og_jt_unregister_dev: buffer is not registered");
+}
 
 int og_problem_dims(og_handle p, int32_t* n, int32_t* m, int32_t* m_eq, int32_t* m_ineq) {
     if (!p) return fail(1, "og_problem_dims: null handle");
@@ -356,14 +449,16 @@ int og_fd_sweep_dev(og_handle p, const double* d_x, const double* d_h, int32_t l
     int rc;
     if (p->sweep_mode == 5 && hi > lo) {
         // one launch: the evaluation workgroups count into a ticket that is never reset
-        p->fused_launches += 1;
-        a.ready_target = p->fused_launches * (unsigned)p->n_eval_blocks;
+        a.ready_target = (p->fused_launches + 1) * (unsigned)p->n_eval_blocks;
         rc = p->launch(&a, 5, hip_stream);
+        // the ticket only advances when the launch was accepted: a failed launch must not leave every later
+        // sweep waiting for evaluation workgroups that never ran
+        if (!rc) p->fused_launches += 1;
     } else {
         rc = p->launch(&a, 0, hip_stream);          // F(x0) first: the sweep subtracts it
         if (!rc) rc = p->launch(&a, p->sweep_mode == 5 ? 1 : p->sweep_mode, hip_stream);
     }
-    if (rc) return fail(100 + rc, std::string("og_fd_sweep_dev: ") + hipGetErrorString((hipError_t)rc));
+    if (rc) return launch_failed(p, rc, "og_fd_sweep_dev");
     return 0;
 }
 
@@ -374,7 +469,7 @@ int og_fd_columns_dev(og_handle p, const double* d_x, const double* d_h, int32_t
     ogk_args a;
     fill_args(p, &a, d_x, d_h, const_cast<double*>(d_F0), d_JT, lo, hi);
     int rc = p->launch(&a, p->sweep_mode == 5 ? 1 : p->sweep_mode, hip_stream);
-    if (rc) return fail(100 + rc, std::string("og_fd_columns_dev: ") + hipGetErrorString((hipError_t)rc));
+    if (rc) return launch_failed(p, rc, "og_fd_columns_dev");
     return 0;
 }
 
@@ -387,7 +482,7 @@ int og_jacobian_exact_dev(og_handle p, const double* d_x, int32_t lo, int32_t hi
     fill_args(p, &a, d_x, nullptr, d_F0, d_JT, lo, hi);
     int rc = p->launch(&a, 0, hip_stream);          // F(x0) and the base collocation products
     if (!rc) rc = p->launch(&a, p->exact_mode, hip_stream);   // forward-mode derivatives, column by column
-    if (rc) return fail(100 + rc, std::string("og_jacobian_exact_dev: ") + hipGetErrorString((hipError_t)rc));
+    if (rc) return launch_failed(p, rc, "og_jacobian_exact_dev");
     return 0;
 }
 
@@ -412,12 +507,9 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
         if (!F0) return 0;
         return og_eval(p, x, F0);
     }
-    if (need > p->jt_capacity) {
-        if (p->d_jt) OG_HIP(hipFree(p->d_jt));
-        p->d_jt = nullptr;
-        p->jt_capacity = 0;
-        OG_HIP(hipMalloc(&p->d_jt, sizeof(double) * need));
-        p->jt_capacity = need;
+    {
+        const int rcj = own_jt(p, lo, hi);
+        if (rcj) return rcj;
     }
     OG_HIP(hipMemcpyAsync(p->d_x, x, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
     OG_HIP(hipMemcpyAsync(p->d_h, hstep, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
@@ -440,12 +532,9 @@ int og_jacobian_exact(og_handle p, const double* x, int32_t lo, int32_t hi, doub
         if (!F0) return 0;
         return og_eval(p, x, F0);
     }
-    if (need > p->jt_capacity) {
-        if (p->d_jt) OG_HIP(hipFree(p->d_jt));
-        p->d_jt = nullptr;
-        p->jt_capacity = 0;
-        OG_HIP(hipMalloc(&p->d_jt, sizeof(double) * need));
-        p->jt_capacity = need;
+    {
+        const int rcj = own_jt(p, lo, hi);
+        if (rcj) return rcj;
     }
     OG_HIP(hipMemcpyAsync(p->d_x, x, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
     int rc = og_jacobian_exact_dev(p, p->d_x, lo, hi, p->d_jt, p->d_f0, p->stream);

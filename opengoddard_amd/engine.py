@@ -123,6 +123,15 @@ class HipEngine:
         _native.check(self._lib.og_fd_sweep_dev(self._handle, d_x, d_h, int(col_lo), int(col_hi),
                                                 d_JT, d_F0, stream), "og_fd_sweep_dev")
 
+    def register_jt_dev(self, d_JT, col_lo, col_hi, stream=0):
+        """Declare ``d_JT`` a persistent-zero buffer for the columns [col_lo, col_hi): it is zero-filled now
+        and later sweeps into it write the non-zeros only (``og_jt_register_dev``, include/ogpsx.h)."""
+        _native.check(self._lib.og_jt_register_dev(self._handle, d_JT, int(col_lo), int(col_hi), stream),
+                      "og_jt_register_dev")
+
+    def unregister_jt_dev(self, d_JT):
+        _native.check(self._lib.og_jt_unregister_dev(self._handle, d_JT), "og_jt_unregister_dev")
+
     def columns_dev(self, d_x, d_h, col_lo, col_hi, d_JT, d_F0, stream=0):
         """The sweep kernel alone (``d_F0`` must already hold F(x) from :meth:`eval_dev`)."""
         _native.check(self._lib.og_fd_columns_dev(self._handle, d_x, d_h, int(col_lo), int(col_hi),

@@ -217,6 +217,79 @@ def test_non_finite_rows_propagate_like_dense_fd(name, state, layout, monkeypatc
     eng.close()
 
 
+@pytest.mark.parametrize("layout", ["fused", "split", "dense"])
+@pytest.mark.parametrize("name,state", [("goddard", 2), ("polar_tsto", 4)])
+def test_registered_buffer_keeps_its_structural_zeros(name, state, layout, monkeypatch):
+    """og_jt_register_dev: a persistent-zero buffer is written only where J_T can be non-zero, and must
+    hold exactly what an unregistered (fully rewritten) buffer holds after every sweep - through a
+    finite -> non-finite -> non-finite -> finite -> finite sequence on one handle (the NaN fill of a
+    non-finite sweep has to be cleaned up by the next one), with the exact-Jacobian mode in between, and
+    for a block of columns."""
+    import torch
+    from opengoddard_amd.engine import HipEngine
+    from oracle import np_path, twin
+    monkeypatch.setenv("OGPSX_SWEEP", layout)
+    prob, obj = problems.build(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    eng = HipEngine(prob, obj)
+    tw = twin.Twin(prob, obj, program=eng.program, header=eng.header)
+    n, m = eng.n, eng.m
+    x_ok = np.clip(prob.p, lb, ub)
+    x_bad = x_ok.copy()
+    x_bad[prob.index_states(state, 0, 7)] = 0.0            # mass = 0 at one node -> division by zero
+    rng = np.random.default_rng(5)
+    x_other = np.clip(x_ok + 1e-3 * rng.standard_normal(n), lb, ub)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_F = torch.empty(m, dtype=torch.float64, device=dev)
+    lo, hi = n // 3, n // 3 + max(5, n // 2)
+    reg_full = torch.full((n, m), 7.0, dtype=torch.float64, device=dev)       # garbage before registration
+    reg_part = torch.full((hi - lo, m), -3.0, dtype=torch.float64, device=dev)
+    eng.register_jt_dev(reg_full.data_ptr(), 0, n, stream)
+    eng.register_jt_dev(reg_part.data_ptr(), lo, hi, stream)
+    plain = torch.empty((n, m), dtype=torch.float64, device=dev)
+
+    def sweep(x, into, c0, c1):
+        h = _native.fd_step(x, lb, ub)
+        d_x, d_h = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+        eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), c0, c1, into.data_ptr(), d_F.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return into.cpu().numpy().copy(), h
+
+    for step, x in enumerate((x_ok, x_bad, x_bad, x_ok, x_other, x_bad, x_other)):
+        plain.fill_(float(step) + 0.5)
+        want, h = sweep(x, plain, 0, n)
+        got, _ = sweep(x, reg_full, 0, n)
+        part, _ = sweep(x, reg_part, lo, hi)
+        assert np.array_equal(got, want, equal_nan=True), "registered buffer differs at step %d" % step
+        assert np.array_equal(part, want[lo:hi], equal_nan=True), "registered block differs at step %d" % step
+        assert np.array_equal(want, tw.sweep(x, h)[1], equal_nan=True)
+        assert np.isnan(want).any() == (x is x_bad)
+        if step == 2:            # exact-Jacobian mode into the buffer a NaN fill was left in: cleans it too
+            d_x = torch.from_numpy(x_ok).to(dev)
+            eng.exact_dev(d_x.data_ptr(), 0, n, plain.data_ptr(), d_F.data_ptr(), stream)
+            eng.exact_dev(d_x.data_ptr(), 0, n, reg_full.data_ptr(), d_F.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(reg_full.cpu().numpy(), plain.cpu().numpy())
+            assert np.isfinite(reg_full.cpu().numpy()).all()
+    # the sweep kernel alone (og_fd_columns_dev) honours the registration as well
+    h = _native.fd_step(x_ok, lb, ub)
+    d_x, d_h = torch.from_numpy(x_ok).to(dev), torch.from_numpy(h).to(dev)
+    eng.eval_dev(d_x.data_ptr(), d_F.data_ptr(), stream)
+    eng.columns_dev(d_x.data_ptr(), d_h.data_ptr(), 0, n, reg_full.data_ptr(), d_F.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(reg_full.cpu().numpy(), tw.sweep(x_ok, h)[1])
+    # after unregistering, the buffer is an ordinary one again (everything rewritten)
+    eng.unregister_jt_dev(reg_full.data_ptr())
+    reg_full.fill_(11.0)
+    got, h = sweep(x_other, reg_full, 0, n)
+    assert np.array_equal(got, tw.sweep(x_other, h)[1])
+    lib = _native.lib()
+    assert lib.og_jt_unregister_dev(eng._handle, reg_full.data_ptr()) != 0
+    assert b"not registered" in lib.og_last_error()
+    eng.close()
+
+
 def test_sweep_is_deterministic(golden):
     G = golden("cfg_polar_tsto")
     prob, obj, eng, tw = _engine_and_twin("polar_tsto")

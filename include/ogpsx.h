@@ -132,6 +132,11 @@ int og_jacobian_exact_dev(og_handle h, const double* d_x, int32_t col_lo, int32_
 
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 const char* og_last_error(void);
+/* Developer diagnostics: phase stamps (s_memrealtime ticks) written by kernel modules compiled with
+ * -DOGK_TRACE=1 on a handle created with OGPSX_TRACE=1 in the environment; 8 doubles per wavefront,
+ * 8 wavefronts per workgroup, in grid order (tools/trace_fused.py).  Reads `count` doubles and clears
+ * the buffer.  Fails on an ordinary handle. */
+int og_trace_read(og_handle h, double* out, int64_t count);
 int og_device_count(void);     /* HIP devices visible to the library (0 without a GPU) */
 
 #ifdef __cplusplus

@@ -50,6 +50,7 @@ SIGNATURES = {
     "og_jacobian_exact": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p]),
     "og_jacobian_exact_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "og_trace_read": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64]),
     "og_last_error": (C.c_char_p, []),
     "og_device_count": (C.c_int, []),
 }

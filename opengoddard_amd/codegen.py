@@ -704,6 +704,52 @@ def _int_table(name, values):
             % (name, len(values), body))
 
 
+def _column_items(P):
+    """Per-column work lists of the structured sweep: every (group, output, element) that reads p[j].
+    Entries whose J_T position is written by the MFMA tiles (row of state s, column in state s's own
+    slice) are left out."""
+    col_elems = [set() for _ in range(P.n)]
+    for gi, g in enumerate(P.groups):
+        per_output = g.out_deps if g.kind == "defect" else [g.deps] * len(g.outputs)
+        for o, deps in enumerate(per_output):
+            lo = hi = -1
+            if g.kind == "defect":
+                sl = P.mv[g.mv_slots[o]]
+                lo, hi = sl.leaf_base, sl.leaf_base + sl.length
+            for kind, base, cnt in deps:
+                for j in range(base, base + cnt):
+                    if lo <= j < hi:
+                        continue
+                    if kind == 1:
+                        col_elems[j].add((gi, o, j - base))
+                    else:
+                        col_elems[j].update((gi, o, k) for k in range(g.length))
+    return col_elems
+
+
+def sparsity(P):
+    """Static pattern of the transposed Jacobian: ``(indptr, rows)`` with ``rows[indptr[j]:indptr[j+1]]`` the
+    rows of F that can depend on p[j] - for column j first the collocation block its state slice owns
+    (``N`` consecutive defect rows, written by the MFMA tiles), then the row items in work-list order.
+    This is the order of the packed non-zeros (``og_pack_dev``, include/ogpsx.h); every other entry of
+    J_T is an exact zero in every sweep."""
+    col_elems = _column_items(P)
+    own = {}
+    for gi, g in enumerate(P.groups):
+        for o, si in enumerate(g.mv_slots):
+            sl = P.mv[si]
+            row0 = g.outputs[o][0]
+            for j in range(sl.leaf_base, sl.leaf_base + sl.length):
+                own[j] = (row0, row0 + sl.length)
+    indptr, rows = [0], []
+    for j in range(P.n):
+        lo, hi = own.get(j, (0, 0))
+        rows.extend(range(lo, hi))
+        rows.extend(P.groups[gi].outputs[o][0] + k for gi, o, k in sorted(col_elems[j]))
+        indptr.append(len(rows))
+    return np.asarray(indptr, dtype=np.int64), np.asarray(rows, dtype=np.int32)
+
+
 def emit_header(P):
     """C++17 source of ``struct OgGen`` for this program (host+device, no includes of its own
     beyond og_math.h)."""
@@ -766,25 +812,7 @@ def emit_header(P):
     for sl in P.mv:
         y0_off.append(at)
         at += sl.length
-    # per-column work lists of the structured sweep: every (group, output, element) that reads
-    # p[j].  Entries whose J_T position is written by the MFMA tiles (row of state s, column in
-    # state s's own slice) are left out.
-    col_elems = [set() for _ in range(P.n)]
-    for gi, g in enumerate(P.groups):
-        per_output = g.out_deps if g.kind == "defect" else [g.deps] * len(g.outputs)
-        for o, deps in enumerate(per_output):
-            lo = hi = -1
-            if g.kind == "defect":
-                sl = P.mv[g.mv_slots[o]]
-                lo, hi = sl.leaf_base, sl.leaf_base + sl.length
-            for kind, base, cnt in deps:
-                for j in range(base, base + cnt):
-                    if lo <= j < hi:
-                        continue
-                    if kind == 1:
-                        col_elems[j].add((gi, o, j - base))
-                    else:
-                        col_elems[j].update((gi, o, k) for k in range(g.length))
+    col_elems = _column_items(P)
     col_ptr, elem_g, elem_o, elem_k = [0], [], [], []
     for j in range(P.n):
         for gi, o, k in sorted(col_elems[j]):

@@ -46,8 +46,7 @@ typedef struct ogk_args {
     double* z;              // [m] F0 - F0: 0, or NaN for non-finite rows (written by mode 0)
     int* nonfinite;         // number of non-finite rows of F(x0): counted by mode 0, read by mode 1
     int* nonfinite_next;    // the slot the *next* evaluation counts into (mode 0 zeroes it)
-    unsigned* ready;        // mode 5: ticket the evaluation workgroups count into (never reset) ...
-    unsigned ready_target;  // ... and the value it has once all of THIS launch's have
+    unsigned* ready;        // mode 5: ticket the evaluation workgroups count into; the last one resets it
     double* hscr;           // mode 5: [n_heavy][2][n_y0] private operands / base products of the heavy columns
     double* jt;             // [(col_hi-col_lo) * m] transposed Jacobian rows (mode 1)
     // Persistent-zero output (og_jt_register_dev, include/ogpsx.h).  jt_sparse != 0: the structural zeros of
@@ -60,6 +59,7 @@ typedef struct ogk_args {
     uint32_t jt_gen;        // number of this launch among the launches into this registered buffer (1, 2, ...)
     uint32_t* jt_state;     // generation of the last launch into the buffer that left NaN fill behind
     int32_t col_lo, col_hi; // FD columns handled by this launch
+    double* trace;          // -DOGK_TRACE builds: [workgroup][8 wavefronts][8] phase stamps (else unused)
     int64_t dfrag_off[OGK_MAX_PHASE];
 } ogk_args;
 

@@ -847,9 +847,6 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx) {
 #ifndef OGK_FZ
 #define OGK_FZ 0
 #endif
-#ifndef OGK_SPIN_LIMIT
-#define OGK_SPIN_LIMIT (1u << 22)       // polls before a waiting wavefront gives up (seconds)
-#endif
 
 // barrier that orders LDS traffic only: the global stores of the fill keep draining underneath
 // (__syncthreads() would wait for them)
@@ -859,30 +856,50 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-__device__ __forceinline__ void signal_ready(const ogk_args& a) {
-    __builtin_amdgcn_s_waitcnt(0);          // this wavefront's write-through stores have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(a.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// What is left of the dependence on the evaluation in the fused launch.  A registered (persistent-zero)
+// buffer needs a fill only when F(x0) of THIS launch has non-finite rows (NaN in those rows of every column)
+// or when the previous launch into the buffer left such a fill behind.  Nobody waits for that verdict:
+// every evaluation workgroup takes a ticket when its results are out, and the one that draws the last
+// ticket - by then the count of non-finite rows is complete - looks at it and, in the rare case, fills
+// every row of this launch's block from z (0, or NaN) around the positions the sweep workgroups write
+// (bitmap per row from the column's item list, as in mode 1).  It also resets the ticket, so that the
+// launch arguments do not depend on how many launches went before.
+__device__ __forceinline__ void fz_fill_from_z(const ogk_args& a, unsigned* bits) {
+    const int tid = (int)threadIdx.x;
+    for (int j = a.col_lo; j < a.col_hi; ++j) {
+        const int4 col = OGT_COL[j];
+        const int own_lo = col.z, own_hi = col.w & ~HEAVY_FLAG;
+        for (int w = tid; w < ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
+        __syncthreads();
+        for (int e = col.x + tid; e < col.y; e += SWEEP_THREADS) {
+            const int r = OGT_ELEM[e].w;
+            atomicOr(&bits[r >> 5], 1u << (r & 31));
+        }
+        __syncthreads();
+        fill_row(a, a.jt + (long)(j - a.col_lo) * OgGen::M, bits, own_lo, own_hi, tid, SWEEP_THREADS, false, true);
+        __syncthreads();
+    }
 }
 
-// one wavefront: true when F(x0) of THIS launch has a non-finite row.  The two non-finite counters and the
-// ticket share one 16-byte line ({nonfinite[0], nonfinite[1], ticket, -}, ogpsx_core.hip) and are read with ONE
-// agent-scope load: a workgroup's count of non-finite rows is performed before its ticket, both at the memory
-// side, so a line that shows the complete ticket shows the complete count - no second round trip.
-__device__ __forceinline__ bool wave_nonfinite_verdict(const ogk_args& a) {
-    if (OGK_FZ & 1) return false;
-    const int* line = reinterpret_cast<const int*>(a.ready) - 2;
-    const int slot = (int)(a.nonfinite - line);
-    unsigned polls = 0;
-    int4 v;
-    for (;;) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(line) : "memory");
-        if ((int)((unsigned)v.z - a.ready_target) >= 0) break;
-        __builtin_amdgcn_s_sleep(2);
-        if (++polls > OGK_SPIN_LIMIT) __builtin_trap();     // never on a healthy device: fail loudly, do not hang
+__device__ __forceinline__ void finish_eval(const ogk_args& a, const unsigned n_eval, unsigned* bits) {
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);          // this wavefront's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(a.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = 0;
+        if (t + 1u == n_eval) {
+            // the counts of non-finite rows were performed before their workgroups' tickets, at the memory side
+            const int bad = __hip_atomic_load(a.nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned st = __hip_atomic_load(a.jt_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bad != 0) jt_mark_nan_fill(a);
+            last = (bad != 0 || st == a.jt_gen - 1u) ? 1 : 0;
+        }
+        s_last = last;
     }
-    return (slot == 0 ? v.x : v.y) != 0;
+    __syncthreads();
+    if (s_last) fz_fill_from_z(a, bits);
 }
 
 // base collocation products of one (defect group, node tile) on one wavefront: states are the rows of the
@@ -934,16 +951,13 @@ __device__ __forceinline__ void eval_item_paired(const ogk_args& a, const int4 i
 
 constexpr int FZ_MAXN = OgGen::MAX_NODES;                      // longest phase
 constexpr int FZ_NP = ((FZ_MAXN + 3) / 4) * 4;
-constexpr int FZ_BITS_WORDS = (FZ_COLS * ROW_WORDS + 3) & ~3;
 constexpr int FZ_ITEM_WAVES = SWEEP_WAVES - 1;                 // item slots of a light workgroup (the last wavefront
                                                                // runs the MFMA chain instead)
-// LDS of a light workgroup: bitmaps | D panel of the tile [KS][64] | operands [state][NP] | base products [state][N]
-constexpr size_t FZ_LDS_BYTES = (size_t)FZ_BITS_WORDS * sizeof(unsigned) +
-                                ((size_t)(FZ_NP / 4) * 64 + (size_t)OgGen::MAX_NMV * (FZ_NP + FZ_MAXN)) * sizeof(double);
+// LDS of a light workgroup: D panel of the tile [KS][64] | operands [state][NP] | base products [state][N]
+constexpr size_t FZ_LDS_BYTES = ((size_t)(FZ_NP / 4) * 64 + (size_t)OgGen::MAX_NMV * (FZ_NP + FZ_MAXN)) * sizeof(double);
 constexpr int HPART_PAIRS = SWEEP_THREADS / 2;                 // codegen.HPART_ITEMS
 
-// flags a service wavefront raises in LDS for the other wavefronts of its workgroup (no s_barrier: a barrier
-// after the fill would make every wavefront wait until the slowest one has got its stores accepted)
+// flag the service wavefront raises in LDS for the other wavefronts of its workgroup
 __device__ __forceinline__ void lds_flag_raise(int* flag, const int value) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     *reinterpret_cast<volatile int*>(flag) = value;
@@ -955,16 +969,30 @@ __device__ __forceinline__ int lds_flag_wait(int* flag) {
     return v;
 }
 
-__device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, unsigned* bits) {
-    __shared__ int s_flags[2];          // [0] base products ready, [1] verdict: 1 finite, 2 non-finite rows
+#if OGK_TRACE                           // tools/trace_fused.py: phase stamps of every wavefront, next to the results
+#define FZ_TRACE_DECL(kind_) long long tr_[6] = {(long long)__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0}; \
+    const int tr_kind_ = (kind_)
+#define FZ_STAMP(i) tr_[i] = (long long)__builtin_amdgcn_s_memrealtime()
+#define FZ_TRACE_OUT(a_)                                                                                   \
+    do {                                                                                                   \
+        if (((int)threadIdx.x & 63) == 0 && (a_).trace) {                                                  \
+            double* t_ = (a_).trace + ((long)blockIdx.x * SWEEP_WAVES + ((int)threadIdx.x >> 6)) * 8;       \
+            t_[0] = (double)tr_kind_; t_[1] = (double)tr_[0]; t_[2] = (double)tr_[1]; t_[3] = (double)tr_[2]; \
+            t_[4] = (double)tr_[3]; t_[5] = (double)tr_[4]; t_[6] = (double)tr_[5];                          \
+            t_[7] = (double)__builtin_amdgcn_s_memrealtime();                                              \
+        }                                                                                                  \
+    } while (0)
+#else
+#define FZ_TRACE_DECL(kind_) do { } while (0)
+#define FZ_STAMP(i) do { } while (0)
+#define FZ_TRACE_OUT(a_) do { } while (0)
+#endif
+
+__device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, double* lds) {
+    __shared__ int s_flag;              // base products of the tile are in LDS
+    FZ_TRACE_DECL(1);
     // {first column, columns, y0 offset of the tile's first slot, node tile, first slot, slots (0: no defect
     //  items), nodes, phase}
-#if OGK_TRACE                           // tools/trace_fused.py: phase stamps instead of results
-    long long tr[6] = {(long long)__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0};
-#define FZ_STAMP(i) tr[i] = (long long)__builtin_amdgcn_s_memrealtime()
-#else
-#define FZ_STAMP(i) do { } while (0)
-#endif
     const ogt_int8 grp = OGT_LGRP[b];
     const int first_j = grp.v[0], cnt = grp.v[1], y0_first = grp.v[2], nt = grp.v[3];
     const int mv0 = grp.v[4], nmv = grp.v[5], N = grp.v[6], phase = grp.v[7];
@@ -972,7 +1000,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
     const bool has_tile = nmv > 0;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const bool service = wave == SWEEP_WAVES - 1;   // no fill, no items: the tile's MFMA chain and the verdict
+    const bool service = wave == SWEEP_WAVES - 1;   // no items: the tile's MFMA chain
     // items: lanes 0..FZ_COLS-1 evaluate at x0 + h e_j, the next FZ_COLS lanes the same items at x0 -
     // one instruction stream, so the base value of a row item costs no time; wavefront = item slot
     const int cl = lane % FZ_COLS;
@@ -980,31 +1008,24 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
     const int ji = first_j + cl;
     const bool item_on = !service && lane < 2 * FZ_COLS && cl < cnt && ji >= a.col_lo && ji < a.col_hi;
     const int4 coli = OGT_LRNG[b * FZ_COLS + cl];   // {items begin, end} of this lane's column (no OGT_COL round trip)
-    const bool zero_fill = jt_needs_fill(a);        // false for a registered (persistent-zero) buffer in good state
     const double xb = a.x0[item_on ? ji : first_j];
     const double hh = a.h[item_on ? ji : first_j];
     int4 item = make_int4(0, 0, 0, 0);
     const bool has_item = item_on && coli.x + wave < coli.y;
     if (has_item) item = OGT_ELEM[coli.x + wave];
-    int own_lo[FZ_COLS], own_hi[FZ_COLS];     // the fill's view of each row: rows the MFMA tiles write
-#pragma unroll
-    for (int c = 0; c < FZ_COLS; ++c) {
-        const int4 cc = OGT_COL[first_j + (c < cnt ? c : 0)];
-        own_lo[c] = cc.z;
-        own_hi[c] = cc.w & ~HEAVY_FLAG;
-    }
 
-    double* dpanel = reinterpret_cast<double*>(bits + FZ_BITS_WORDS);
+    double* dpanel = lds;
     double* xt = dpanel + (FZ_NP / 4) * 64;                        // [state][NP] operands
     double* yb = xt + OgGen::MAX_NMV * FZ_NP;                      // [state][N] base products (one tile of it)
     const XCol xbase{a.x0, -1, 0.0};
-    // the service wavefront's inputs (D^T panel of the tile, the group's operands) are requested now by everybody
-    // and parked in LDS only before the second barrier: by then they have arrived, nobody waits for them
+    // the service wavefront's inputs (D^T panel of the tile, the group's operands) are requested by everybody
+    // and parked in LDS before the workgroup's only barrier
     constexpr int ST_D = (FZ_NP / 4 * 64 + SWEEP_THREADS - 1) / SWEEP_THREADS;
     constexpr int ST_S = (OgGen::MAX_NMV + SWEEP_WAVES - 1) / SWEEP_WAVES, ST_L = (FZ_NP + 63) / 64;
-    double st_d[ST_D], st_x[ST_S * ST_L];
     const bool staging = has_tile && !(OGK_FZ & 4);
+    if (tid == 0) s_flag = 0;
     if (staging) {
+        double st_d[ST_D];
         const double* src = a.dfrag + a.dfrag_off[phase] + (long)nt * KS * 64;
 #pragma unroll
         for (int u = 0; u < ST_D; ++u) {
@@ -1016,68 +1037,27 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
 #pragma unroll
             for (int q = 0; q < ST_L; ++q) {
                 const int sl = wave + u * SWEEP_WAVES, l = lane + q * 64;
-                st_x[u * ST_L + q] = (sl < nmv && l < N) ? OgGen::mv_operand(mv0 + sl, l, xbase, a.cvec) : 0.0;
+                if (sl < nmv && l < NP) xt[sl * NP + l] = l < N ? OgGen::mv_operand(mv0 + sl, l, xbase, a.cvec) : 0.0;
             }
-    }
-    for (int w = tid; w < FZ_COLS * ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
-    if (tid < 2) s_flags[tid] = 0;
-    lds_barrier();            // (only LDS data crosses this workgroup's barriers: loads in flight stay in flight)
-    if (has_item && !base_role) {
-        unsigned* mine = bits + cl * ROW_WORDS;
-        atomicOr(&mine[item.w >> 5], 1u << (item.w & 31));
-        for (int e = coli.x + wave + FZ_ITEM_WAVES; e < coli.y; e += FZ_ITEM_WAVES) {
-            const int r = OGT_ELEM[e].w;
-            atomicOr(&mine[r >> 5], 1u << (r & 31));
-        }
-    }
-    if (staging) {
 #pragma unroll
         for (int u = 0; u < ST_D; ++u) {
             const int i = tid + u * SWEEP_THREADS;
             if (i < KS * 64) dpanel[i] = st_d[u];
         }
-#pragma unroll
-        for (int u = 0; u < ST_S; ++u)
-#pragma unroll
-            for (int q = 0; q < ST_L; ++q) {
-                const int sl = wave + u * SWEEP_WAVES, l = lane + q * 64;
-                if (sl < nmv && l < NP) xt[sl * NP + l] = st_x[u * ST_L + q];
-            }
     }
-    lds_barrier();
+    lds_barrier();            // (only LDS data crosses it: global loads in flight stay in flight)
     FZ_STAMP(1);
     if (service) {
-        // the last barrier of this workgroup is behind us: from here on the wavefronts only meet through flags
         if (has_tile && !(OGK_FZ & 2))
             base_products_tile(dpanel, N, nt, nmv, xt, NP,
                                [&](const int st, const int k, const double v) { yb[st * N + k] = v; });
         FZ_STAMP(2);
-        if (lane == 0) lds_flag_raise(&s_flags[0], 1);
-        const bool nonfinite = wave_nonfinite_verdict(a);          // no stores in this wavefront's queue: the poll
-        if (lane == 0) lds_flag_raise(&s_flags[1], nonfinite ? 2 : 1);   // returns when the evaluation has
-#if OGK_TRACE
-        FZ_STAMP(5);
-        if (lane == 0 && first_j >= a.col_lo && first_j < a.col_hi) {
-            double* t = a.jt + (long)(first_j - a.col_lo) * OgGen::M + 8 * wave;
-            t[0] = 3.0e6; t[1] = (double)tr[0]; t[2] = (double)tr[1]; t[3] = (double)tr[2]; t[4] = 0.0; t[5] = 0.0;
-            t[6] = (double)tr[5]; t[7] = 0.0;
-        }
-#endif
+        if (lane == 0) lds_flag_raise(&s_flag, 1);
+        FZ_TRACE_OUT(a);
         return;
     }
-    // zeros (the verdict on non-finite rows comes at the end); drains while everything below runs
-    if (zero_fill) {
-#pragma unroll
-        for (int c = 0; c < FZ_COLS; ++c) {
-            const int jf = first_j + c;
-            if (c < cnt && jf >= a.col_lo && jf < a.col_hi)
-                fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],
-                         tid, 64 * FZ_ITEM_WAVES, true);
-        }
-    }
-    FZ_STAMP(2);
     if (has_item && !(OGK_FZ & 2048)) {
-        lds_flag_wait(&s_flags[0]);
+        lds_flag_wait(&s_flag);
         FZ_STAMP(3);
         const double xj = xb + hh;
         const double dx = xj - xb;
@@ -1089,50 +1069,25 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, un
             eval_item_paired(a, OGT_ELEM[e], xa, base_role, dx, jrow);
     }
     FZ_STAMP(4);
-#if OGK_TRACE
-    {
-        const int verdict = lds_flag_wait(&s_flags[1]);
-        FZ_STAMP(5);
-        if (lane == 0 && first_j >= a.col_lo && first_j < a.col_hi) {
-            __builtin_amdgcn_s_waitcnt(0);
-            double* t = a.jt + (long)(first_j - a.col_lo) * OgGen::M + 8 * wave;
-            t[0] = 1.0e6 + (has_item ? 1 : 0); t[1] = (double)tr[0]; t[2] = (double)tr[1]; t[3] = (double)tr[2];
-            t[4] = (double)tr[3]; t[5] = (double)tr[4]; t[6] = (double)tr[5]; t[7] = (double)verdict;
-        }
-        return;
-    }
-#endif
-    if (lds_flag_wait(&s_flags[1]) == 2) {
-        if (tid == 0) jt_mark_nan_fill(a);
-#pragma unroll
-        for (int c = 0; c < FZ_COLS; ++c) {
-            const int jf = first_j + c;
-            if (c < cnt && jf >= a.col_lo && jf < a.col_hi)
-                fill_row(a, a.jt + (long)(jf - a.col_lo) * OgGen::M, bits + c * ROW_WORDS, own_lo[c], own_hi[c],
-                         tid, 64 * FZ_ITEM_WAVES, false, true);
-        }
-    }
+    FZ_TRACE_OUT(a);
 }
 
 // One part of a heavy column: HPART_PAIRS of its items (thread t < HPART_PAIRS at x0 + h e_j, thread
-// t + HPART_PAIRS the same item at x0), its share of the row's fill, and the base products of the node
-// tiles those items read - operands and products in a private global scratch (written and read by this
-// workgroup only: coherent through the CU's own cache path after a workgroup barrier).
-__device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx, unsigned* bits) {
-    __shared__ int s_nonfinite;
-    const ogt_int8 rec = OGT_HPART[pidx];      // {column, items begin, end, block list begin, end, fill rows begin, end}
+// t + HPART_PAIRS the same item at x0) and the base products of the node tiles those items read - operands
+// and products in a private global scratch (written and read by this workgroup only: coherent through the
+// CU's own cache path after a workgroup barrier).
+__device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx, double* vbase) {
+    FZ_TRACE_DECL(2);
+    const ogt_int8 rec = OGT_HPART[pidx];      // {column, items begin, end, block list begin, end, -, -}
     const int j = rec.v[0];
     if (j < a.col_lo || j >= a.col_hi) return;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int4 col = OGT_COL[j];
-    const int own_lo = col.z, own_hi = col.w & ~HEAVY_FLAG;
     const double xb = a.x0[j];
     const double xj = xb + a.h[j];
     const double dx = xj - xb;
     double* hx = a.hscr + (long)pidx * 2 * OgGen::N_Y0;            // operands of the collocation slots (as y0 is laid out)
     double* hy = hx + OgGen::N_Y0;                                 // their base products
-    double* vbase = reinterpret_cast<double*>(bits + ((ROW_WORDS + 3) & ~3));    // [HPART_PAIRS] base values
     const XCol xbase{a.x0, -1, 0.0};
     const int e_first = rec.v[1] + (tid & (HPART_PAIRS - 1));
     const int4 it_first = OGT_ELEM[e_first < rec.v[2] ? e_first : rec.v[1]];   // requested now, used after the chains
@@ -1144,14 +1099,8 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
             for (int l = lane; l < N; l += 64)
                 hx[blk.v[4] + s * N + l] = OgGen::mv_operand(blk.v[0] + s, l, xbase, a.cvec);
     }
-    for (int w = tid; w < ROW_WORDS; w += SWEEP_THREADS) bits[w] = 0u;
-    if (tid == 0) s_nonfinite = 0;
     __syncthreads();
-    // positions written by ANY part of this column are not filled
-    for (int e = col.x + tid; e < col.y; e += SWEEP_THREADS) {
-        const int r = OGT_ELEM[e].w;
-        atomicOr(&bits[r >> 5], 1u << (r & 31));
-    }
+    FZ_STAMP(1);
     for (int i = rec.v[3] + wave; i < rec.v[4]; i += SWEEP_WAVES) {
         const ogt_int8 blk = OGT_HPART_EB[i];
         const int N = blk.v[2], KS = (N + 3) >> 2, nt = blk.v[5], off = blk.v[4];
@@ -1160,11 +1109,8 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
                            [&](const int st, const int k, const double v) { hy[off + st * N + k] = v; });
     }
     __syncthreads();
+    FZ_STAMP(2);
     double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    const int r0 = rec.v[5], r1 = rec.v[6];
-    if (jt_needs_fill(a))
-        for (int r = r0 + tid; r < r1; r += SWEEP_THREADS)
-            if ((r < own_lo || r >= own_hi) && !marked(bits, r)) jrow[r] = 0.0;
     const bool base_role = tid >= HPART_PAIRS;
     const XCol xa{a.x0, base_role ? -1 : j, xj};
     for (int e0 = rec.v[1]; e0 < rec.v[2]; e0 += HPART_PAIRS) {
@@ -1181,16 +1127,12 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
         if (on && !base_role) jrow[row] = (v - vbase[tid]) / dx;
         if (e0 + HPART_PAIRS < rec.v[2]) lds_barrier();            // vbase is reused by the next round
     }
-    if (wave == SWEEP_WAVES - 1 && wave_nonfinite_verdict(a) && lane == 0) s_nonfinite = 1;
-    lds_barrier();
-    if (s_nonfinite && tid == 0) jt_mark_nan_fill(a);
-    if (s_nonfinite)
-        for (int r = r0 + tid; r < r1; r += SWEEP_THREADS)
-            if ((r < own_lo || r >= own_hi) && !marked(bits, r))
-                jrow[r] = __hip_atomic_load(&a.z[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FZ_STAMP(4);
+    FZ_TRACE_OUT(a);
 }
 
 __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, double* xt) {
+    FZ_TRACE_DECL(3);
     const int4 tile = OGT_TILE[bx];                    // {slot, tile group, node tile}
     const int slot = tile.x, nt = tile.z;
     const ogt_int8 rec = OGT_SLOT[slot];
@@ -1205,6 +1147,7 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
     for (int l = tid; l < KS * 4; l += SWEEP_THREADS)
         xt[l] = l < N ? OgGen::mv_operand(slot, l, xbase, a.cvec) : 0.0;
     __syncthreads();
+    FZ_STAMP(1);
     const int l0 = (tile.y * SWEEP_WAVES + wave) * 16;  // first slice offset of this wave's tile
     if (l0 >= N || leaf + l0 >= a.col_hi || leaf + l0 + 16 <= a.col_lo) return;
     const int k = nt * 16 + (lane & 15);                // output node of this lane
@@ -1271,6 +1214,7 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
 #pragma unroll
         for (int u = 0; u < CH; ++u) bv[u] = bn[u];
     }
+    FZ_STAMP(2);
     if (!k_on) return;
     const double f_base = accb[0] - t_base;             // every row of accb holds the base product of node k
 #pragma unroll
@@ -1296,6 +1240,8 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
         const double val = acc[reg] - t;
         a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - f_base) / dx;
     }
+    FZ_STAMP(4);
+    FZ_TRACE_OUT(a);
 }
 
 __global__ __launch_bounds__(SWEEP_THREADS) void ogk_fused(const ogk_args a, const int ndef, const int n_eval,
@@ -1303,21 +1249,25 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_fused(const ogk_args a, con
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int id = (int)blockIdx.x;
     if (id < n_eval) {
+        FZ_TRACE_DECL(0);
         if (id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
         if (!(OGK_FZ & 16)) {
             if (id < ndef) eval_defect_body<true>(a, id, lds);
             else eval_rows_body<true>(a, id - ndef);
         }
-        signal_ready(a);
+        FZ_STAMP(1);
+        finish_eval(a, (unsigned)n_eval, reinterpret_cast<unsigned*>(lds));
+        FZ_STAMP(4);
+        FZ_TRACE_OUT(a);
         return;
     }
     id -= n_eval;
-    // the light workgroups carry the J_T stream and have the longest life: dispatched right behind the
-    // evaluation workgroups (which must come first: the service wavefronts poll their ticket)
+    // nothing in the sweep workgroups waits for the evaluation workgroups (finish_eval); the light workgroups
+    // have the longest life and are dispatched right behind them, heavy parts and MFMA tiles last
     if (id < n_light) {
-        fz_light_body(a, group_lo + id, reinterpret_cast<unsigned*>(lds));
+        fz_light_body(a, group_lo + id, lds);
     } else if (id < n_light + OGT_N_HPART) {
-        if (!(OGK_FZ & 32)) fz_heavy_part(a, id - n_light, reinterpret_cast<unsigned*>(lds));
+        if (!(OGK_FZ & 32)) fz_heavy_part(a, id - n_light, lds);
     } else {
         if (OGK_FZ & 64) tile_body(a, id - n_light - OGT_N_HPART);
         else fz_tile_body(a, id - n_light - OGT_N_HPART, lds);
@@ -1407,11 +1357,13 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         while (glo < ghi && OGH_LGRP_J[glo + 1] <= args->col_lo) ++glo;
         while (ghi > glo && OGH_LGRP_J[ghi - 1] >= args->col_hi) --ghi;
         size_t lds_bytes = defect_lds_bytes() > FZ_LDS_BYTES ? defect_lds_bytes() : FZ_LDS_BYTES;
-        const size_t heavy_lds = (size_t)((ROW_WORDS + 3) & ~3) * sizeof(unsigned) + HPART_PAIRS * sizeof(double);
-        if (heavy_lds > lds_bytes) lds_bytes = heavy_lds;
-        if (lds_bytes > 64 * 1024) {
-            // a tile's panel and operands do not fit the default LDS window (hundreds of nodes x 16 states):
-            // the same work as two launches
+        const size_t other_lds = (size_t)ROW_WORDS * sizeof(unsigned) > HPART_PAIRS * sizeof(double)
+                                     ? (size_t)ROW_WORDS * sizeof(unsigned) : HPART_PAIRS * sizeof(double);
+        if (other_lds > lds_bytes) lds_bytes = other_lds;
+        if (!args->jt_sparse || lds_bytes > 64 * 1024 || ndef + eval_row_blocks == 0) {
+            // the one-launch form writes the non-zeros only: it needs a registered (persistent-zero) output
+            // buffer (og_jt_register_dev).  Also when a tile's panel and operands do not fit the default LDS
+            // window (hundreds of nodes x 16 states): the same work as two launches.
             const int rc0 = ogk_launch(args, 0, stream_);
             return rc0 ? rc0 : ogk_launch(args, 1, stream_);
         }

@@ -83,7 +83,7 @@ struct og_problem_s {
     int* d_flags = nullptr;             // two non-finite-row counters used alternately, then the ticket of the
     int flag_slot = 0;                  // fused launch (evaluation workgroups that have finished, ever)
     int n_eval_blocks = 0;
-    unsigned fused_launches = 0;
+    double* d_trace = nullptr;          // phase stamps of -DOGK_TRACE kernel builds (tools/trace_fused.py)
     // how og_fd_sweep_dev runs: 5 evaluation + structured sweep in one launch (default), 1 the same as two
     // launches (OGPSX_SWEEP=split), 2 evaluation + dense sweep (OGPSX_SWEEP=dense).  og_fd_columns_dev (the
     // sweep alone, F(x0) supplied) uses 1 or 2.
@@ -103,6 +103,7 @@ struct og_problem_s {
     uint32_t* d_state = nullptr;
 };
 static const int OG_MAX_JT_REGS = 63;
+static const size_t OG_TRACE_DOUBLES = (size_t)1 << 20;     // 16384 workgroups x 8 wavefronts x 8 stamps
 
 namespace {
 
@@ -120,7 +121,7 @@ void fill_args(og_problem_s* p, ogk_args* a, const double* x, const double* h, d
     a->nonfinite = p->d_flags + p->flag_slot;
     a->nonfinite_next = p->d_flags + (p->flag_slot ^ 1);
     a->ready = reinterpret_cast<unsigned*>(p->d_flags + 2);
-    a->ready_target = 0;
+    a->trace = p->d_trace;
     a->hscr = p->d_hscr;
     a->jt = jt;
     a->col_lo = lo;
@@ -339,6 +340,10 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
                                       (size_t)(info.n_heavy > 0 ? info.n_heavy : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_flags, 4 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(int));
+    if (e == hipSuccess && getenv("OGPSX_TRACE")) {
+        e = hipMalloc(&p->d_trace, sizeof(double) * OG_TRACE_DOUBLES);
+        if (e == hipSuccess) e = hipMemset(p->d_trace, 0, sizeof(double) * OG_TRACE_DOUBLES);
+    }
     if (e == hipSuccess) e = hipMalloc(&p->d_state, (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(p->d_state, 0xff, (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
     p->n_eval_blocks = info.n_eval_blocks;
@@ -376,12 +381,24 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_z);
     hipFree(p->d_flags);
     hipFree(p->d_state);
+    hipFree(p->d_trace);
     hipFree(p->d_hscr);
     if (p->module) dlclose(p->module);
     delete p;
 }
 
 int og_sweep_mode(og_handle p) { return p ? p->sweep_mode : 0; }
+
+int og_trace_read(og_handle p, double* out, int64_t count) {
+    if (!p || !out) return fail(1, "og_trace_read: null argument");
+    if (!p->d_trace) return fail(1, "og_trace_read: the handle was created without OGPSX_TRACE=1");
+    if (count < 0 || (size_t)count > OG_TRACE_DOUBLES) return fail(1, "og_trace_read: bad count");
+    OG_HIP(hipSetDevice(p->device));
+    OG_HIP(hipDeviceSynchronize());
+    OG_HIP(hipMemcpy(out, p->d_trace, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+    OG_HIP(hipMemset(p->d_trace, 0, sizeof(double) * OG_TRACE_DOUBLES));
+    return 0;
+}
 
 int og_jt_register_dev(og_handle p, double* d_JT, int32_t lo, int32_t hi, void* hip_stream) {
     if (!p || !d_JT) return fail(1, "og_jt_register_dev: null argument");
@@ -448,12 +465,8 @@ int og_fd_sweep_dev(og_handle p, const double* d_x, const double* d_h, int32_t l
     fill_args(p, &a, d_x, d_h, d_F0, d_JT, lo, hi);
     int rc;
     if (p->sweep_mode == 5 && hi > lo) {
-        // one launch: the evaluation workgroups count into a ticket that is never reset
-        a.ready_target = (p->fused_launches + 1) * (unsigned)p->n_eval_blocks;
+        // one launch (the module falls back to two when d_JT is not a registered buffer)
         rc = p->launch(&a, 5, hip_stream);
-        // the ticket only advances when the launch was accepted: a failed launch must not leave every later
-        // sweep waiting for evaluation workgroups that never ran
-        if (!rc) p->fused_launches += 1;
     } else {
         rc = p->launch(&a, 0, hip_stream);          // F(x0) first: the sweep subtracts it
         if (!rc) rc = p->launch(&a, p->sweep_mode == 5 ? 1 : p->sweep_mode, hip_stream);

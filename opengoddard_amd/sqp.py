@@ -63,6 +63,8 @@ class DeviceJacobian:
         self.d_F0 = torch.empty(self.ld, dtype=torch.float64, device=dev)
         self.d_JT = torch.empty(self.n * self.ld, dtype=torch.float64, device=dev)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
+        # persistent-zero output: every sweep of the solve writes the non-zeros only (include/ogpsx.h)
+        engine.register_jt_dev(self.d_JT.data_ptr(), 0, self.n, self.stream)
 
     def sweep(self, x, lb, ub):
         """One FD sweep at ``x`` (SciPy's step rule); returns F(x) on the host."""

@@ -11,7 +11,7 @@
 import numpy as np
 import pytest
 
-from conftest import fd_noise_bound, inject_reference_lgl
+from conftest import assert_zero_pattern, fd_noise_bound, golden_full_columns, inject_reference_lgl
 from opengoddard_amd import _native, problems
 
 pytestmark = pytest.mark.gpu
@@ -83,6 +83,41 @@ def test_against_reference_goldens(name, golden, lgl_golden):
         err = np.abs(JT[cols] - JTg)
         assert np.all(err <= bound), "Jacobian outside the FD noise bound: worst ratio %.3g" % \
             np.max(err / np.maximum(bound, 1e-300))
+        # structural zeros are exact zeros on both sides (same code for base and perturbed values)
+        assert np.array_equal(JT[cols] != 0, JTg != 0), "zero pattern differs from the reference's"
+        full = golden_full_columns(G, k)
+        if full is not None:            # every column (C3, C4) / 1024 columns (C5) the reference differenced
+            fcols, JTf = full
+            err, bound = np.abs(JT[fcols] - JTf), fd_noise_bound(JTf, scale, h[fcols])
+            assert np.all(err <= bound), "full-column golden: worst ratio %.3g" % np.max(err / np.maximum(bound, 1e-300))
+            assert_zero_pattern(eng.program, fcols, JT[fcols], JTf)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_against_numpy_restatement_without_generated_code(name, golden):
+    """An oracle link that shares NOTHING with the code under test: the GPU results against (a) the NumPy
+    restatement of the reference path (oracle/np_path.py: the user's callbacks run by NumPy, SciPy's column
+    loop - no tracer, no generated code, no og_math.h) for EVERY column up to C4's size and 768 columns at
+    C5, and (b) the NumPy interpreter of the traced program (oracle/program_eval.py).  A tracer, lowering,
+    code-emission or og_math bug cannot hide here the way it could behind the CPU twin, which compiles the
+    same generated header.  Bounds: residual 1e-9 of the row's term magnitude; Jacobian within the
+    forward-difference noise bound with factor 4; identical zero pattern."""
+    from oracle import np_path, program_eval
+    G = golden("cfg_" + name)
+    prob, obj, eng, tw = _engine_and_twin(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    k = G["x"].shape[0] - 1
+    x = G["x"][k]
+    cols = np.arange(eng.n) if eng.n <= 2100 else np.unique(np.linspace(0, eng.n - 1, 768).astype(int))
+    F_np, h, JT_np = np_path.sweep(prob, obj, x, cols)
+    F0, JT = eng.sweep_stacked(x, h)
+    scale = row_scales(eng, prob, x, F_np)
+    assert np.all(np.abs(F0 - F_np) <= 1e-9 * scale)
+    assert np.all(np.abs(program_eval.evaluate(eng.program, prob, x) - F0) <= 1e-9 * scale)
+    err, bound = np.abs(JT[cols] - JT_np), fd_noise_bound(JT_np, scale, h[cols])
+    assert np.all(err <= bound), "worst ratio %.3g" % np.max(err / np.maximum(bound, 1e-300))
+    assert_zero_pattern(eng.program, cols, JT[cols], JT_np)
     eng.close()
 
 
@@ -115,7 +150,7 @@ def test_structured_sweep_equals_dense_sweep(name, golden, monkeypatch):
         prob, obj, eng, tw = _engine_and_twin(name)
         assert eng.sweep_mode == layout
         out[layout] = eng.sweep_stacked(x, h)
-        if layout == "fused":                        # back to back on one handle: the ticket advances
+        if layout == "fused":                        # back to back on one handle: the ticket resets itself
             for _ in range(3):
                 again = eng.sweep_stacked(x, h)
                 assert np.array_equal(again[0], out[layout][0]) and np.array_equal(again[1], out[layout][1])
@@ -189,7 +224,8 @@ def test_non_finite_rows_propagate_like_dense_fd(name, state, layout, monkeypatc
     """A row that is NaN/inf at x0 makes its whole Jacobian row NaN in SciPy's dense FD
     ((NaN - NaN)/dx); the structured sweep must reproduce that, not write zeros.  (In the fused launch
     this is the one thing the sweep workgroups take from the evaluation workgroups of the same kernel:
-    they fill with zeros first and rewrite the fill when the ticket says there are non-finite rows.)"""
+    the evaluation workgroup that draws the last ticket sees the count of non-finite rows and fills every row
+    from z around the positions the sweep workgroups write; unregistered buffers take the two-launch form.)"""
     from opengoddard_amd.engine import HipEngine
     from oracle import np_path, twin
     monkeypatch.setenv("OGPSX_SWEEP", layout)

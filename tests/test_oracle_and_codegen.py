@@ -9,7 +9,7 @@ plus the FD step rule in all three places (SciPy-made goldens, oracle, og_fd_ste
 import numpy as np
 import pytest
 
-from conftest import fd_noise_bound, inject_reference_lgl
+from conftest import assert_zero_pattern, fd_noise_bound, golden_full_columns, inject_reference_lgl
 from opengoddard_amd import _native, codegen, problems
 from opengoddard_amd import trace as tr
 from oracle import np_path, program_eval, twin
@@ -103,6 +103,13 @@ def test_cpu_twin_against_reference_goldens(name, golden, lgl_golden):
         JTg = G["JT"][k][:ncheck]
         assert np.all(np.abs(JT - JTg) <= fd_noise_bound(JTg, scale, h[cols]))
         assert np.array_equal(JT == 0.0, JTg == 0.0)
+        full = golden_full_columns(G, k)
+        if full is not None:            # every column (C3, C4) / 1024 columns (C5) the reference differenced
+            fcols, JTf = full
+            JT = tw.sweep(x, h, fcols)[1]
+            err, bound = np.abs(JT - JTf), fd_noise_bound(JTf, scale, h[fcols])
+            assert np.all(err <= bound), "worst ratio %.3g" % np.max(err / np.maximum(bound, 1e-300))
+            assert_zero_pattern(tw.program, fcols, JT, JTf)
 
 
 def test_fd_step_rule_on_adversarial_bounds():

@@ -123,8 +123,27 @@ def column_sample(n, prob_like_div, rng):
     return np.array(sorted(picks))
 
 
-def evaluate_case(got, div, extra_points=1, iterate_point=True):
-    """Evaluate the captured closures at x0 (clipped) and at further points."""
+def fd_rows(stacked, x, f0, h, cols):
+    """J_transposed rows for ``cols``: the loop of ``_dense_difference`` ('2-point',
+    scipy/optimize/_numdiff.py:592-620) on the stacked function; checked against ``approx_derivative``
+    itself on the small cases (FULL_J_MAX_N branch) where both are stored."""
+    jt = np.empty((len(cols), f0.size))
+    x1 = x.copy()
+    for r, i in enumerate(cols):
+        x1[i] += h[i]
+        dx = x1[i] - x[i]
+        jt[r] = (stacked(x1) - f0) / dx
+        x1[i] = x[i]
+    return jt
+
+
+def evaluate_case(got, div, extra_points=1, iterate_point=True, iterate_maxiter=5, full_points=(), full_count=None):
+    """Evaluate the captured closures at x0 (clipped) and at further points.
+
+    ``full_points``: indices of evaluation points at which, for a problem too large to store densely,
+    ALL columns (or ``full_count`` evenly spaced ones plus the sample) of J_transposed are captured and
+    stored as CSR over the exact non-zeros (``Jfull_*`` keys) - structural zeros are exact zeros in the
+    reference's differences, so the pattern is part of the golden."""
     args = got["args"]
     funs = [got["fun"], got["constraints"][0]["fun"], got["constraints"][1]["fun"]]
     lb, ub = bounds_arrays(got["bounds"])
@@ -139,14 +158,20 @@ def evaluate_case(got, div, extra_points=1, iterate_point=True):
             warnings.simplefilter("ignore")
             opt = sciopt.minimize(got["fun"], x0.copy(), args=args, bounds=got["bounds"],
                                   constraints=got["constraints"], jac=got["jac"], method="SLSQP",
-                                  options={"disp": False, "maxiter": 5, "ftol": 1e-12})
+                                  options={"disp": False, "maxiter": iterate_maxiter, "ftol": 1e-12})
         points.append(np.clip(np.array(opt.x, dtype=float), lb, ub))
 
     n = x0.size
     cols = column_sample(n, div, np.random.default_rng(1))
     X, F, H, JT = [], [], [], []
     sizes = None
-    for x in points:
+    full = {}
+    if n > FULL_J_MAX_N and full_points:
+        fc = np.arange(n) if not full_count or full_count >= n else \
+            np.unique(np.concatenate([np.linspace(0, n - 1, full_count).astype(int), cols]))
+        full["Jfull_cols"] = fc
+        full["Jfull_points"] = np.array([k % len(points) for k in full_points])
+    for ip, x in enumerate(points):
         vals = [np.atleast_1d(np.asarray(f(x.copy(), *args), dtype=float)) for f in funs]
         sizes = [v.size for v in vals]
         f0 = np.concatenate(vals)
@@ -161,15 +186,18 @@ def evaluate_case(got, div, extra_points=1, iterate_point=True):
         else:
             stacked = lambda p: np.concatenate(                           # noqa: E731
                 [np.atleast_1d(np.asarray(f(p, *args), dtype=float)) for f in funs])
-            jt = np.empty((cols.size, f0.size))
-            x1 = x.copy()
-            for r, i in enumerate(cols):
-                x1[i] += h[i]
-                dx = x1[i] - x[i]
-                jt[r] = (stacked(x1) - f0) / dx
-                x1[i] = x[i]
+            jt = fd_rows(stacked, x, f0, h, cols)
+            if full and ip in set(full["Jfull_points"].tolist()):
+                fj = fd_rows(stacked, x, f0, h, full["Jfull_cols"])
+                assert np.array_equal(fj[np.searchsorted(full["Jfull_cols"], cols)], jt)
+                nz = fj != 0
+                full["Jfull_indptr_%d" % ip] = np.concatenate([[0], np.cumsum(nz.sum(axis=1))]).astype(np.int64)
+                full["Jfull_indices_%d" % ip] = np.nonzero(nz)[1].astype(np.int32)
+                full["Jfull_data_%d" % ip] = fj[nz]
+                print("    full columns at point %d: %d x %d, %d non-zeros (%.1f %%)" % (
+                    ip, fj.shape[0], fj.shape[1], int(nz.sum()), 100.0 * nz.mean()), flush=True)
         X.append(x), F.append(f0), H.append(h), JT.append(jt)
-    return dict(x=np.array(X), F=np.array(F), h=np.array(H), JT=np.array(JT), cols=cols,
+    return dict(x=np.array(X), F=np.array(F), h=np.array(H), JT=np.array(JT), cols=cols, **full,
                 lb=lb, ub=ub, m_eq=np.int64(sizes[1]), m_ineq=np.int64(sizes[2]),
                 scipy_version=np.array(scipy.__version__), numpy_version=np.array(np.__version__))
 
@@ -304,8 +332,12 @@ def golden_config(name):
 
     got = capture(run)
     prob = holder["prob"]
-    big = prob.number_of_variables > 2500
-    data = evaluate_case(got, prob.div, iterate_point=not big)
+    n = prob.number_of_variables
+    # C5: one major iteration of SciPy's Fortran SLSQP is minutes of O(n^3) work - the iterate after the
+    # first one (bounds already active) is what is affordable
+    big = n > 2500
+    data = evaluate_case(got, prob.div, iterate_maxiter=1 if big else 5,
+                         full_points=(0, -1) if n <= 1600 else (0,), full_count=None if n <= 2500 else 1024)
     data["nodes"] = np.array(prob.nodes)
     np.savez_compressed(os.path.join(OUT, "cfg_%s.npz" % name), **data)
     print("  cfg_%s: n=%d m_eq=%d m_ineq=%d cols=%d" % (name, data["x"].shape[1], data["m_eq"],

@@ -1,45 +1,75 @@
 #!/usr/bin/env python3
-"""Dev tool (GPU box): phase timing of the light workgroups of ogk_fused from in-kernel stamps
-(s_memrealtime, 100 MHz: 10 ns per tick, one clock for the whole chip).
-    OG_EXTRA_HIPFLAGS=-DOGK_TRACE=1 OGPSX_SWEEP=fused python tools/trace_fused.py [workload]
+"""Dev tool (GPU box): phase timing of every workgroup of ogk_fused from in-kernel stamps
+(s_memrealtime, 100 MHz: 10 ns per tick, one clock for the whole chip), read back through og_trace_read.
+    OG_EXTRA_HIPFLAGS=-DOGK_TRACE=1 OGPSX_TRACE=1 OGPSX_SWEEP=fused python tools/trace_fused.py [workload]
+Record per wavefront: kind (0 evaluation, 1 light, 2 heavy part, 3 MFMA tile), start, four phase stamps, end.
 """
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 assert "OGK_TRACE" in os.environ.get("OG_EXTRA_HIPFLAGS", ""), "set OG_EXTRA_HIPFLAGS=-DOGK_TRACE=1"
+os.environ["OGPSX_TRACE"] = "1"
+import torch
 from opengoddard_amd import _native, problems
 from opengoddard_amd.engine import HipEngine
 name = sys.argv[1] if len(sys.argv) > 1 else "polar_tsto"
 prob, obj = problems.build(name)
 eng = HipEngine(prob, obj)
+n, m = eng.n, eng.m
 lb = np.array([-np.inf if b[0] is None else b[0] for b in prob.bounds])
 ub = np.array([np.inf if b[1] is None else b[1] for b in prob.bounds])
 x = np.clip(prob.p, lb, ub); h = _native.fd_step(x, lb, ub)
-for _ in range(5):
-    F0, JT = eng.sweep_stacked(x, h)
-flat = JT.ravel()
-def records(tag_lo, tag_hi, width):
-    """rows: the stamps of one wavefront, with the J_T row (= first column of its workgroup) appended"""
-    idx = np.nonzero((flat >= tag_lo) & (flat <= tag_hi))[0]
-    idx = idx[idx + width < flat.size]
-    recs = np.array([np.r_[flat[i:i + width], i // JT.shape[1]] for i in idx])
-    return recs[recs[:, 1] > 1e6] if len(recs) else recs
-item = records(1.0e6, 1.0e6 + 1, 8)
-serv = records(3.0e6, 3.0e6, 8)
-t0 = min(item[:, 1].min(), serv[:, 1].min())
-print("%s: %d item / %d service wavefront records; times in us after the first light wavefront started" % (
-    name, len(item), len(serv)))
+dev = torch.device("cuda", 0)
+d_x, d_h = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+d_F = torch.empty(m, dtype=torch.float64, device=dev)
+d_JT = torch.empty((n, m), dtype=torch.float64, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+eng.register_jt_dev(d_JT.data_ptr(), 0, n, stream)
+count = 1 << 20
+buf = np.empty(count)
+for rep in range(6):
+    for _ in range(5):
+        eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), 0, n, d_JT.data_ptr(), d_F.data_ptr(), stream)
+    torch.cuda.synchronize()
+    _native.check(_native.lib().og_trace_read(eng._handle, _native.dptr(buf), count), "og_trace_read")
+rec = buf.reshape(-1, 8)
+wg = np.repeat(np.arange(rec.shape[0] // 8), 8)
+live = rec[:, 1] > 0
+rec, wg = rec[live], wg[live]
+t0 = rec[:, 1].min()
+us = lambda v: (v - t0) * 0.01
+print("%s (%s): %d wavefront records, kernel span %.2f us (first start to last end)" % (
+    name, eng.sweep_mode, len(rec), us(rec[:, 7].max())))
+names = {0: "evaluation", 1: "light", 2: "heavy part", 3: "MFMA tile"}
 def line(label, v):
-    v = (v - t0) * 0.01
-    print("   %-38s p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f" % (label, np.percentile(v, 10), np.median(v), np.percentile(v, 90), v.max()))
-line("start", item[:, 1]); line("after barrier 2", item[:, 2]); line("fill issued", item[:, 3])
-w = item[item[:, 0] == 1.0e6 + 1]
-line("base products flag seen", w[:, 4]); line("items done", w[:, 5]); line("end (verdict seen)", item[:, 6])
-line("service: chain done", serv[:, 3]); line("service: verdict", serv[:, 6])
-# which workgroups are the late ones?  second barrier by position in the grid (first column of the workgroup)
-order = np.argsort(serv[:, -1])
-b2 = (serv[order, 2] - t0) * 0.01
-st = (serv[order, 1] - t0) * 0.01
-print("   second barrier / start by tenth of the grid (first to last light workgroup):")
-for part, (x, y) in enumerate(zip(np.array_split(b2, 10), np.array_split(st, 10))):
-    print("      tenth %d: start p50 %5.2f  barrier 2 p50 %5.2f  max %5.2f" % (part, np.median(y), np.median(x), x.max()))
+    v = us(v)
+    print("      %-28s p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f" % (label, np.percentile(v, 10), np.median(v), np.percentile(v, 90), v.max()))
+for kind in (0, 1, 2, 3):
+    r = rec[rec[:, 0] == kind]
+    if not len(r):
+        continue
+    print("   %s: %d wavefronts in %d workgroups" % (names[kind], len(r), len(set(wg[rec[:, 0] == kind]))))
+    line("start", r[:, 1])
+    if kind == 0:
+        line("results out", r[r[:, 2] > 0][:, 2])
+    if kind == 1:
+        line("after the barrier", r[r[:, 2] > 0][:, 2])
+        s = r[r[:, 3] > 0]
+        if len(s): line("service: chain done", s[:, 3])
+        it = r[r[:, 4] > 0]
+        if len(it): line("items: flag seen", it[:, 4])
+    if kind == 2:
+        line("operands staged", r[r[:, 2] > 0][:, 2]); line("base products done", r[r[:, 3] > 0][:, 3])
+    if kind == 3:
+        line("operands staged", r[r[:, 2] > 0][:, 2]); line("MFMA chain done", r[r[:, 3] > 0][:, 3])
+    line("end", r[:, 7])
+# who ends last?
+order = np.argsort(-rec[:, 7])[:12]
+print("   last wavefronts to end: " + ", ".join("%s wg %d @%.2f" % (names[int(rec[i, 0])][:5], wg[i], us(rec[i, 7])) for i in order))
+light = rec[rec[:, 0] == 1]
+lw = wg[rec[:, 0] == 1]
+if len(light):
+    print("   light workgroups by tenth of their grid range: start p50 / end p50 / end max")
+    o = np.argsort(lw)
+    for part, idx in enumerate(np.array_split(o, 10)):
+        print("      tenth %d: %5.2f  %5.2f  %5.2f" % (part, np.median(us(light[idx, 1])), np.median(us(light[idx, 7])), us(light[idx, 7]).max()))

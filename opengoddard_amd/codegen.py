@@ -40,7 +40,6 @@ def fused_cols(n):
     return int(env) if env else (8 if n >= 1024 else 4)
 
 
-HPART_ITEMS = 256                # items of a heavy column per workgroup in the fused launch (half of SWEEP_THREADS)
 MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "1"))
 
 
@@ -893,6 +892,27 @@ def emit_header(P):
             L += ["            *row = %d + k; return group%d_v(k, x, cv);" % (g.outputs[0][0], gi)]
         L.append("        }")
     L += ["        default: break;", "        }", "        *row = 0;", "        return S(0.0);", "    }", ""]
+    # the same split in two: everything of an item except the base collocation product it subtracts from
+    # (row items: the whole value, *yoff = -1) - the long chain that does not depend on the product - and the
+    # offset of that product in the y0 scratch.  value = yoff >= 0 ? y0[yoff] - tail : tail.
+    L.append("    template <class X> OG_HDI static typename X::scalar item_tail(const int g, const int o, "
+             "const int k, const X& x, const double* cv, int* row, int* yoff) {")
+    L.append("        typedef typename X::scalar S;")
+    L.append("        (void)o;")
+    L.append("        switch (g) {")
+    for gi, g in enumerate(P.groups):
+        L.append("        case %d: {" % gi)
+        if g.kind == "defect":
+            L.append("            switch (o) {")
+            for si in range(len(g.tails)):
+                L.append("            case %d: *row = %d + k; *yoff = %d + k; return tail%d_%d(k, x, cv);"
+                         % (si, g.outputs[si][0], y0_off[g.mv_slots[si]], gi, si))
+            L += ["            default: break;", "            }", "            break;"]
+        else:
+            L += ["            *row = %d + k; *yoff = -1; return group%d_v(k, x, cv);" % (g.outputs[0][0], gi)]
+        L.append("        }")
+    L += ["        default: break;", "        }", "        *row = 0;", "        *yoff = -1;", "        return S(0.0);",
+          "    }", ""]
     # the dynamics term of one collocation slot (one state) at node k
     L.append("    template <class X> OG_HDI static typename X::scalar tail_one(const int slot, const int k, "
              "const X& x, const double* cv) {")
@@ -965,39 +985,51 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
             lgrp.append([j0, cnt, y0_off[g.mv_slots[0]], key[1], g.mv_slots[0], len(g.mv_slots), g.length, g.phase])
         else:
             lgrp.append([j0, cnt, 0, 0, 0, 0, 0, 0])
-    # heavy columns of the fused launch: HPART_ITEMS items per workgroup (one lane pair each), the row's
-    # fill split evenly; each part lists the evaluation blocks (defect group, node tile) whose base
-    # products its items read (bit 16: first block of its group in the list -> stage that group's operands)
-    eb_index = {(r[0], r[1]): i for i, r in enumerate(evalblk)}
-    hpart, hpart_eb = [], []
+    # heavy columns of the fused launch are cut into parts that look like light workgroups: one part per
+    # (defect group, 16-node tile) the column has items in - the tile's D^T panel and the group's operands go
+    # through LDS, one wavefront runs the tile's base products - plus one tile-less part for its row items.
+    # A part's items come in *slots*: runs of at most 16 (defect: one output over the tile's nodes) or 32 (rows:
+    # one row group) items that share their code, one wavefront each (lanes: items at x0 + h e_j | the same at x0).
+    # OGT_HELEM holds the heavy columns' items in that order (OGT_ELEM keeps the order mode 1 uses).
+    hpart, hslot, helem = [], [], []
     for j in heavy:
-        e0, e1 = col_ptr[j], col_ptr[j + 1]
-        nparts = max(1, -(-(e1 - e0) // HPART_ITEMS))
-        for pi in range(nparts):
-            a0, a1 = e0 + pi * HPART_ITEMS, min(e1, e0 + (pi + 1) * HPART_ITEMS)
-            need = sorted({eb_index[(elem_g[e], elem_k[e] >> 4)] for e in range(a0, a1)
-                           if P.groups[elem_g[e]].kind == "defect"})
-            first, seen = len(hpart_eb), set()
-            for eb in need:
-                gi, nt_, mv0_, nmv_ = evalblk[eb]
-                hpart_eb.append([mv0_, nmv_, P.groups[gi].length, P.groups[gi].phase, y0_off[mv0_], nt_,
-                                 0 if gi in seen else 1, 0])
-                seen.add(gi)
-            r0 = (P.m * pi // nparts) & ~1
-            r1 = P.m if pi == nparts - 1 else (P.m * (pi + 1) // nparts) & ~1
-            hpart.append([j, a0, a1, first, len(hpart_eb), r0, r1, len(hpart)])
+        entries = [(elem_g[e], elem_o[e], elem_k[e]) for e in range(col_ptr[j], col_ptr[j + 1])]
+        tiles_of = {}
+        for gi, o, k in entries:
+            if P.groups[gi].kind == "defect":
+                tiles_of.setdefault((gi, k >> 4), {}).setdefault(o, []).append(k)
+        for (gi, nt_), by_out in sorted(tiles_of.items()):
+            g = P.groups[gi]
+            first_slot = len(hslot)
+            for o, ks in sorted(by_out.items()):
+                hslot.append([len(helem), len(ks), 0, 0])
+                helem += [[gi, o, k, g.outputs[o][0] + k] for k in sorted(ks)]
+            hpart.append([j, first_slot, len(hslot), y0_off[g.mv_slots[0]], nt_, g.mv_slots[0], len(g.mv_slots),
+                          g.length | (g.phase << 20)])
+        rows_by_group = {}
+        for gi, o, k in entries:
+            if P.groups[gi].kind != "defect":
+                rows_by_group.setdefault((gi, o), []).append(k)
+        if rows_by_group:
+            first_slot = len(hslot)
+            for (gi, o), ks in sorted(rows_by_group.items()):
+                ks = sorted(ks)
+                for c0 in range(0, len(ks), 32):
+                    chunk = ks[c0:c0 + 32]
+                    hslot.append([len(helem), len(chunk), 0, 0])
+                    helem += [[gi, o, k, P.groups[gi].outputs[max(o, 0)][0] + k] for k in chunk]
+            hpart.append([j, first_slot, len(hslot), 0, 0, 0, 0, 0])
     L += ["struct ogt_int8 { int v[8]; };",
           "static __device__ const ogt_int8 OGT_HPART[%d] = {" % max(len(hpart), 1),
           ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (hpart or [[0] * 8])),
           "};",
           "static constexpr int OGT_N_HPART = %d;" % len(hpart),
-          "static __device__ const ogt_int8 OGT_HPART_EB[%d] = {" % max(len(hpart_eb), 1),
-          ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (hpart_eb or [[0] * 8])),
-          "};",
           "static constexpr int OGT_LGRP_COLS = %d;" % fused_cols(P.n),
           "static __device__ const ogt_int8 OGT_LGRP[%d] = {" % max(len(lgrp), 1),
           ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (lgrp or [[0] * 8])),
           "};"]
+    L += table("int4", "OGT_HSLOT", hslot)    # {first item in OGT_HELEM, items} per slot of a heavy part
+    L += table("int4", "OGT_HELEM", helem)
     L += table("int4", "OGT_LRNG", lrng)      # {items begin, end} per (group, column)
     L += ["static constexpr int OGT_N_LGRP = %d;" % len(light_groups),
           "static const int OGH_LGRP_J[%d] = {%s};" % (len(light_groups) + 1, ", ".join(
@@ -1007,6 +1039,18 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     L += table("int4", "OGT_COL", col)
     L += table("int4", "OGT_ELEM", elem)
     L += table("int4", "OGT_TILE", tiles)
+    # fused launch: {slot, first column tile, node tile, column tiles} - at most SWEEP_WAVES - 1 column tiles
+    # per workgroup (the last wavefront computes the base products of the node tile), spread evenly
+    ftiles = []
+    for si, sl in enumerate(P.mv):
+        t16 = (sl.length + 15) // 16
+        ngrp = -(-t16 // (SWEEP_WAVES - 1))
+        per = -(-t16 // ngrp)
+        for c0 in range(0, t16, per):
+            for nt in range(t16):
+                ftiles.append([si, c0, nt, min(per, t16 - c0)])
+    L += table("int4", "OGT_FTILE", ftiles)
+    L.append("static constexpr int OGT_N_FTILES = %d;" % len(ftiles))
     L += table("ogt_int8", "OGT_SLOT", [[r] for r in []] or None) if False else \
         ["static __device__ const ogt_int8 OGT_SLOT[%d] = {" % max(len(slots), 1),
          ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (slots or [[0] * 8])),

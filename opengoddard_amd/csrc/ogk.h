@@ -31,7 +31,6 @@ typedef struct ogk_info {
     int32_t n_y0;           // doubles of scratch for the unperturbed collocation products
     int32_t phase_nodes[OGK_MAX_PHASE];
     int32_t n_eval_blocks;  // evaluation workgroups of one launch (what the mode-5 ticket counts)
-    int32_t n_heavy;        // columns that get a workgroup of their own (mode 5 scratch: 2 * n_y0 doubles each)
 } ogk_info;
 
 typedef struct ogk_args {
@@ -47,7 +46,6 @@ typedef struct ogk_args {
     int* nonfinite;         // number of non-finite rows of F(x0): counted by mode 0, read by mode 1
     int* nonfinite_next;    // the slot the *next* evaluation counts into (mode 0 zeroes it)
     unsigned* ready;        // mode 5: ticket the evaluation workgroups count into; the last one resets it
-    double* hscr;           // mode 5: [n_heavy][2][n_y0] private operands / base products of the heavy columns
     double* jt;             // [(col_hi-col_lo) * m] transposed Jacobian rows (mode 1)
     // Persistent-zero output (og_jt_register_dev, include/ogpsx.h).  jt_sparse != 0: the structural zeros of
     // `jt` are known to hold zeros already, so the sweep writes ONLY the positions that can be non-zero (row

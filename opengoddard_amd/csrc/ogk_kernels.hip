@@ -446,7 +446,10 @@ __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx
     for (int i = tid + SWEEP_THREADS * UNR; i < KS * 64; i += SWEEP_THREADS) dpanel[i] = src[i];
     __syncthreads();
 
-    if (wave == 0) {
+    // The last wavefront runs the MFMA chain; meanwhile the others evaluate the dynamics terms (one state per
+    // wavefront at the tile's 16 nodes): those do not depend on the products, only the final subtraction does.
+    constexpr int TR = (OgGen::MAX_NMV + SWEEP_WAVES - 1) / SWEEP_WAVES;
+    if (wave == SWEEP_WAVES - 1) {
         const int srow = lane & 15;
         v4f64 acc = {0.0, 0.0, 0.0, 0.0};
         const double* xrow = xt + (srow < OgGen::MAX_NMV ? srow : 0) * NP;
@@ -470,18 +473,25 @@ __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) ybuf[(lk + 4 * reg) * 16 + (lane & 15)] = acc[reg];
     }
-    __syncthreads();
-
-    // one state per wavefront: its dynamics term at the tile's 16 nodes
     const int k = nt * 16 + lane;
-    if (lane >= 16 || k >= N) return;
-    for (int s = wave; s < nmv; s += SWEEP_WAVES) {
+    const bool node_on = lane < 16 && k < N;
+    double T[TR];
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        const int s = wave + r * SWEEP_WAVES;
+        T[r] = (node_on && s < nmv) ? OgGen::tail_one(mv0 + s, k, base, a.cvec) : 0.0;
+    }
+    __syncthreads();
+    if (!node_on) return;
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        const int s = wave + r * SWEEP_WAVES;
+        if (s >= nmv) break;
         const ogt_int8 rec = OGT_SLOT[mv0 + s];
         const double y = ybuf[s * 16 + lane];
-        const double T = OgGen::tail_one(mv0 + s, k, base, a.cvec);
         const int row = rec.v[3] + k;
-        publish_row<FUSED>(a, row, y - T);
-        a.t0[row] = T;
+        publish_row<FUSED>(a, row, y - T[r]);
+        a.t0[row] = T[r];
         a.y0[rec.v[4] + k] = y;
     }
 }
@@ -916,18 +926,28 @@ __device__ __forceinline__ void base_products_tile(const double* panel, const in
     const double* xrow = xt + (live ? srow : 0) * xstride;
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     constexpr int CH = 8;
+    double bv[CH], av[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        const int l = u * 4 + lk;
+        bv[u] = u < KS ? bsrc[u * 64] : 0.0;
+        av[u] = (u < KS && live && l < N) ? xrow[l] : 0.0;
+    }
     for (int ks0 = 0; ks0 < KS; ks0 += CH) {
-        double bv[CH], av[CH];
+        // the next chunk's operands are requested before this chunk's MFMAs issue
+        double bn[CH], an[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int ks = ks0 + u;
+            const int ks = ks0 + CH + u;
             const int l = ks * 4 + lk;
-            bv[u] = ks < KS ? bsrc[ks * 64] : 0.0;
-            av[u] = (ks < KS && live && l < N) ? xrow[l] : 0.0;
+            bn[u] = ks < KS ? bsrc[ks * 64] : 0.0;
+            an[u] = (ks < KS && live && l < N) ? xrow[l] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u)
             if (ks0 + u < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { bv[u] = bn[u]; av[u] = an[u]; }
     }
     // C/D layout: node = lane & 15, state = (lane >> 4) + 4 * reg
     const int k = nt * 16 + (lane & 15);
@@ -951,11 +971,11 @@ __device__ __forceinline__ void eval_item_paired(const ogk_args& a, const int4 i
 
 constexpr int FZ_MAXN = OgGen::MAX_NODES;                      // longest phase
 constexpr int FZ_NP = ((FZ_MAXN + 3) / 4) * 4;
+constexpr int FZ_ROUNDS = 2;                                    // items per column and wavefront evaluated ahead of the base products
 constexpr int FZ_ITEM_WAVES = SWEEP_WAVES - 1;                 // item slots of a light workgroup (the last wavefront
                                                                // runs the MFMA chain instead)
 // LDS of a light workgroup: D panel of the tile [KS][64] | operands [state][NP] | base products [state][N]
 constexpr size_t FZ_LDS_BYTES = ((size_t)(FZ_NP / 4) * 64 + (size_t)OgGen::MAX_NMV * (FZ_NP + FZ_MAXN)) * sizeof(double);
-constexpr int HPART_PAIRS = SWEEP_THREADS / 2;                 // codegen.HPART_ITEMS
 
 // flag the service wavefront raises in LDS for the other wavefronts of its workgroup
 __device__ __forceinline__ void lds_flag_raise(int* flag, const int value) {
@@ -988,6 +1008,49 @@ __device__ __forceinline__ int lds_flag_wait(int* flag) {
 #define FZ_TRACE_OUT(a_) do { } while (0)
 #endif
 
+// LDS of a workgroup that owns one (defect group, node tile): what its service wavefront needs
+struct FzTile {
+    double* dpanel;     // [KS][64] D^T panel of the tile in operand order
+    double* xt;         // [state][NP] operands of the group
+    double* yb;         // [state][N] base products (the tile's nodes)
+};
+__device__ __forceinline__ FzTile fz_tile_lds(double* lds) {
+    FzTile t;
+    t.dpanel = lds;
+    t.xt = lds + (FZ_NP / 4) * 64;
+    t.yb = t.xt + OgGen::MAX_NMV * FZ_NP;
+    return t;
+}
+// everybody requests the tile's D^T panel and the group's operands and parks them in LDS; the caller's barrier
+// publishes them to the service wavefront
+__device__ __forceinline__ void fz_stage_tile(const ogk_args& a, const FzTile& t, const int nt, const int mv0,
+                                              const int nmv, const int N, const int phase) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KS = (N + 3) >> 2, NP = KS << 2;
+    constexpr int ST_D = (FZ_NP / 4 * 64 + SWEEP_THREADS - 1) / SWEEP_THREADS;
+    constexpr int ST_S = (OgGen::MAX_NMV + SWEEP_WAVES - 1) / SWEEP_WAVES, ST_L = (FZ_NP + 63) / 64;
+    const XCol xbase{a.x0, -1, 0.0};
+    double st_d[ST_D];
+    const double* src = a.dfrag + a.dfrag_off[phase] + (long)nt * KS * 64;
+#pragma unroll
+    for (int u = 0; u < ST_D; ++u) {
+        const int i = tid + u * SWEEP_THREADS;
+        st_d[u] = i < KS * 64 ? src[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < ST_S; ++u)                             // a slot per wavefront: no divergence
+#pragma unroll
+        for (int q = 0; q < ST_L; ++q) {
+            const int sl = wave + u * SWEEP_WAVES, l = lane + q * 64;
+            if (sl < nmv && l < NP) t.xt[sl * NP + l] = l < N ? OgGen::mv_operand(mv0 + sl, l, xbase, a.cvec) : 0.0;
+        }
+#pragma unroll
+    for (int u = 0; u < ST_D; ++u) {
+        const int i = tid + u * SWEEP_THREADS;
+        if (i < KS * 64) t.dpanel[i] = st_d[u];
+    }
+}
+
 __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, double* lds) {
     __shared__ int s_flag;              // base products of the tile are in LDS
     FZ_TRACE_DECL(1);
@@ -996,7 +1059,6 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
     const ogt_int8 grp = OGT_LGRP[b];
     const int first_j = grp.v[0], cnt = grp.v[1], y0_first = grp.v[2], nt = grp.v[3];
     const int mv0 = grp.v[4], nmv = grp.v[5], N = grp.v[6], phase = grp.v[7];
-    const int KS = (N + 3) >> 2, NP = KS << 2;
     const bool has_tile = nmv > 0;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1014,154 +1076,204 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
     const bool has_item = item_on && coli.x + wave < coli.y;
     if (has_item) item = OGT_ELEM[coli.x + wave];
 
-    double* dpanel = lds;
-    double* xt = dpanel + (FZ_NP / 4) * 64;                        // [state][NP] operands
-    double* yb = xt + OgGen::MAX_NMV * FZ_NP;                      // [state][N] base products (one tile of it)
-    const XCol xbase{a.x0, -1, 0.0};
-    // the service wavefront's inputs (D^T panel of the tile, the group's operands) are requested by everybody
-    // and parked in LDS before the workgroup's only barrier
-    constexpr int ST_D = (FZ_NP / 4 * 64 + SWEEP_THREADS - 1) / SWEEP_THREADS;
-    constexpr int ST_S = (OgGen::MAX_NMV + SWEEP_WAVES - 1) / SWEEP_WAVES, ST_L = (FZ_NP + 63) / 64;
-    const bool staging = has_tile && !(OGK_FZ & 4);
+    const FzTile t = fz_tile_lds(lds);
     if (tid == 0) s_flag = 0;
-    if (staging) {
-        double st_d[ST_D];
-        const double* src = a.dfrag + a.dfrag_off[phase] + (long)nt * KS * 64;
-#pragma unroll
-        for (int u = 0; u < ST_D; ++u) {
-            const int i = tid + u * SWEEP_THREADS;
-            st_d[u] = i < KS * 64 ? src[i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < ST_S; ++u)                             // a slot per wavefront: no divergence
-#pragma unroll
-            for (int q = 0; q < ST_L; ++q) {
-                const int sl = wave + u * SWEEP_WAVES, l = lane + q * 64;
-                if (sl < nmv && l < NP) xt[sl * NP + l] = l < N ? OgGen::mv_operand(mv0 + sl, l, xbase, a.cvec) : 0.0;
-            }
-#pragma unroll
-        for (int u = 0; u < ST_D; ++u) {
-            const int i = tid + u * SWEEP_THREADS;
-            if (i < KS * 64) dpanel[i] = st_d[u];
-        }
-    }
+    if (has_tile && !(OGK_FZ & 4)) fz_stage_tile(a, t, nt, mv0, nmv, N, phase);
     lds_barrier();            // (only LDS data crosses it: global loads in flight stay in flight)
     FZ_STAMP(1);
     if (service) {
         if (has_tile && !(OGK_FZ & 2))
-            base_products_tile(dpanel, N, nt, nmv, xt, NP,
-                               [&](const int st, const int k, const double v) { yb[st * N + k] = v; });
+            base_products_tile(t.dpanel, N, nt, nmv, t.xt, ((N + 3) >> 2) << 2,
+                               [&](const int st, const int k, const double v) { t.yb[st * N + k] = v; });
         FZ_STAMP(2);
         if (lane == 0) lds_flag_raise(&s_flag, 1);
         FZ_TRACE_OUT(a);
         return;
     }
     if (has_item && !(OGK_FZ & 2048)) {
-        lds_flag_wait(&s_flag);
-        FZ_STAMP(3);
         const double xj = xb + hh;
         const double dx = xj - xb;
         double* jrow = a.jt + (long)(ji - a.col_lo) * OgGen::M;
+        const XCol xa{a.x0, base_role ? -1 : ji, xj};
+        // The long part of an item - its dynamics term, or the whole value of a row item - does not depend on
+        // the base products: the first FZ_ROUNDS items of every column are evaluated while the service
+        // wavefront is still in its chain; only the subtraction from the product waits for the flag.
+        double tv[FZ_ROUNDS];
+        int trow[FZ_ROUNDS], tyo[FZ_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < FZ_ROUNDS; ++r) {
+            const int e = coli.x + wave + r * FZ_ITEM_WAVES;
+            tv[r] = 0.0, trow[r] = 0, tyo[r] = -1;
+            if (e < coli.y) {
+                const int4 it = r == 0 ? item : OGT_ELEM[e];
+                tv[r] = OgGen::item_tail(it.x, it.y, it.z, xa, a.cvec, &trow[r], &tyo[r]);
+            }
+        }
+        lds_flag_wait(&s_flag);
+        FZ_STAMP(3);
+#pragma unroll
+        for (int r = 0; r < FZ_ROUNDS; ++r) {
+            const double v = tyo[r] >= 0 ? t.yb[tyo[r] - y0_first] - tv[r] : tv[r];
+            const double v0 = __shfl_down(v, FZ_COLS);
+            if (!base_role && coli.x + wave + r * FZ_ITEM_WAVES < coli.y) jrow[trow[r]] = (v - v0) / dx;
+        }
         // item_value indexes y0 by slot offset + node; the accessor turns that into the LDS tile
-        const XColL xa{a.x0, base_role ? -1 : ji, xj, a.y0 + y0_first, yb};
-        eval_item_paired(a, item, xa, base_role, dx, jrow);
-        for (int e = coli.x + wave + FZ_ITEM_WAVES; e < coli.y; e += FZ_ITEM_WAVES)
-            eval_item_paired(a, OGT_ELEM[e], xa, base_role, dx, jrow);
+        const XColL xl{a.x0, base_role ? -1 : ji, xj, a.y0 + y0_first, t.yb};
+        for (int e = coli.x + wave + FZ_ROUNDS * FZ_ITEM_WAVES; e < coli.y; e += FZ_ITEM_WAVES)
+            eval_item_paired(a, OGT_ELEM[e], xl, base_role, dx, jrow);
     }
     FZ_STAMP(4);
     FZ_TRACE_OUT(a);
 }
 
-// One part of a heavy column: HPART_PAIRS of its items (thread t < HPART_PAIRS at x0 + h e_j, thread
-// t + HPART_PAIRS the same item at x0) and the base products of the node tiles those items read - operands
-// and products in a private global scratch (written and read by this workgroup only: coherent through the
-// CU's own cache path after a workgroup barrier).
-__device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx, double* vbase) {
+// One part of a heavy column (a phase's final time, say: it moves every defect row of the phase): the column's
+// items in ONE (defect group, node tile), staged exactly like a light workgroup, or its row items (no tile).
+// A slot = up to 32 items with the same code (one output over the tile's nodes / one row group): lanes 0..31 at
+// x0 + h e_j, lanes 32..63 the same items at x0, one wavefront per slot.
+__device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx, double* lds) {
+    __shared__ int s_flag;
     FZ_TRACE_DECL(2);
-    const ogt_int8 rec = OGT_HPART[pidx];      // {column, items begin, end, block list begin, end, -, -}
+    const ogt_int8 rec = OGT_HPART[pidx];      // {column, slots begin, end, y0 offset, node tile, first slot, slots, nodes | phase << 20}
     const int j = rec.v[0];
     if (j < a.col_lo || j >= a.col_hi) return;
+    const int y0_first = rec.v[3], nt = rec.v[4], mv0 = rec.v[5], nmv = rec.v[6];
+    const int N = rec.v[7] & 0xfffff, phase = rec.v[7] >> 20;
+    const bool has_tile = nmv > 0;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const bool service = wave == SWEEP_WAVES - 1;
     const double xb = a.x0[j];
-    const double xj = xb + a.h[j];
-    const double dx = xj - xb;
-    double* hx = a.hscr + (long)pidx * 2 * OgGen::N_Y0;            // operands of the collocation slots (as y0 is laid out)
-    double* hy = hx + OgGen::N_Y0;                                 // their base products
-    const XCol xbase{a.x0, -1, 0.0};
-    const int e_first = rec.v[1] + (tid & (HPART_PAIRS - 1));
-    const int4 it_first = OGT_ELEM[e_first < rec.v[2] ? e_first : rec.v[1]];   // requested now, used after the chains
-    for (int i = rec.v[3]; i < rec.v[4]; ++i) {
-        const ogt_int8 blk = OGT_HPART_EB[i];      // {first slot, slots, nodes, phase, y0 offset, node tile, first of its group}
-        if (!blk.v[6]) continue;                                   // this group's operands are staged already
-        const int N = blk.v[2];
-        for (int s = wave; s < blk.v[1]; s += SWEEP_WAVES)         // slots of a group are consecutive in the scratch
-            for (int l = lane; l < N; l += 64)
-                hx[blk.v[4] + s * N + l] = OgGen::mv_operand(blk.v[0] + s, l, xbase, a.cvec);
+    const double hh = a.h[j];
+    const int il = lane & 31;
+    const bool base_role = lane >= 32;
+    int4 slot = make_int4(0, 0, 0, 0), item = make_int4(0, 0, 0, 0);
+    const bool has_slot = !service && rec.v[1] + wave < rec.v[2];
+    if (has_slot) {
+        slot = OGT_HSLOT[rec.v[1] + wave];
+        item = OGT_HELEM[slot.x + (il < slot.y ? il : 0)];
     }
-    __syncthreads();
+    const FzTile t = fz_tile_lds(lds);
+    if (tid == 0) s_flag = 0;
+    if (has_tile) fz_stage_tile(a, t, nt, mv0, nmv, N, phase);
+    lds_barrier();
     FZ_STAMP(1);
-    for (int i = rec.v[3] + wave; i < rec.v[4]; i += SWEEP_WAVES) {
-        const ogt_int8 blk = OGT_HPART_EB[i];
-        const int N = blk.v[2], KS = (N + 3) >> 2, nt = blk.v[5], off = blk.v[4];
-        // row s of the A operand starts N further on
-        base_products_tile(a.dfrag + a.dfrag_off[blk.v[3]] + (long)nt * KS * 64, N, nt, blk.v[1], hx + off, N,
-                           [&](const int st, const int k, const double v) { hy[off + st * N + k] = v; });
+    if (service) {
+        if (has_tile)
+            base_products_tile(t.dpanel, N, nt, nmv, t.xt, ((N + 3) >> 2) << 2,
+                               [&](const int st, const int k, const double v) { t.yb[st * N + k] = v; });
+        FZ_STAMP(2);
+        if (lane == 0) lds_flag_raise(&s_flag, 1);
+        FZ_TRACE_OUT(a);
+        return;
     }
-    __syncthreads();
-    FZ_STAMP(2);
-    double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-    const bool base_role = tid >= HPART_PAIRS;
-    const XCol xa{a.x0, base_role ? -1 : j, xj};
-    for (int e0 = rec.v[1]; e0 < rec.v[2]; e0 += HPART_PAIRS) {
-        const int e = e0 + (tid & (HPART_PAIRS - 1));
-        const bool on = e < rec.v[2];
-        int row = 0;
-        double v = 0.0;
-        if (on) {
-            const int4 it = e0 == rec.v[1] ? it_first : OGT_ELEM[e];
-            v = OgGen::item_value(it.x, it.y, it.z, xa, hy, a.cvec, &row);
-            if (base_role) vbase[tid - HPART_PAIRS] = v;
+    if (has_slot) {
+        const double xj = xb + hh;
+        const double dx = xj - xb;
+        double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+        const XCol xa{a.x0, base_role ? -1 : j, xj};
+        // as in the light workgroups: the items' long chains run while the service wavefront is in its own
+        for (int s0 = rec.v[1] + wave; s0 < rec.v[2]; s0 += FZ_ROUNDS * FZ_ITEM_WAVES) {
+            double tv[FZ_ROUNDS];
+            int trow[FZ_ROUNDS], tyo[FZ_ROUNDS], cnt[FZ_ROUNDS];
+#pragma unroll
+            for (int r = 0; r < FZ_ROUNDS; ++r) {
+                const int s = s0 + r * FZ_ITEM_WAVES;
+                tv[r] = 0.0, trow[r] = 0, tyo[r] = -1, cnt[r] = 0;
+                if (s < rec.v[2]) {
+                    const int4 sl = (r == 0 && s0 == rec.v[1] + wave) ? slot : OGT_HSLOT[s];
+                    const int4 it = (r == 0 && s0 == rec.v[1] + wave) ? item : OGT_HELEM[sl.x + (il < sl.y ? il : 0)];
+                    cnt[r] = sl.y;
+                    tv[r] = OgGen::item_tail(it.x, it.y, it.z, xa, a.cvec, &trow[r], &tyo[r]);
+                }
+            }
+            if (s0 == rec.v[1] + wave) {
+                lds_flag_wait(&s_flag);
+                FZ_STAMP(3);
+            }
+#pragma unroll
+            for (int r = 0; r < FZ_ROUNDS; ++r) {
+                const double v = tyo[r] >= 0 ? t.yb[tyo[r] - y0_first] - tv[r] : tv[r];
+                const double v0 = __shfl_down(v, 32);
+                if (!base_role && il < cnt[r]) jrow[trow[r]] = (v - v0) / dx;
+            }
         }
-        lds_barrier();
-        if (on && !base_role) jrow[row] = (v - vbase[tid]) / dx;
-        if (e0 + HPART_PAIRS < rec.v[2]) lds_barrier();            // vbase is reused by the next round
     }
     FZ_STAMP(4);
     FZ_TRACE_OUT(a);
 }
 
-__device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, double* xt) {
+// MFMA tiles of the fused launch.  Workgroup = (collocation slot, node tile, up to SWEEP_WAVES - 1 column
+// tiles): wavefront w < nct owns the (16 perturbed columns) x (16 nodes) tile of column tile ct0 + w - one
+// accumulator, its MFMA chain and, on the diagonal tile only, the perturbed dynamics term.  What every column
+// tile of the node tile shares - the base product and the base dynamics term of the 16 nodes - is computed
+// ONCE per workgroup by the last wavefront (and the one before it when it is free), in parallel, and handed
+// over through LDS; the column wavefronts meet it only at their epilogue.
+__device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, double* lds) {
+    __shared__ int s_flags[2];          // [0] base products of the node tile, [1] base dynamics terms
     FZ_TRACE_DECL(3);
-    const int4 tile = OGT_TILE[bx];                    // {slot, tile group, node tile}
-    const int slot = tile.x, nt = tile.z;
+    const int4 tile = OGT_FTILE[bx];                   // {slot, first column tile, node tile, column tiles}
+    const int slot = tile.x, ct0 = tile.y, nt = tile.z, nct = tile.w;
     const ogt_int8 rec = OGT_SLOT[slot];
     const int N = rec.v[0], leaf = rec.v[2], row0 = rec.v[3];
     const bool diag = rec.v[6] & 1, generic = rec.v[6] & 2;
     const int dep0 = rec.v[7] >> 12, ndep = rec.v[7] & 0xfff;
     const int KS = (N + 3) >> 2;
     const int tid = (int)threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
-    // the slot's operand vector once per workgroup (eight column tiles share it)
+    const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4, kk = lane & 15;
+    double* xt = lds;                                   // [NP] the slot's operand vector
+    double* yb = lds + FZ_NP;                           // [16] base products of the node tile
+    double* tb = yb + 16;                               // [16] base dynamics terms
     const XCol xbase{a.x0, -1, 0.0};
     for (int l = tid; l < KS * 4; l += SWEEP_THREADS)
         xt[l] = l < N ? OgGen::mv_operand(slot, l, xbase, a.cvec) : 0.0;
-    __syncthreads();
-    FZ_STAMP(1);
-    const int l0 = (tile.y * SWEEP_WAVES + wave) * 16;  // first slice offset of this wave's tile
-    if (l0 >= N || leaf + l0 >= a.col_hi || leaf + l0 + 16 <= a.col_lo) return;
-    const int k = nt * 16 + (lane & 15);                // output node of this lane
-    const int la = l0 + (lane & 15);                    // A-operand row of this lane
-
+    if (tid < 2) s_flags[tid] = 0;
+    const int k = nt * 16 + kk;                         // output node of this lane
+    const bool k_on = k < N;
     const double* bsrc = a.dfrag + a.dfrag_off[rec.v[5]] + (long)nt * KS * 64 + lane;
     constexpr int CH = 10;                              // k-steps per chunk
+    const int prod_wave = SWEEP_WAVES - 1;
+    const int term_wave = nct < SWEEP_WAVES - 1 ? SWEEP_WAVES - 2 : SWEEP_WAVES - 1;
+    const bool col_wave = wave < nct;
     double bv[CH];
+    if (col_wave || wave == prod_wave) {
 #pragma unroll
-    for (int u = 0; u < CH; ++u) bv[u] = (u < KS) ? bsrc[u * 64] : 0.0;
+        for (int u = 0; u < CH; ++u) bv[u] = (u < KS) ? bsrc[u * 64] : 0.0;
+    }
+    lds_barrier();
+    FZ_STAMP(1);
+    if (!col_wave) {
+        if (wave == term_wave && lk == 0) tb[kk] = k_on ? OgGen::tail_one(slot, k, xbase, a.cvec) : 0.0;
+        if (wave == term_wave && lane == 0) lds_flag_raise(&s_flags[1], 1);
+        if (wave == prod_wave) {
+            v4f64 accb = {0.0, 0.0, 0.0, 0.0};
+            for (int ks0 = 0; ks0 < KS; ks0 += CH) {
+                double bn[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int ks = ks0 + CH + u;
+                    bn[u] = (ks < KS) ? bsrc[ks * 64] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int ks = ks0 + u;
+                    if (ks < KS) accb = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[ks * 4 + lk], bv[u], accb, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) bv[u] = bn[u];
+            }
+            if (lk == 0) yb[kk] = accb[0];              // every row of accb holds the base product of node k
+            FZ_STAMP(2);
+            if (lane == 0) lds_flag_raise(&s_flags[0], 1);
+        }
+        FZ_TRACE_OUT(a);
+        return;
+    }
+    const int l0 = (ct0 + wave) * 16;                   // first slice offset of this wave's tile
+    if (l0 >= N || leaf + l0 >= a.col_hi || leaf + l0 + 16 <= a.col_lo) return;
+    const int la = l0 + kk;                             // A-operand row of this lane
     const bool a_on = la < N;
     const double xa_b = a.x0[a_on ? leaf + la : leaf];
     const double xa_h = a.h[a_on ? leaf + la : leaf];
-    const bool k_on = k < N;
     const int row = row0 + (k_on ? k : 0);
     double xbv[4], hv[4];
 #pragma unroll
@@ -1171,9 +1283,8 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
         xbv[reg] = a.x0[jj];
         hv[reg] = a.h[jj];
     }
-    // dynamics terms (base, and perturbed on the diagonal): their chains run while the loads are in flight
-    const double t_base = k_on ? OgGen::tail_one(slot, k, xbase, a.cvec) : 0.0;
-    double t_diag = t_base;
+    // the perturbed dynamics term on the diagonal: its chain runs while the loads are in flight
+    double t_diag = 0.0;
     bool have_diag = false;
     {
         const int lc = k;                                // column whose perturbed node is k
@@ -1192,8 +1303,7 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
         const XCol xa{a.x0, leaf + la, xa_b + xa_h};
         hit_v = OgGen::mv_operand(slot, la, xa, a.cvec);
     }
-    // acc: 16 perturbed columns x 16 nodes; accb: the unperturbed operand in every row (the base product)
-    v4f64 acc = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0};
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     for (int ks0 = 0; ks0 < KS; ks0 += CH) {
         double bn[CH];
 #pragma unroll
@@ -1205,18 +1315,20 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
         for (int u = 0; u < CH; ++u) {
             const int ks = ks0 + u;
             if (ks < KS) {
-                const double base_op = xt[ks * 4 + lk];
-                const double aop = (ks * 4 + lk == la) ? hit_v : base_op;
+                const double aop = (ks * 4 + lk == la) ? hit_v : xt[ks * 4 + lk];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bv[u], acc, 0, 0, 0);
-                accb = __builtin_amdgcn_mfma_f64_16x16x4f64(base_op, bv[u], accb, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) bv[u] = bn[u];
     }
     FZ_STAMP(2);
+    lds_flag_wait(&s_flags[1]);
+    lds_flag_wait(&s_flags[0]);
+    FZ_STAMP(3);
     if (!k_on) return;
-    const double f_base = accb[0] - t_base;             // every row of accb holds the base product of node k
+    const double t_base = tb[kk];
+    const double f_base = yb[kk] - t_base;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int lc = l0 + lk + 4 * reg;
@@ -1269,8 +1381,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_fused(const ogk_args a, con
     } else if (id < n_light + OGT_N_HPART) {
         if (!(OGK_FZ & 32)) fz_heavy_part(a, id - n_light, lds);
     } else {
-        if (OGK_FZ & 64) tile_body(a, id - n_light - OGT_N_HPART);
-        else fz_tile_body(a, id - n_light - OGT_N_HPART, lds);
+        fz_tile_body(a, id - n_light - OGT_N_HPART, lds);
     }
 }
 
@@ -1316,7 +1427,6 @@ size_t sweep_lds_bytes() { return (size_t)LIGHT_COLS * ROW_WORDS * sizeof(unsign
 extern "C" int ogk_get_info(ogk_info* out) {
     out->abi = OGK_ABI;
     out->n_eval_blocks = defect_blocks() + (OGT_N_ROWWAVES + SWEEP_WAVES - 1) / SWEEP_WAVES;
-    out->n_heavy = OGT_N_HPART;
     out->n = OgGen::N_VAR;
     out->m = OgGen::M;
     out->m_eq = OgGen::M_EQ;
@@ -1357,9 +1467,8 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         while (glo < ghi && OGH_LGRP_J[glo + 1] <= args->col_lo) ++glo;
         while (ghi > glo && OGH_LGRP_J[ghi - 1] >= args->col_hi) --ghi;
         size_t lds_bytes = defect_lds_bytes() > FZ_LDS_BYTES ? defect_lds_bytes() : FZ_LDS_BYTES;
-        const size_t other_lds = (size_t)ROW_WORDS * sizeof(unsigned) > HPART_PAIRS * sizeof(double)
-                                     ? (size_t)ROW_WORDS * sizeof(unsigned) : HPART_PAIRS * sizeof(double);
-        if (other_lds > lds_bytes) lds_bytes = other_lds;
+        const size_t fill_lds = (size_t)ROW_WORDS * sizeof(unsigned);      // finish_eval's bitmap of one row
+        if (fill_lds > lds_bytes) lds_bytes = fill_lds;
         if (!args->jt_sparse || lds_bytes > 64 * 1024 || ndef + eval_row_blocks == 0) {
             // the one-launch form writes the non-zeros only: it needs a registered (persistent-zero) output
             // buffer (og_jt_register_dev).  Also when a tile's panel and operands do not fit the default LDS
@@ -1367,7 +1476,7 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
             const int rc0 = ogk_launch(args, 0, stream_);
             return rc0 ? rc0 : ogk_launch(args, 1, stream_);
         }
-        hipLaunchKernelGGL(ogk_fused, dim3(ndef + eval_row_blocks + OGT_N_TILES + OGT_N_HPART + (ghi - glo)),
+        hipLaunchKernelGGL(ogk_fused, dim3(ndef + eval_row_blocks + OGT_N_FTILES + OGT_N_HPART + (ghi - glo)),
                            dim3(SWEEP_THREADS), lds_bytes, stream, *args, ndef, ndef + eval_row_blocks, glo, ghi - glo);
         return (int)hipGetLastError();
     }

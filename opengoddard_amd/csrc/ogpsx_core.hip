@@ -79,7 +79,6 @@ struct og_problem_s {
     double* d_xop = nullptr;
     double* d_t0 = nullptr;
     double* d_z = nullptr;
-    double* d_hscr = nullptr;           // fused launch: private base products of the heavy-column workgroups
     int* d_flags = nullptr;             // two non-finite-row counters used alternately, then the ticket of the
     int flag_slot = 0;                  // fused launch (evaluation workgroups that have finished, ever)
     int n_eval_blocks = 0;
@@ -122,7 +121,6 @@ void fill_args(og_problem_s* p, ogk_args* a, const double* x, const double* h, d
     a->nonfinite_next = p->d_flags + (p->flag_slot ^ 1);
     a->ready = reinterpret_cast<unsigned*>(p->d_flags + 2);
     a->trace = p->d_trace;
-    a->hscr = p->d_hscr;
     a->jt = jt;
     a->col_lo = lo;
     a->col_hi = hi;
@@ -335,9 +333,6 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMalloc(&p->d_xop, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_t0, sizeof(double) * (size_t)p->m);
     if (e == hipSuccess) e = hipMalloc(&p->d_z, sizeof(double) * (size_t)p->m);
-    if (e == hipSuccess)
-        e = hipMalloc(&p->d_hscr, sizeof(double) * 2 * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1) *
-                                      (size_t)(info.n_heavy > 0 ? info.n_heavy : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_flags, 4 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(int));
     if (e == hipSuccess && getenv("OGPSX_TRACE")) {
@@ -382,7 +377,6 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_flags);
     hipFree(p->d_state);
     hipFree(p->d_trace);
-    hipFree(p->d_hscr);
     if (p->module) dlclose(p->module);
     delete p;
 }

@@ -32,12 +32,14 @@ LIGHT_COLS = 4                   # columns per workgroup otherwise (csrc/ogk_ker
 
 
 def fused_cols(n):
-    """Columns per light workgroup of the fused launch.  Measured (bench step, MI355X): 8 beats 4 once there
-    are enough columns to keep every CU busy with one workgroup (C3 14.6 -> 13.6 us, C4 30.6 -> 28.9 us: half as
-    many light workgroups share a CU with an MFMA-tile workgroup), 4 beats 8 on small problems (C2 5.6 vs 6.6
-    us), 16 loses everywhere (C3 18.8 us).  ``OG_FUSED_COLS`` overrides (timing experiments)."""
+    """Columns per light workgroup of the fused launch: a run of neighbouring columns whose defect items lie in
+    one (defect group, 16-node tile), i.e. at most the 16 nodes of one variable's tile.  Every light workgroup
+    recomputes the base products of its tile, so fewer, wider workgroups mean fewer redundant MFMA chains.
+    Measured with persistent-zero output (bench step, MI355X, 4 / 8 / 16 columns): C3 7.8 / 7.3 / 6.9 us,
+    C4 15.8 / 13.8 / 12.4 us, C5 32.8 / 24.3 / 18.7 us.  (With the zero fill of round 1 in the same workgroups
+    8 was the optimum and 16 lost.)  ``OG_FUSED_COLS`` overrides (timing experiments)."""
     env = os.environ.get("OG_FUSED_COLS")
-    return int(env) if env else (8 if n >= 1024 else 4)
+    return int(env) if env else 16
 
 
 MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "1"))

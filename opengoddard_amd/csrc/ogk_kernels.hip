@@ -857,6 +857,15 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx) {
 #ifndef OGK_FZ
 #define OGK_FZ 0
 #endif
+// the wavefront whose MFMA chain a whole workgroup waits for asks for issue priority over its neighbours
+#ifndef OGK_PRIO
+#define OGK_PRIO 1
+#endif
+#if OGK_PRIO
+#define OGK_SERVICE_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define OGK_SERVICE_PRIO() do { } while (0)
+#endif
 
 // barrier that orders LDS traffic only: the global stores of the fill keep draining underneath
 // (__syncthreads() would wait for them)
@@ -899,10 +908,11 @@ __device__ __forceinline__ void finish_eval(const ogk_args& a, const unsigned n_
         const unsigned t = __hip_atomic_fetch_add(a.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int last = 0;
         if (t + 1u == n_eval) {
-            // the counts of non-finite rows were performed before their workgroups' tickets, at the memory side
+            // the counts of non-finite rows were performed before their workgroups' tickets, at the memory side.
+            // Two independent loads, one round trip; the ticket's reset needs no answer.
             const int bad = __hip_atomic_load(a.nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned st = __hip_atomic_load(a.jt_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (bad != 0) jt_mark_nan_fill(a);
             last = (bad != 0 || st == a.jt_gen - 1u) ? 1 : 0;
         }
@@ -1082,6 +1092,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
     lds_barrier();            // (only LDS data crosses it: global loads in flight stay in flight)
     FZ_STAMP(1);
     if (service) {
+        OGK_SERVICE_PRIO();
         if (has_tile && !(OGK_FZ & 2))
             base_products_tile(t.dpanel, N, nt, nmv, t.xt, ((N + 3) >> 2) << 2,
                                [&](const int st, const int k, const double v) { t.yb[st * N + k] = v; });
@@ -1158,6 +1169,7 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
     lds_barrier();
     FZ_STAMP(1);
     if (service) {
+        OGK_SERVICE_PRIO();
         if (has_tile)
             base_products_tile(t.dpanel, N, nt, nmv, t.xt, ((N + 3) >> 2) << 2,
                                [&](const int st, const int k, const double v) { t.yb[st * N + k] = v; });
@@ -1245,6 +1257,7 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
         if (wave == term_wave && lk == 0) tb[kk] = k_on ? OgGen::tail_one(slot, k, xbase, a.cvec) : 0.0;
         if (wave == term_wave && lane == 0) lds_flag_raise(&s_flags[1], 1);
         if (wave == prod_wave) {
+            OGK_SERVICE_PRIO();
             v4f64 accb = {0.0, 0.0, 0.0, 0.0};
             for (int ks0 = 0; ks0 < KS; ks0 += CH) {
                 double bn[CH];

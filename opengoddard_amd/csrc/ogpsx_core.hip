@@ -343,10 +343,11 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMemset(p->d_state, 0xff, (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
     p->n_eval_blocks = info.n_eval_blocks;
     const char* mode_env = getenv("OGPSX_SWEEP");
-    // one launch while the kernel boundary is a noticeable part of the step.  Measured (bench step, fused /
-    // split, us): 1 MB 5.7 / 8.6, 5 MB 11.1 / 13.8, 19 MB (C3) 13.6 / 16.3, 43 MB 20.3 / 24.1, 48 MB (C4) 29.2 /
-    // 28.5, 77 MB 26.6 / 28.5, 171 MB 41.5 / 38.5, 304 MB (C5) 68.5 / 66.8
-    p->sweep_mode = (double)p->n * (double)p->m * sizeof(double) <= 100.0e6 ? 5 : 1;
+    // One launch (evaluation + structured sweep) whenever the output is a registered persistent-zero buffer;
+    // measured against the two-launch form with such a buffer (bench step, us, one launch / two): C2 4.8 / 8.1,
+    // C3 7.6 / 12.4, C4 13.9 / 22.6, C5 23.9 / 33.0.  An unregistered buffer always takes two launches (the
+    // module decides: the one-launch form never fills).
+    p->sweep_mode = 5;
     if (mode_env && std::string(mode_env) == "dense") p->sweep_mode = 2, p->exact_mode = 3;
     if (mode_env && std::string(mode_env) == "split") p->sweep_mode = 1;
     if (mode_env && std::string(mode_env) == "fused") p->sweep_mode = 5;

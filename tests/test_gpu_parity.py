@@ -164,17 +164,38 @@ def test_structured_sweep_equals_dense_sweep(name, golden, monkeypatch):
     assert (JT_s != 0).mean() < 0.2
 
 
-def test_launch_form_is_chosen_by_size(monkeypatch):
-    """og_fd_sweep runs as one fused launch up to 100 MB of Jacobian and as two launches above
-    (include/ogpsx.h og_sweep_mode); OGPSX_SWEEP overrides."""
+def test_launch_form(monkeypatch):
+    """og_fd_sweep(_dev) runs evaluation + structured sweep as ONE launch at every size when the output is a
+    registered persistent-zero buffer (the host-pointer entry points register their own); an unregistered
+    buffer gets the two-launch form from the same handle, with identical results (include/ogpsx.h
+    og_sweep_mode); OGPSX_SWEEP overrides."""
+    import torch
     from opengoddard_amd.engine import HipEngine
+    from oracle import np_path
     monkeypatch.delenv("OGPSX_SWEEP", raising=False)
-    for name, expect in (("goddard", "fused"), ("polar_tsto", "fused"), ("low_thrust", "fused"), ("launch4", "split")):
+    for name in ("goddard", "polar_tsto", "launch4"):
         prob, obj = problems.build(name)
         eng = HipEngine(prob, obj)
-        assert (eng.n * eng.m * 8 <= 100e6) == (expect == "fused")
-        assert eng.sweep_mode == expect
+        assert eng.sweep_mode == "fused"
+        if name != "launch4":
+            lb, ub = np_path.bounds_arrays(prob)
+            x = np.clip(prob.p, lb, ub)
+            h = _native.fd_step(x, lb, ub)
+            F0, JT = eng.sweep_stacked(x, h)                      # registered staging buffer: one launch
+            dev = torch.device("cuda", 0)
+            d_x, d_h = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+            d_F = torch.empty(eng.m, dtype=torch.float64, device=dev)
+            d_JT = torch.full((eng.n, eng.m), 3.0, dtype=torch.float64, device=dev)      # unregistered: two launches
+            eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), 0, eng.n, d_JT.data_ptr(), d_F.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_JT.cpu().numpy(), JT) and np.array_equal(d_F.cpu().numpy(), F0)
         eng.close()
+    monkeypatch.setenv("OGPSX_SWEEP", "split")
+    prob, obj = problems.build("goddard")
+    eng = HipEngine(prob, obj)
+    assert eng.sweep_mode == "split"
+    eng.close()
 
 
 @pytest.mark.parametrize("name", ["polar_tsto", "low_thrust", "launch4"])

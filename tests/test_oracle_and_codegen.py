@@ -217,8 +217,10 @@ def _table(src, name):
 def test_fused_launch_work_lists_partition_the_sweep(name):
     """The work lists of the fused launch (codegen._sweep_records): every column is either heavy or in exactly
     one light group; a light group is a run of neighbouring columns whose defect items all lie in the group's
-    (defect group, 16-node tile); the parts of a heavy column take each of its items once, split the fill of
-    its row without gap or overlap, and list exactly the evaluation blocks their defect items read."""
+    (defect group, 16-node tile); the parts of a heavy column take each of its items exactly once, every part
+    holds the items of one (defect group, node tile) - or row items only - in slots of at most 32 items that share
+    their code; the MFMA tile workgroups cover every (slot, column tile, node tile) once with at most 7 column
+    tiles each."""
     import re
     from opengoddard_amd import codegen, problems
     prob, obj = problems.build(name)
@@ -226,7 +228,8 @@ def test_fused_launch_work_lists_partition_the_sweep(name):
     src = codegen.emit_header(P)
     col, elem = _table(src, "OGT_COL"), _table(src, "OGT_ELEM")
     lgrp, lrng = _table(src, "OGT_LGRP"), _table(src, "OGT_LRNG")
-    hpart, heb, evalblk = _table(src, "OGT_HPART"), _table(src, "OGT_HPART_EB"), _table(src, "OGT_EVALBLK")
+    hpart, hslot, helem = _table(src, "OGT_HPART"), _table(src, "OGT_HSLOT"), _table(src, "OGT_HELEM")
+    ftile, slots = _table(src, "OGT_FTILE"), _table(src, "OGT_SLOT")
     cols = int(re.search(r"OGT_LGRP_COLS = (\d+)", src).group(1))
     assert cols == codegen.fused_cols(P.n) and len(lrng) == len(lgrp) * cols
     heavy = {j for j in range(P.n) if col[j][3] & (1 << 30)}
@@ -243,23 +246,35 @@ def test_fused_launch_work_lists_partition_the_sweep(name):
                     assert nmv > 0 and P.groups[g].mv_slots[0] == mv0 and len(P.groups[g].mv_slots) == nmv
                     assert k >> 4 == nt and P.groups[g].length == N and P.groups[g].phase == phase
     assert set(owner) | heavy == set(range(P.n))
-    seen, fill = {}, {}
-    for j, e0, e1, b0, b1, r0, r1, idx in hpart:
-        assert j in heavy and 0 < e1 - e0 <= codegen.HPART_ITEMS
-        seen.setdefault(j, []).append((e0, e1))
-        fill.setdefault(j, []).append((r0, r1))
-        need = {(g, k >> 4) for g, o, k, row in elem[e0:e1] if P.groups[g].kind == "defect"}
-        listed = set()
-        for mv0, nmv, N, phase, y0off, nt, first, _ in heb[b0:b1]:
-            g = next(i for i, gr in enumerate(P.groups) if gr.kind == "defect" and gr.mv_slots[0] == mv0)
-            listed.add((g, nt))
-        assert listed == need
-        firsts = [r[6] for r in heb[b0:b1]]
-        assert sum(firsts) == len({r[0] for r in heb[b0:b1]})          # one staging pass per group
+    taken = {}
+    n_hpart = int(re.search(r"OGT_N_HPART = (\d+)", src).group(1))
+    for j, s0, s1, y0off, nt, mv0, nmv, packed in hpart[:n_hpart]:
+        assert j in heavy and s1 > s0
+        N, phase = packed & 0xfffff, packed >> 20
+        for e0, cnt, _, _ in hslot[s0:s1]:
+            assert 0 < cnt <= 32
+            items = helem[e0:e0 + cnt]
+            assert len({(g, o) for g, o, k, row in items}) == 1                  # one piece of code per slot
+            for g, o, k, row in items:
+                assert row == P.groups[g].outputs[o][0] + k
+                if nmv:
+                    gr = P.groups[g]
+                    assert gr.kind == "defect" and gr.mv_slots[0] == mv0 and len(gr.mv_slots) == nmv
+                    assert k >> 4 == nt and gr.length == N and gr.phase == phase and cnt <= 16
+                else:
+                    assert P.groups[g].kind != "defect"
+                taken.setdefault(j, []).append((g, o, k))
     for j in heavy:
-        spans = sorted(seen[j])
-        assert spans[0][0] == col[j][0] and spans[-1][1] == col[j][1]
-        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-        rows = sorted(fill[j])
-        assert rows[0][0] == 0 and rows[-1][1] == P.m and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
-    assert evalblk                                                       # (used by the heavy parts' lists)
+        want = [tuple(r[:3]) for r in elem[col[j][0]:col[j][1]]]
+        assert sorted(taken[j]) == sorted(want) and len(set(taken[j])) == len(taken[j])
+    covered = set()
+    for si, c0, nt, nct in ftile:
+        assert 1 <= nct <= 7
+        for c in range(c0, c0 + nct):
+            assert (si, c, nt) not in covered
+            covered.add((si, c, nt))
+    want = set()
+    for si, rec in enumerate(slots[:len(P.mv)]):
+        t16 = (rec[0] + 15) // 16
+        want |= {(si, c, nt) for c in range(t16) for nt in range(t16)}
+    assert covered == want

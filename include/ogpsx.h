@@ -120,6 +120,73 @@ int og_fd_columns_dev(og_handle h, const double* d_x, const double* d_hstep,
 int og_jt_register_dev(og_handle h, double* d_JT, int32_t col_lo, int32_t col_hi, void* hip_stream);
 int og_jt_unregister_dev(og_handle h, double* d_JT);
 
+/* The same for a host matrix handed to og_fd_sweep / og_jacobian_exact: og_jt_register_host zero-fills JT
+ * ((col_hi-col_lo)*m doubles) and later calls with exactly (JT, col_lo, col_hi) transfer only the packed
+ * non-zeros (plus F and the count of non-finite rows, one pinned copy) and scatter them on the host; a sweep
+ * with non-finite rows transfers the dense block, and the next call re-zeroes the matrix first.  Contract as
+ * above: the caller only reads JT between calls.  This is what Problem.solve uses: SciPy's SLSQP copies the
+ * Jacobian it is handed (scipy:_slsqp_py.py:490-511), so one persistent matrix serves every major iteration. */
+int og_jt_register_host(og_handle h, double* JT, int32_t col_lo, int32_t col_hi);
+int og_jt_unregister_host(og_handle h, double* JT);
+
+/* ---- static pattern and packed non-zeros ---------------------------------------------------------
+ * Which entries of J_T can be non-zero is fixed by the traced callbacks: column j reads the collocation
+ * block its state slice owns (N consecutive defect rows) and a list of row items.  og_pattern returns that
+ * pattern for the columns [col_lo, col_hi) as CSR over columns: *nnz entries, indptr[col_hi-col_lo+1]
+ * (relative to the block), rows[*nnz]; any output pointer may be NULL.  og_pack_dev gathers exactly those
+ * entries of a dense block (d_JT: (col_hi-col_lo) x m) into d_vals (*nnz doubles, pattern order);
+ * og_unpack_dev scatters them back into a dense block whose other entries it leaves alone.  No reference
+ * counterpart: the reference's Jacobian is dense (scipy:_numdiff.py:587). */
+int og_pattern(og_handle h, int32_t col_lo, int32_t col_hi, int64_t* nnz, int64_t* indptr, int32_t* rows);
+int og_pack_dev(og_handle h, const double* d_JT, int32_t col_lo, int32_t col_hi, double* d_vals, void* hip_stream);
+int og_unpack_dev(og_handle h, const double* d_vals, int32_t col_lo, int32_t col_hi, double* d_JT, void* hip_stream);
+
+/* ---- column sharding across GPUs ------------------------------------------
+ * The n forward-difference columns are independent given x (scipy:_numdiff.py:592-620 has no cross-iteration
+ * dependency): rank r of `world` sweeps the block [r*B, min(n, (r+1)*B)), B = ceil(n/world), into ITS rows of
+ * a full n x m replica that was zeroed once (register the block: og_jt_register_dev(h, d_JT_full + r*B*m,
+ * r*B, ...)), and the ranks exchange only the packed non-zeros: og_shard_plan fixes the layout (*block_vals =
+ * doubles per rank's message, padded to the largest block so that one all-gather of equal messages does it);
+ * og_shard_pack_dev gathers this rank's non-zeros into d_send (*block_vals doubles); after the all-gather
+ * (RCCL ncclAllGather / torch.distributed.all_gather_into_tensor; world * *block_vals doubles in d_recv)
+ * og_shard_unpack_dev scatters every other rank's non-zeros into the replica.  When F(x) has non-finite rows,
+ * or had in the previous step, the rows of the other ranks are filled from this rank's own F(x) - F(x)
+ * first (every rank evaluates the same F(x)), so the replica equals the single-GPU result in that case too.
+ * Call order per step on one stream: og_fd_sweep_dev (own block), og_shard_pack_dev, all-gather,
+ * og_shard_unpack_dev.  Results are bitwise independent of `world`. */
+int og_shard_plan(og_handle h, int32_t world, int32_t* block_cols, int64_t* block_vals);
+int og_shard_pack_dev(og_handle h, int32_t rank, const double* d_JT_block, double* d_send, void* hip_stream);
+int og_shard_unpack_dev(og_handle h, int32_t rank, const double* d_recv, double* d_JT_full, void* hip_stream);
+
+/* ---- several GPUs of one node from one process ---------------------------------------------------
+ * og_comm_init(G, devs) names the devices the sharded handles use and brings up one RCCL communicator per
+ * device (ncclCommInitAll; librccl is loaded at run time - a copy already in the process, e.g. torch's, is
+ * reused).  OGPSX_GATHER=peer exchanges the packed blocks with hipMemcpyPeerAsync instead (the reported
+ * alternative of SURVEY.md section 8(e); it also allows listing one device several times, which is how the
+ * single-GPU test box exercises G > 1), OGPSX_GATHER=rccl makes a missing librccl an error.
+ * og_multi_create makes one sub-handle, one stream and one zero-initialised n x m replica of J_T per device
+ * (desc->device is ignored).  og_multi_fd_sweep = og_fd_sweep over all n columns, the columns split in G
+ * contiguous blocks, the packed non-zeros exchanged by one grouped ncclAllGather over xGMI, the host result
+ * (JT: n x m, may be registered with og_multi_jt_register_host; F0 may be NULL) taken from device 0.
+ * og_multi_fd_sweep_enqueue does the same without the download and without synchronising: afterwards every
+ * device's replica (og_multi_replica_dev: device pointers + the device's stream) holds the whole matrix, for
+ * device-side consumers such as the SQP core.  Bitwise the same matrix as a single-device sweep for any G.
+ * Replaces the same 3n+2 callback evaluations as og_fd_sweep (scipy:_slsqp_py.py:299-313). */
+typedef struct og_multi_s* og_multi;
+int og_comm_init(int32_t G, const int32_t* devs);
+void og_comm_finalize(void);
+int og_comm_size(void);          /* devices named by the last og_comm_init (0: none) */
+int og_comm_uses_rccl(void);     /* 1: ncclAllGather, 0: peer copies */
+int og_multi_create(const og_desc* desc, og_multi* out);
+void og_multi_destroy(og_multi mh);
+int og_multi_devices(og_multi mh);
+int og_multi_eval(og_multi mh, const double* x, double* F);
+int og_multi_fd_sweep(og_multi mh, const double* x, const double* hstep, double* JT, double* F0);
+int og_multi_fd_sweep_enqueue(og_multi mh, const double* x, const double* hstep);
+int og_multi_synchronize(og_multi mh);
+int og_multi_replica_dev(og_multi mh, int32_t g, double** d_JT_full, double** d_F0, void** hip_stream);
+int og_multi_jt_register_host(og_multi mh, double* JT);
+
 /* ---- exact Jacobian (opt-in, changes the numbers SLSQP sees) ---
  * Same layout as the sweep: JT[(j - col_lo) * m + r] = dF_r/dx_j, but by forward-mode
  * differentiation of the traced callbacks (no step h, no subtraction, no FD noise; where a callback
@@ -132,6 +199,9 @@ int og_jacobian_exact_dev(og_handle h, const double* d_x, int32_t col_lo, int32_
 
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 const char* og_last_error(void);
+/* Diagnostics: synchronise `device` and copy `bytes` bytes of its memory to the host (tests read the replicas of
+ * a multi-device handle with it). */
+int og_device_read(int32_t device, const void* d_src, void* dst, int64_t bytes);
 /* Developer diagnostics: phase stamps (s_memrealtime ticks) written by kernel modules compiled with
  * -DOGK_TRACE=1 on a handle created with OGPSX_TRACE=1 in the environment; 8 doubles per wavefront,
  * 8 wavefronts per workgroup, in grid order (tools/trace_fused.py).  Reads `count` doubles and clears

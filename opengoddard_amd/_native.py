@@ -47,9 +47,33 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_jt_register_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "og_jt_unregister_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "og_jt_register_host": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32]),
+    "og_jt_unregister_host": (C.c_int, [C.c_void_p, _c_double_p]),
+    "og_pattern": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                             _c_int32_p]),
+    "og_pack_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "og_unpack_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "og_shard_plan": (C.c_int, [C.c_void_p, C.c_int32, _c_int32_p, C.POINTER(C.c_int64)]),
+    "og_shard_pack_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_shard_unpack_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_comm_init": (C.c_int, [C.c_int32, _c_int32_p]),
+    "og_comm_finalize": (None, []),
+    "og_comm_size": (C.c_int, []),
+    "og_comm_uses_rccl": (C.c_int, []),
+    "og_multi_create": (C.c_int, [C.POINTER(OgDesc), C.POINTER(C.c_void_p)]),
+    "og_multi_destroy": (None, [C.c_void_p]),
+    "og_multi_devices": (C.c_int, [C.c_void_p]),
+    "og_multi_eval": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
+    "og_multi_fd_sweep": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    "og_multi_fd_sweep_enqueue": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
+    "og_multi_synchronize": (C.c_int, [C.c_void_p]),
+    "og_multi_replica_dev": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p)]),
+    "og_multi_jt_register_host": (C.c_int, [C.c_void_p, _c_double_p]),
     "og_jacobian_exact": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p]),
     "og_jacobian_exact_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "og_device_read": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     "og_trace_read": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64]),
     "og_last_error": (C.c_char_p, []),
     "og_device_count": (C.c_int, []),

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define OGK_ABI 8
+#define OGK_ABI 9
 #define OGK_MAX_PHASE 32
 
 // MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
@@ -57,6 +57,13 @@ typedef struct ogk_args {
     uint32_t jt_gen;        // number of this launch among the launches into this registered buffer (1, 2, ...)
     uint32_t* jt_state;     // generation of the last launch into the buffer that left NaN fill behind
     int32_t col_lo, col_hi; // FD columns handled by this launch
+    // Packed non-zeros (modes 6-9).  The static pattern of J_T is the tracer's: column j can be non-zero in
+    // the collocation block its state slice owns (N consecutive rows) and at its row items, in that order.
+    const int64_t* poff;    // [n] offset of column j's entries in the packed array (modes 7-9)
+    int32_t* pint;          // mode 6: [n] entries per column (out); mode 7: row index of every packed entry (out)
+    double* pvals;          // packed values: mode 8 writes them, mode 9 reads them
+    double* ptail;          // mode 8: m + 1 doubles that receive F(x0) and the count of non-finite rows, or NULL
+    int32_t ulo, uhi;       // mode 9: columns to scatter; those inside [col_lo, col_hi) are this rank's own: skipped
     double* trace;          // -DOGK_TRACE builds: [workgroup][8 wavefronts][8] phase stamps (else unused)
     int64_t dfrag_off[OGK_MAX_PHASE];
 } ogk_args;
@@ -69,6 +76,10 @@ int ogk_get_info(ogk_info* out);
 // mode 0: evaluate F(x0) into f0 (+ scratch y0/t0/z).  mode 1: structured FD sweep over
 // [col_lo, col_hi) into jt (needs mode 0's outputs at the same x0).  mode 2: dense FD sweep.
 // mode 3 / 4: exact Jacobian, dense / structured (needs mode 0).  mode 5: modes 0 + 1 in one launch.
+// mode 6 / 7: the static pattern (entries per column / row indices).  mode 8: gather the pattern entries of
+// the columns [col_lo, col_hi) of `jt` into pvals.  mode 9: scatter pvals into the rows [ulo, uhi) of a full
+// matrix `jt` (row 0 = column 0), filling those rows from z first when F(x0) has non-finite rows or the
+// previous step left such a fill behind.
 // Only enqueues kernels on `stream`; returns a hipError_t value (0 = success).
 int ogk_launch(const ogk_args* args, int mode, void* stream);
 #ifdef __cplusplus

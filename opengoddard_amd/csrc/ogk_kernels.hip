@@ -1415,6 +1415,64 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Modes 6-9: the packed non-zeros.  One wavefront per column; entry i of column j is row own_lo + i for
+// i < own_hi - own_lo (the collocation block the MFMA tiles write) and the row of item i - (own_hi - own_lo)
+// after that (OGT_ELEM order) - the order codegen.sparsity() documents.
+// ------------------------------------------------------------------------------------------
+constexpr int PACK_THREADS = 256;
+__device__ __forceinline__ int pattern_row(const int4 col, const int own, const int i) {
+    return i < own ? col.z + i : OGT_ELEM[col.x + (i - own)].w;
+}
+
+__global__ __launch_bounds__(PACK_THREADS) void ogk_pattern(const ogk_args a, const int rows_pass) {
+    const int j = (int)(blockIdx.x * (PACK_THREADS / 64) + (threadIdx.x >> 6));
+    const int lane = (int)threadIdx.x & 63;
+    if (j >= OgGen::N_VAR) return;
+    const int4 col = OGT_COL[j];
+    const int own = (col.w & ~HEAVY_FLAG) - col.z, cnt = own + (col.y - col.x);
+    if (!rows_pass) {
+        if (lane == 0) a.pint[j] = cnt;
+        return;
+    }
+    for (int i = lane; i < cnt; i += 64) a.pint[a.poff[j] + i] = pattern_row(col, own, i);
+}
+
+__global__ __launch_bounds__(PACK_THREADS) void ogk_pack(const ogk_args a) {
+    const int j = a.col_lo + (int)(blockIdx.x * (PACK_THREADS / 64) + (threadIdx.x >> 6));
+    const int lane = (int)threadIdx.x & 63;
+    if (blockIdx.x == 0 && a.ptail) {
+        for (int r = (int)threadIdx.x; r < OgGen::M; r += PACK_THREADS) a.ptail[r] = a.f0[r];
+        if (threadIdx.x == 0) a.ptail[OgGen::M] = (double)*a.nonfinite;
+    }
+    if (j >= a.col_hi) return;
+    const int4 col = OGT_COL[j];
+    const int own = (col.w & ~HEAVY_FLAG) - col.z, cnt = own + (col.y - col.x);
+    const double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+    double* out = a.pvals + a.poff[j];
+    for (int i = lane; i < cnt; i += 64) out[i] = jrow[pattern_row(col, own, i)];
+}
+
+__global__ __launch_bounds__(PACK_THREADS) void ogk_unpack(const ogk_args a) {
+    // rows [ulo, uhi) of the full matrix except this rank's own block; one wavefront per row
+    int j = a.ulo + (int)(blockIdx.x * (PACK_THREADS / 64) + (threadIdx.x >> 6));
+    if (j >= a.col_lo) j += a.col_hi - a.col_lo;
+    const int lane = (int)threadIdx.x & 63;
+    if (j >= a.uhi) return;
+    const int4 col = OGT_COL[j];
+    const int own = (col.w & ~HEAVY_FLAG) - col.z, cnt = own + (col.y - col.x);
+    double* jrow = a.jt + (long)j * OgGen::M;
+    // every rank evaluated the same F(x0): its z says which rows are NaN in every column; a fill (NaN now, or
+    // zeros to clean up after one) goes first, the wavefront's own stores to one row stay in order
+    const bool fill = a.jt_sparse && (*a.nonfinite != 0 || *a.jt_state == a.jt_gen - 1u);
+    if (fill) {
+        for (int r = lane; r < OgGen::M; r += 64) jrow[r] = a.z[r];
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    const double* in = a.pvals + a.poff[j];
+    for (int i = lane; i < cnt; i += 64) jrow[pattern_row(col, own, i)] = in[i];
+}
+
 int defect_blocks() {
     int nb = 0;
     for (int g = 0; g < OgGen::N_GROUPS; ++g)
@@ -1466,6 +1524,24 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         return (int)hipGetLastError();
     }
     const int ncols = args->col_hi - args->col_lo;
+    if (mode == 6 || mode == 7) {
+        hipLaunchKernelGGL(ogk_pattern, dim3((OgGen::N_VAR + PACK_THREADS / 64 - 1) / (PACK_THREADS / 64)),
+                           dim3(PACK_THREADS), 0, stream, *args, mode == 7 ? 1 : 0);
+        return (int)hipGetLastError();
+    }
+    if (mode == 8) {
+        if (ncols <= 0 && !args->ptail) return 0;
+        hipLaunchKernelGGL(ogk_pack, dim3(ncols > 0 ? (ncols + PACK_THREADS / 64 - 1) / (PACK_THREADS / 64) : 1), dim3(PACK_THREADS),
+                           0, stream, *args);
+        return (int)hipGetLastError();
+    }
+    if (mode == 9) {
+        const int others = (args->uhi - args->ulo) - ncols;
+        if (others > 0)
+            hipLaunchKernelGGL(ogk_unpack, dim3((others + PACK_THREADS / 64 - 1) / (PACK_THREADS / 64)),
+                               dim3(PACK_THREADS), 0, stream, *args);
+        return (int)hipGetLastError();
+    }
     if (ncols <= 0) return 0;
     if (mode == 1) {
         const int light_blocks = (ncols + LIGHT_COLS - 1) / LIGHT_COLS;

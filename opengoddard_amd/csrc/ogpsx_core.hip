@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +101,27 @@ struct og_problem_s {
     std::vector<jt_reg> regs;
     int last_reg = -1;                  // registration the most recent fill_args matched (-1: none)
     uint32_t* d_state = nullptr;
+    // static pattern of J_T (og_pattern): entries of column j are indptr[j]..indptr[j+1] of the packed order
+    bool have_pattern = false;
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> rows;
+    int64_t* d_indptr = nullptr;
+    // host-pointer entry points: pinned staging ([x | h] up, [packed non-zeros | F | non-finite count] down)
+    double* h_up = nullptr;
+    double* h_down = nullptr;
+    double* d_down = nullptr;
+    size_t down_capacity = 0;
+    // host matrices registered as persistent-zero (og_jt_register_host)
+    struct host_reg {
+        double* ptr;
+        int lo, hi;
+        bool dirty;                     // holds a NaN fill: zero it before the next scatter
+    };
+    std::vector<host_reg> host_regs;
+    // column sharding (og_shard_plan)
+    int shard_world = 0;
+    int64_t shard_block_vals = 0;
+    int64_t* d_shard_off = nullptr;
 };
 static const int OG_MAX_JT_REGS = 63;
 static const size_t OG_TRACE_DOUBLES = (size_t)1 << 20;     // 16384 workgroups x 8 wavefronts x 8 stamps
@@ -107,7 +129,8 @@ static const size_t OG_TRACE_DOUBLES = (size_t)1 << 20;     // 16384 workgroups 
 namespace {
 
 void fill_args(og_problem_s* p, ogk_args* a, const double* x, const double* h, double* f0,
-               double* jt, int lo, int hi) {
+               double* jt, int lo, int hi, bool new_launch = true) {
+    memset(a, 0, sizeof *a);
     a->x0 = x;
     a->h = h;
     a->dfrag = p->d_dfrag;
@@ -134,9 +157,9 @@ void fill_args(og_problem_s* p, ogk_args* a, const double* x, const double* h, d
             auto& r = p->regs[i];
             if (r.ptr == jt && r.lo == lo && r.hi == hi) {
                 a->jt_sparse = 1;
-                a->jt_gen = ++r.launches;
+                a->jt_gen = new_launch ? ++r.launches : r.launches;
                 a->jt_state = p->d_state + r.slot;
-                p->last_reg = (int)i;
+                p->last_reg = new_launch ? (int)i : -1;
                 break;
             }
         }
@@ -166,6 +189,129 @@ int own_jt(og_problem_s* p, int lo, int hi) {
     for (auto& r : p->regs)
         if (r.ptr == p->d_jt && r.lo == lo && r.hi == hi) return 0;
     return og_jt_register_dev(p, p->d_jt, lo, hi, p->stream);
+}
+
+// the static pattern, once per handle: entries per column from the module (mode 6), prefix sums here, row
+// indices from the module again (mode 7)
+int ensure_pattern(og_problem_s* p) {
+    if (p->have_pattern) return 0;
+    OG_HIP(hipSetDevice(p->device));
+    const int n = p->n;
+    int32_t* d_cnt = nullptr;
+    OG_HIP(hipMalloc(&d_cnt, sizeof(int32_t) * (size_t)n));
+    ogk_args a;
+    fill_args(p, &a, nullptr, nullptr, nullptr, nullptr, 0, 0, false);
+    a.pint = d_cnt;
+    int rc = p->launch(&a, 6, p->stream);
+    std::vector<int32_t> cnt((size_t)n);
+    hipError_t e = rc ? (hipError_t)rc : hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int32_t) * (size_t)n,
+                                                        hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    hipFree(d_cnt);
+    if (e != hipSuccess) return fail(100 + (int)e, std::string("og_pattern: ") + hipGetErrorString(e));
+    p->indptr.assign((size_t)n + 1, 0);
+    for (int j = 0; j < n; ++j) p->indptr[(size_t)j + 1] = p->indptr[(size_t)j] + cnt[(size_t)j];
+    const size_t nnz = (size_t)p->indptr[(size_t)n];
+    OG_HIP(hipMalloc(&p->d_indptr, sizeof(int64_t) * ((size_t)n + 1)));
+    OG_HIP(hipMemcpy(p->d_indptr, p->indptr.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    int32_t* d_rows = nullptr;
+    OG_HIP(hipMalloc(&d_rows, sizeof(int32_t) * (nnz ? nnz : 1)));
+    a.pint = d_rows;
+    a.poff = p->d_indptr;
+    rc = p->launch(&a, 7, p->stream);
+    p->rows.assign(nnz, 0);
+    e = rc ? (hipError_t)rc : hipMemcpyAsync(p->rows.data(), d_rows, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost,
+                                             p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    hipFree(d_rows);
+    if (e != hipSuccess) return fail(100 + (int)e, std::string("og_pattern: ") + hipGetErrorString(e));
+    p->have_pattern = true;
+    return 0;
+}
+
+// pinned staging of the host-pointer entry points
+int ensure_staging(og_problem_s* p, size_t down_doubles) {
+    if (!p->h_up) OG_HIP(hipHostMalloc(&p->h_up, sizeof(double) * 2 * (size_t)p->n, hipHostMallocDefault));
+    if (down_doubles > p->down_capacity) {
+        if (p->h_down) OG_HIP(hipHostFree(p->h_down));
+        if (p->d_down) OG_HIP(hipFree(p->d_down));
+        p->h_down = p->d_down = nullptr;
+        p->down_capacity = 0;
+        OG_HIP(hipHostMalloc(&p->h_down, sizeof(double) * down_doubles, hipHostMallocDefault));
+        OG_HIP(hipMalloc(&p->d_down, sizeof(double) * down_doubles));
+        p->down_capacity = down_doubles;
+    }
+    return 0;
+}
+
+// x (and h) to the device through the pinned buffer: one copy
+int upload_point(og_problem_s* p, const double* x, const double* hstep) {
+    int rc = ensure_staging(p, p->down_capacity ? p->down_capacity : (size_t)p->m + 1);
+    if (rc) return rc;
+    memcpy(p->h_up, x, sizeof(double) * (size_t)p->n);
+    if (hstep) memcpy(p->h_up + p->n, hstep, sizeof(double) * (size_t)p->n);
+    // d_x and d_h are one allocation: [x | h]
+    OG_HIP(hipMemcpyAsync(p->d_x, p->h_up, sizeof(double) * (size_t)p->n * (hstep ? 2 : 1), hipMemcpyHostToDevice,
+                          p->stream));
+    return 0;
+}
+
+og_problem_s::host_reg* find_host_reg(og_problem_s* p, const double* JT, int lo, int hi) {
+    for (auto& r : p->host_regs)
+        if (r.ptr == JT && r.lo == lo && r.hi == hi) return &r;
+    return nullptr;
+}
+
+// After a sweep / exact Jacobian into the handle's own registered buffer: bring the result to the host.  A
+// registered host matrix receives the packed non-zeros (one pinned copy together with F and the count of
+// non-finite rows) and a scatter; anything else, and any sweep with non-finite rows, the dense block.
+int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, const double* d_src = nullptr) {
+    const size_t need = (size_t)(hi - lo) * (size_t)p->m;
+    if (!d_src) d_src = p->d_jt;
+    og_problem_s::host_reg* reg = find_host_reg(p, JT, lo, hi);
+    if (!reg) {
+        OG_HIP(hipMemcpyAsync(JT, d_src, sizeof(double) * need, hipMemcpyDeviceToHost, p->stream));
+        if (F0) OG_HIP(hipMemcpyAsync(F0, p->d_f0, sizeof(double) * p->m, hipMemcpyDeviceToHost, p->stream));
+        OG_HIP(hipStreamSynchronize(p->stream));
+        return 0;
+    }
+    int rc = ensure_pattern(p);
+    if (rc) return rc;
+    const int64_t first = p->indptr[(size_t)lo], nnz = p->indptr[(size_t)hi] - first;
+    const size_t down = (size_t)nnz + (size_t)p->m + 1;
+    rc = ensure_staging(p, down);
+    if (rc) return rc;
+    ogk_args a;
+    fill_args(p, &a, p->d_x, p->d_h, p->d_f0, const_cast<double*>(d_src), lo, hi, false);
+    a.poff = p->d_indptr;
+    a.pvals = p->d_down - first;
+    a.ptail = p->d_down + nnz;
+    rc = p->launch(&a, 8, p->stream);
+    if (rc) return fail(100 + rc, std::string("og_fd_sweep: pack: ") + hipGetErrorString((hipError_t)rc));
+    OG_HIP(hipMemcpyAsync(p->h_down, p->d_down, sizeof(double) * down, hipMemcpyDeviceToHost, p->stream));
+    OG_HIP(hipStreamSynchronize(p->stream));
+    const bool bad = p->h_down[(size_t)nnz + (size_t)p->m] != 0.0;
+    if (F0) memcpy(F0, p->h_down + nnz, sizeof(double) * (size_t)p->m);
+    if (bad) {                           // rows of NaN in every column: the dense block
+        OG_HIP(hipMemcpyAsync(JT, d_src, sizeof(double) * need, hipMemcpyDeviceToHost, p->stream));
+        OG_HIP(hipStreamSynchronize(p->stream));
+        reg->dirty = true;
+        return 0;
+    }
+    if (reg->dirty) {
+        memset(JT, 0, sizeof(double) * need);
+        reg->dirty = false;
+    }
+    const int m = p->m;
+    const double* v = p->h_down;
+    for (int j = lo; j < hi; ++j) {
+        double* row = JT + (size_t)(j - lo) * (size_t)m;
+        const int32_t* r = p->rows.data() + p->indptr[(size_t)j];
+        const int64_t cnt = p->indptr[(size_t)j + 1] - p->indptr[(size_t)j];
+        for (int64_t i = 0; i < cnt; ++i) row[r[i]] = v[i];
+        v += cnt;
+    }
+    return 0;
 }
 
 }  // namespace
@@ -326,8 +472,8 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
             e = hipMemcpy(p->d_cvec, desc->cvec, sizeof(double) * (size_t)desc->n_cvec,
                           hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMalloc(&p->d_x, sizeof(double) * (size_t)p->n);
-    if (e == hipSuccess) e = hipMalloc(&p->d_h, sizeof(double) * (size_t)p->n);
+    if (e == hipSuccess) e = hipMalloc(&p->d_x, sizeof(double) * 2 * (size_t)p->n);      // [x | h]
+    if (e == hipSuccess) p->d_h = p->d_x + p->n;
     if (e == hipSuccess) e = hipMalloc(&p->d_f0, sizeof(double) * (size_t)p->m);
     if (e == hipSuccess) e = hipMalloc(&p->d_y0, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_xop, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
@@ -368,7 +514,6 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_dfrag);
     hipFree(p->d_cvec);
     hipFree(p->d_x);
-    hipFree(p->d_h);
     hipFree(p->d_f0);
     hipFree(p->d_jt);
     hipFree(p->d_y0);
@@ -378,11 +523,24 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_flags);
     hipFree(p->d_state);
     hipFree(p->d_trace);
+    hipFree(p->d_indptr);
+    hipFree(p->d_down);
+    hipFree(p->d_shard_off);
+    if (p->h_up) hipHostFree(p->h_up);
+    if (p->h_down) hipHostFree(p->h_down);
     if (p->module) dlclose(p->module);
     delete p;
 }
 
 int og_sweep_mode(og_handle p) { return p ? p->sweep_mode : 0; }
+
+int og_device_read(int32_t device, const void* d_src, void* dst, int64_t bytes) {
+    if (!d_src || !dst || bytes < 0) return fail(1, "og_device_read: bad argument");
+    OG_HIP(hipSetDevice(device));
+    OG_HIP(hipDeviceSynchronize());
+    OG_HIP(hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int og_trace_read(og_handle p, double* out, int64_t count) {
     if (!p || !out) return fail(1, "og_trace_read: null argument");
@@ -430,6 +588,142 @@ int og_jt_unregister_dev(og_handle p, double* d_JT) {
             return 0;
         }
     return fail(1, "og_jt_unregister_dev: buffer is not registered");
+}
+
+int og_jt_register_host(og_handle p, double* JT, int32_t lo, int32_t hi) {
+    if (!p || !JT) return fail(1, "og_jt_register_host: null argument");
+    if (lo < 0 || hi > p->n || lo >= hi) return fail(1, "og_jt_register_host: bad column range");
+    int rc = ensure_pattern(p);
+    if (rc) return rc;
+    memset(JT, 0, sizeof(double) * (size_t)(hi - lo) * (size_t)p->m);
+    for (auto& r : p->host_regs)
+        if (r.ptr == JT) {
+            r.lo = lo, r.hi = hi, r.dirty = false;
+            return 0;
+        }
+    p->host_regs.push_back({JT, lo, hi, false});
+    return 0;
+}
+
+int og_jt_unregister_host(og_handle p, double* JT) {
+    if (!p) return fail(1, "og_jt_unregister_host: null handle");
+    for (size_t i = 0; i < p->host_regs.size(); ++i)
+        if (p->host_regs[i].ptr == JT) {
+            p->host_regs.erase(p->host_regs.begin() + (long)i);
+            return 0;
+        }
+    return fail(1, "og_jt_unregister_host: matrix is not registered");
+}
+
+int og_pattern(og_handle p, int32_t lo, int32_t hi, int64_t* nnz, int64_t* indptr, int32_t* rows) {
+    if (!p) return fail(1, "og_pattern: null handle");
+    if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_pattern: bad column range");
+    int rc = ensure_pattern(p);
+    if (rc) return rc;
+    const int64_t first = p->indptr[(size_t)lo], count = p->indptr[(size_t)hi] - first;
+    if (nnz) *nnz = count;
+    if (indptr)
+        for (int j = lo; j <= hi; ++j) indptr[j - lo] = p->indptr[(size_t)j] - first;
+    if (rows && count) memcpy(rows, p->rows.data() + first, sizeof(int32_t) * (size_t)count);
+    return 0;
+}
+
+int og_pack_dev(og_handle p, const double* d_JT, int32_t lo, int32_t hi, double* d_vals, void* hip_stream) {
+    if (!p || !d_JT || !d_vals) return fail(1, "og_pack_dev: null argument");
+    if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_pack_dev: bad column range");
+    int rc = ensure_pattern(p);
+    if (rc) return rc;
+    ogk_args a;
+    fill_args(p, &a, nullptr, nullptr, p->d_f0, const_cast<double*>(d_JT), lo, hi, false);
+    a.poff = p->d_indptr;
+    a.pvals = d_vals - p->indptr[(size_t)lo];
+    rc = p->launch(&a, 8, hip_stream);
+    if (rc) return fail(100 + rc, std::string("og_pack_dev: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+int og_unpack_dev(og_handle p, const double* d_vals, int32_t lo, int32_t hi, double* d_JT, void* hip_stream) {
+    if (!p || !d_JT || !d_vals) return fail(1, "og_unpack_dev: null argument");
+    if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_unpack_dev: bad column range");
+    int rc = ensure_pattern(p);
+    if (rc) return rc;
+    ogk_args a;
+    fill_args(p, &a, nullptr, nullptr, p->d_f0, nullptr, lo, lo, false);
+    a.jt = d_JT - (size_t)lo * (size_t)p->m;       // the kernel indexes rows by absolute column
+    a.jt_sparse = 0;                               // plain scatter: no fill
+    a.poff = p->d_indptr;
+    a.pvals = const_cast<double*>(d_vals) - p->indptr[(size_t)lo];
+    a.ulo = lo;
+    a.uhi = hi;
+    rc = p->launch(&a, 9, hip_stream);
+    if (rc) return fail(100 + rc, std::string("og_unpack_dev: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+int og_shard_plan(og_handle p, int32_t world, int32_t* block_cols, int64_t* block_vals) {
+    if (!p) return fail(1, "og_shard_plan: null handle");
+    if (world < 1) return fail(1, "og_shard_plan: world must be >= 1");
+    int rc = ensure_pattern(p);
+    if (rc) return rc;
+    OG_HIP(hipSetDevice(p->device));
+    const int n = p->n, B = (n + world - 1) / world;
+    int64_t worst = 0;
+    for (int r = 0; r < world; ++r) {
+        const int lo = std::min(n, r * B), hi = std::min(n, lo + B);
+        worst = std::max(worst, p->indptr[(size_t)hi] - p->indptr[(size_t)lo]);
+    }
+    std::vector<int64_t> off((size_t)n);
+    for (int j = 0; j < n; ++j) {
+        const int r = j / B;
+        off[(size_t)j] = (int64_t)r * worst + p->indptr[(size_t)j] - p->indptr[(size_t)(r * B)];
+    }
+    if (p->d_shard_off) OG_HIP(hipFree(p->d_shard_off));
+    p->d_shard_off = nullptr;
+    OG_HIP(hipMalloc(&p->d_shard_off, sizeof(int64_t) * (size_t)(n ? n : 1)));
+    OG_HIP(hipMemcpy(p->d_shard_off, off.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice));
+    p->shard_world = world;
+    p->shard_block_vals = worst;
+    if (block_cols) *block_cols = B;
+    if (block_vals) *block_vals = worst;
+    return 0;
+}
+
+int og_shard_pack_dev(og_handle p, int32_t rank, const double* d_JT_block, double* d_send, void* hip_stream) {
+    if (!p || !d_JT_block || !d_send) return fail(1, "og_shard_pack_dev: null argument");
+    if (!p->shard_world || rank < 0 || rank >= p->shard_world)
+        return fail(1, "og_shard_pack_dev: no shard plan, or rank out of range");
+    const int n = p->n, B = (n + p->shard_world - 1) / p->shard_world;
+    const int lo = std::min(n, rank * B), hi = std::min(n, lo + B);
+    ogk_args a;
+    fill_args(p, &a, nullptr, nullptr, p->d_f0, const_cast<double*>(d_JT_block), lo, hi, false);
+    a.poff = p->d_shard_off;
+    a.pvals = d_send - (int64_t)rank * p->shard_block_vals;
+    int rc = p->launch(&a, 8, hip_stream);
+    if (rc) return fail(100 + rc, std::string("og_shard_pack_dev: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+int og_shard_unpack_dev(og_handle p, int32_t rank, const double* d_recv, double* d_JT_full, void* hip_stream) {
+    if (!p || !d_recv || !d_JT_full) return fail(1, "og_shard_unpack_dev: null argument");
+    if (!p->shard_world || rank < 0 || rank >= p->shard_world)
+        return fail(1, "og_shard_unpack_dev: no shard plan, or rank out of range");
+    const int n = p->n, B = (n + p->shard_world - 1) / p->shard_world;
+    const int lo = std::min(n, rank * B), hi = std::min(n, lo + B);
+    ogk_args a;
+    // the registration of this rank's own block inside the replica tells whether the previous step left a NaN
+    // fill behind; same generation as the sweep that was just enqueued (no new launch into the block)
+    fill_args(p, &a, nullptr, nullptr, p->d_f0, d_JT_full + (size_t)lo * (size_t)p->m, lo, hi, false);
+    if (!a.jt_sparse && hi > lo)
+        return fail(1, "og_shard_unpack_dev: this rank's block of the replica is not a registered buffer");
+    a.jt = d_JT_full;
+    a.jt_sparse = 1;
+    a.poff = p->d_shard_off;
+    a.pvals = const_cast<double*>(d_recv);
+    a.ulo = 0;
+    a.uhi = n;
+    int rc = p->launch(&a, 9, hip_stream);
+    if (rc) return fail(100 + rc, std::string("og_shard_unpack_dev: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
 }
 
 int og_problem_dims(og_handle p, int32_t* n, int32_t* m, int32_t* m_eq, int32_t* m_ineq) {
@@ -497,11 +791,13 @@ int og_jacobian_exact_dev(og_handle p, const double* d_x, int32_t lo, int32_t hi
 int og_eval(og_handle p, const double* x, double* F) {
     if (!p || !x || !F) return fail(1, "og_eval: null argument");
     OG_HIP(hipSetDevice(p->device));
-    OG_HIP(hipMemcpyAsync(p->d_x, x, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
-    int rc = og_eval_dev(p, p->d_x, p->d_f0, p->stream);
+    int rc = upload_point(p, x, nullptr);
     if (rc) return rc;
-    OG_HIP(hipMemcpyAsync(F, p->d_f0, sizeof(double) * p->m, hipMemcpyDeviceToHost, p->stream));
+    rc = og_eval_dev(p, p->d_x, p->d_f0, p->stream);
+    if (rc) return rc;
+    OG_HIP(hipMemcpyAsync(p->h_down, p->d_f0, sizeof(double) * p->m, hipMemcpyDeviceToHost, p->stream));
     OG_HIP(hipStreamSynchronize(p->stream));
+    memcpy(F, p->h_down, sizeof(double) * (size_t)p->m);
     return 0;
 }
 
@@ -519,16 +815,11 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
         const int rcj = own_jt(p, lo, hi);
         if (rcj) return rcj;
     }
-    OG_HIP(hipMemcpyAsync(p->d_x, x, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
-    OG_HIP(hipMemcpyAsync(p->d_h, hstep, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
-    int rc = og_fd_sweep_dev(p, p->d_x, p->d_h, lo, hi, p->d_jt, p->d_f0, p->stream);
+    int rc = upload_point(p, x, hstep);
     if (rc) return rc;
-    if (need)
-        OG_HIP(hipMemcpyAsync(JT, p->d_jt, sizeof(double) * need, hipMemcpyDeviceToHost, p->stream));
-    if (F0)
-        OG_HIP(hipMemcpyAsync(F0, p->d_f0, sizeof(double) * p->m, hipMemcpyDeviceToHost, p->stream));
-    OG_HIP(hipStreamSynchronize(p->stream));
-    return 0;
+    rc = og_fd_sweep_dev(p, p->d_x, p->d_h, lo, hi, p->d_jt, p->d_f0, p->stream);
+    if (rc) return rc;
+    return download_block(p, lo, hi, JT, F0);
 }
 
 int og_jacobian_exact(og_handle p, const double* x, int32_t lo, int32_t hi, double* JT, double* F0) {
@@ -544,13 +835,301 @@ int og_jacobian_exact(og_handle p, const double* x, int32_t lo, int32_t hi, doub
         const int rcj = own_jt(p, lo, hi);
         if (rcj) return rcj;
     }
-    OG_HIP(hipMemcpyAsync(p->d_x, x, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
-    int rc = og_jacobian_exact_dev(p, p->d_x, lo, hi, p->d_jt, p->d_f0, p->stream);
+    int rc = upload_point(p, x, nullptr);
     if (rc) return rc;
-    OG_HIP(hipMemcpyAsync(JT, p->d_jt, sizeof(double) * need, hipMemcpyDeviceToHost, p->stream));
-    if (F0) OG_HIP(hipMemcpyAsync(F0, p->d_f0, sizeof(double) * p->m, hipMemcpyDeviceToHost, p->stream));
-    OG_HIP(hipStreamSynchronize(p->stream));
+    rc = og_jacobian_exact_dev(p, p->d_x, lo, hi, p->d_jt, p->d_f0, p->stream);
+    if (rc) return rc;
+    return download_block(p, lo, hi, JT, F0);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Column sharding over several devices of one node from ONE process:
+// og_comm_init names the devices (and brings up one RCCL communicator per device, ncclCommInitAll, when
+// librccl is loadable); an og_multi handle holds one sub-handle, one stream and one full replica of J_T
+// per device.  A sweep: every device gets x and h, sweeps ITS block of columns into its replica, packs the
+// non-zeros; one grouped ncclAllGather over xGMI (or, OGPSX_GATHER=peer, G-1 hipMemcpyPeerAsync per device)
+// exchanges the packed blocks; every device scatters the others' non-zeros into its replica.  The host
+// result comes from device 0.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+typedef void* ogn_comm;
+struct rccl_api {
+    void* lib = nullptr;
+    int (*CommInitAll)(ogn_comm*, int, const int*) = nullptr;
+    int (*CommDestroy)(ogn_comm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ogn_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+const int OGN_FLOAT64 = 8;              // ncclFloat64 (rccl.h)
+
+struct comm_state {
+    std::vector<int> devs;
+    std::vector<ogn_comm> comms;        // empty: peer copies
+    rccl_api api;
+} g_comm;
+
+bool load_rccl(rccl_api* api) {
+    // a librccl that is already in the process (torch loads its own) wins over the system one
+    const char* names[] = {nullptr, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        void* lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) continue;
+        void* sym = dlsym(lib, "ncclCommInitAll");
+        if (!sym) continue;
+        api->lib = lib;
+        api->CommInitAll = (int (*)(ogn_comm*, int, const int*))sym;
+        api->CommDestroy = (int (*)(ogn_comm))dlsym(lib, "ncclCommDestroy");
+        api->AllGather = (int (*)(const void*, void*, size_t, int, ogn_comm, hipStream_t))dlsym(lib, "ncclAllGather");
+        api->GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+        api->GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
+        api->GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+        return api->CommDestroy && api->AllGather && api->GroupStart && api->GroupEnd;
+    }
+    return false;
+}
+
+}  // namespace
+
+struct og_multi_s {
+    int G = 0;
+    int n = 0, m = 0, B = 0;
+    int64_t block_vals = 0;
+    bool rccl = false;
+    std::vector<og_problem_s*> sub;
+    std::vector<double*> d_full;        // n x m replica per device (rows of the device's block are registered)
+    std::vector<double*> d_send, d_recv;
+    std::vector<hipEvent_t> packed;     // peer mode: block g's packed values are ready
+};
+
+extern "C" {
+
+int og_comm_init(int32_t G, const int32_t* devs) {
+    if (G < 1 || !devs) return fail(1, "og_comm_init: need at least one device");
+    og_comm_finalize();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(3, "og_comm_init: no HIP device available");
+    bool distinct = true;
+    for (int i = 0; i < G; ++i) {
+        if (devs[i] < 0 || devs[i] >= ndev) return fail(3, "og_comm_init: device ordinal out of range");
+        for (int k = 0; k < i; ++k) distinct = distinct && devs[k] != devs[i];
+    }
+    g_comm.devs.assign(devs, devs + G);
+    const char* mode = getenv("OGPSX_GATHER");
+    const bool want_peer = mode && std::string(mode) == "peer";
+    if (!distinct && !want_peer)
+        return fail(1, "og_comm_init: a device is listed twice (only allowed with OGPSX_GATHER=peer, for tests)");
+    if (!want_peer) {
+        if (!load_rccl(&g_comm.api)) {
+            if (mode && std::string(mode) == "rccl") return fail(7, "og_comm_init: librccl could not be loaded");
+        } else {
+            g_comm.comms.assign((size_t)G, nullptr);
+            const int rc = g_comm.api.CommInitAll(g_comm.comms.data(), G, g_comm.devs.data());
+            if (rc != 0) {
+                g_comm.comms.clear();
+                return fail(7, std::string("og_comm_init: ncclCommInitAll: ") +
+                                   (g_comm.api.GetErrorString ? g_comm.api.GetErrorString(rc) : "?"));
+            }
+        }
+    }
+    if (g_comm.comms.empty())            // peer copies: let every pair of distinct devices reach each other
+        for (int i = 0; i < G; ++i)
+            for (int k = 0; k < G; ++k)
+                if (devs[i] != devs[k]) {
+                    hipSetDevice(devs[i]);
+                    hipDeviceEnablePeerAccess(devs[k], 0);      // "already enabled" is fine
+                    (void)hipGetLastError();
+                }
     return 0;
+}
+
+void og_comm_finalize(void) {
+    for (ogn_comm c : g_comm.comms)
+        if (c && g_comm.api.CommDestroy) g_comm.api.CommDestroy(c);
+    g_comm.comms.clear();
+    g_comm.devs.clear();
+}
+
+int og_comm_size(void) { return (int)g_comm.devs.size(); }
+int og_comm_uses_rccl(void) { return g_comm.comms.empty() ? 0 : 1; }
+
+void og_multi_destroy(og_multi mh) {
+    if (!mh) return;
+    for (int g = 0; g < (int)mh->sub.size(); ++g) {
+        if (!mh->sub[(size_t)g]) continue;
+        hipSetDevice(mh->sub[(size_t)g]->device);
+        if ((size_t)g < mh->d_full.size()) hipFree(mh->d_full[(size_t)g]);
+        if ((size_t)g < mh->d_send.size()) hipFree(mh->d_send[(size_t)g]);
+        if ((size_t)g < mh->d_recv.size()) hipFree(mh->d_recv[(size_t)g]);
+        if ((size_t)g < mh->packed.size() && mh->packed[(size_t)g]) hipEventDestroy(mh->packed[(size_t)g]);
+        og_problem_destroy(mh->sub[(size_t)g]);
+    }
+    delete mh;
+}
+
+int og_multi_create(const og_desc* desc, og_multi* out) {
+    if (!desc || !out) return fail(1, "og_multi_create: null argument");
+    *out = nullptr;
+    const int G = (int)g_comm.devs.size();
+    if (G < 1) return fail(1, "og_multi_create: call og_comm_init first");
+    og_multi_s* mh = new og_multi_s();
+    mh->G = G;
+    mh->rccl = !g_comm.comms.empty();
+    mh->sub.assign((size_t)G, nullptr);
+    mh->d_full.assign((size_t)G, nullptr);
+    mh->d_send.assign((size_t)G, nullptr);
+    mh->d_recv.assign((size_t)G, nullptr);
+    mh->packed.assign((size_t)G, nullptr);
+    for (int g = 0; g < G; ++g) {
+        og_desc d = *desc;
+        d.device = g_comm.devs[(size_t)g];
+        int rc = og_problem_create(&d, &mh->sub[(size_t)g]);
+        if (rc) {
+            og_multi_destroy(mh);
+            return rc;
+        }
+    }
+    mh->n = mh->sub[0]->n;
+    mh->m = mh->sub[0]->m;
+    for (int g = 0; g < G; ++g) {
+        og_problem_s* p = mh->sub[(size_t)g];
+        int32_t B = 0;
+        int64_t bv = 0;
+        int rc = og_shard_plan(p, G, &B, &bv);
+        if (rc) {
+            og_multi_destroy(mh);
+            return rc;
+        }
+        mh->B = B;
+        mh->block_vals = bv;
+        const size_t full = sizeof(double) * (size_t)mh->n * (size_t)mh->m;
+        const size_t blk = sizeof(double) * (size_t)(bv ? bv : 1);
+        hipError_t e = hipSetDevice(p->device);
+        if (e == hipSuccess) e = hipMalloc(&mh->d_full[(size_t)g], full);
+        if (e == hipSuccess) e = hipMemsetAsync(mh->d_full[(size_t)g], 0, full, p->stream);
+        if (e == hipSuccess) e = hipMalloc(&mh->d_send[(size_t)g], blk);
+        if (e == hipSuccess) e = hipMemsetAsync(mh->d_send[(size_t)g], 0, blk, p->stream);
+        if (e == hipSuccess) e = hipMalloc(&mh->d_recv[(size_t)g], blk * (size_t)G);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&mh->packed[(size_t)g], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            og_multi_destroy(mh);
+            return fail(100 + (int)e, std::string("og_multi_create: ") + hipGetErrorString(e));
+        }
+        const int lo = std::min(mh->n, g * B), hi = std::min(mh->n, lo + B);
+        if (hi > lo) {
+            rc = og_jt_register_dev(p, mh->d_full[(size_t)g] + (size_t)lo * (size_t)mh->m, lo, hi, p->stream);
+            if (rc) {
+                og_multi_destroy(mh);
+                return rc;
+            }
+        }
+    }
+    *out = mh;
+    return 0;
+}
+
+int og_multi_devices(og_multi mh) { return mh ? mh->G : 0; }
+
+int og_multi_replica_dev(og_multi mh, int32_t g, double** d_JT_full, double** d_F0, void** hip_stream) {
+    if (!mh || g < 0 || g >= mh->G) return fail(1, "og_multi_replica_dev: bad argument");
+    if (d_JT_full) *d_JT_full = mh->d_full[(size_t)g];
+    if (d_F0) *d_F0 = mh->sub[(size_t)g]->d_f0;
+    if (hip_stream) *hip_stream = (void*)mh->sub[(size_t)g]->stream;
+    return 0;
+}
+
+// enqueue one sharded sweep on every device (x and hstep are host vectors); no synchronisation
+static int multi_enqueue(og_multi_s* mh, const double* x, const double* hstep) {
+    const int G = mh->G, n = mh->n, B = mh->B;
+    for (int g = 0; g < G; ++g) {
+        og_problem_s* p = mh->sub[(size_t)g];
+        OG_HIP(hipSetDevice(p->device));
+        int rc = upload_point(p, x, hstep);
+        if (rc) return rc;
+        const int lo = std::min(n, g * B), hi = std::min(n, lo + B);
+        double* block = mh->d_full[(size_t)g] + (size_t)lo * (size_t)mh->m;
+        if (hi > lo) rc = og_fd_sweep_dev(p, p->d_x, p->d_h, lo, hi, block, p->d_f0, p->stream);
+        else rc = og_eval_dev(p, p->d_x, p->d_f0, p->stream);          // more devices than columns: F(x) only
+        if (rc) return rc;
+        if (G > 1 || mh->rccl) {         // (one device with RCCL: the collective still runs - a plumbing check)
+            rc = og_shard_pack_dev(p, g, block, mh->d_send[(size_t)g], p->stream);
+            if (rc) return rc;
+            if (!mh->rccl) OG_HIP(hipEventRecord(mh->packed[(size_t)g], p->stream));
+        }
+    }
+    if (G == 1 && !mh->rccl) return 0;
+    const size_t count = (size_t)mh->block_vals;
+    if (mh->rccl) {
+        int rc = g_comm.api.GroupStart();
+        for (int g = 0; g < G && rc == 0; ++g)
+            rc = g_comm.api.AllGather(mh->d_send[(size_t)g], mh->d_recv[(size_t)g], count, OGN_FLOAT64,
+                                      g_comm.comms[(size_t)g], mh->sub[(size_t)g]->stream);
+        const int rc2 = g_comm.api.GroupEnd();
+        if (rc == 0) rc = rc2;
+        if (rc != 0)
+            return fail(7, std::string("og_multi_fd_sweep: ncclAllGather: ") +
+                               (g_comm.api.GetErrorString ? g_comm.api.GetErrorString(rc) : "?"));
+    } else {
+        for (int g = 0; g < G; ++g) {
+            og_problem_s* p = mh->sub[(size_t)g];
+            OG_HIP(hipSetDevice(p->device));
+            for (int r = 0; r < G; ++r) {
+                if (r == g) continue;
+                OG_HIP(hipStreamWaitEvent(p->stream, mh->packed[(size_t)r], 0));
+                OG_HIP(hipMemcpyPeerAsync(mh->d_recv[(size_t)g] + (size_t)r * count, p->device, mh->d_send[(size_t)r],
+                                          mh->sub[(size_t)r]->device, sizeof(double) * count, p->stream));
+            }
+        }
+    }
+    for (int g = 0; g < G; ++g) {
+        og_problem_s* p = mh->sub[(size_t)g];
+        OG_HIP(hipSetDevice(p->device));
+        int rc = og_shard_unpack_dev(p, g, mh->d_recv[(size_t)g], mh->d_full[(size_t)g], p->stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int og_multi_fd_sweep_enqueue(og_multi mh, const double* x, const double* hstep) {
+    if (!mh || !x || !hstep) return fail(1, "og_multi_fd_sweep_enqueue: null argument");
+    return multi_enqueue(mh, x, hstep);
+}
+
+int og_multi_synchronize(og_multi mh) {
+    if (!mh) return fail(1, "og_multi_synchronize: null handle");
+    for (int g = 0; g < mh->G; ++g) {
+        OG_HIP(hipSetDevice(mh->sub[(size_t)g]->device));
+        OG_HIP(hipStreamSynchronize(mh->sub[(size_t)g]->stream));
+    }
+    return 0;
+}
+
+int og_multi_fd_sweep(og_multi mh, const double* x, const double* hstep, double* JT, double* F0) {
+    if (!mh || !x || !hstep || !JT) return fail(1, "og_multi_fd_sweep: null argument");
+    int rc = multi_enqueue(mh, x, hstep);
+    if (rc) return rc;
+    // devices 1.. finish their replicas too before the call returns (one call in flight per handle)
+    for (int g = 1; g < mh->G; ++g) {
+        OG_HIP(hipSetDevice(mh->sub[(size_t)g]->device));
+        OG_HIP(hipStreamSynchronize(mh->sub[(size_t)g]->stream));
+    }
+    og_problem_s* p0 = mh->sub[0];
+    OG_HIP(hipSetDevice(p0->device));
+    return download_block(p0, 0, mh->n, JT, F0, mh->d_full[0]);
+}
+
+int og_multi_jt_register_host(og_multi mh, double* JT) {
+    if (!mh) return fail(1, "og_multi_jt_register_host: null handle");
+    return og_jt_register_host(mh->sub[0], JT, 0, mh->n);
+}
+
+int og_multi_eval(og_multi mh, const double* x, double* F) {
+    if (!mh) return fail(1, "og_multi_eval: null handle");
+    return og_eval(mh->sub[0], x, F);
 }
 
 }  // extern "C"

@@ -24,8 +24,14 @@ from . import _native, build, codegen
 class HipEngine:
     jacobian_mode = "fd"        # "fd": SciPy's forward differences (the reference); "exact": forward-mode AD
 
-    def __init__(self, prob, obj, device=0, program=None):
+    def __init__(self, prob, obj, device=0, program=None, devices=None):
+        """``devices=[d0, d1, ...]`` (more than one): every full sweep of :meth:`jacobians` is column-sharded
+        over these GPUs from this one process (``og_comm_init`` + ``og_multi_fd_sweep``); ``device`` is then the
+        first of them and keeps serving the single evaluations and the device-pointer entry points."""
         lib = _native.lib()
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            device = devices[0]
         if _native.device_count() < 1:
             raise RuntimeError("opengoddard_amd: no HIP device is visible; the MI355X engine has "
                                "no CPU fallback")
@@ -58,6 +64,15 @@ class HipEngine:
         self._val_key = self._val = None
         self._jac_key = self._jac = None
         self.n_values = self.n_sweeps = 0
+        # the matrix SciPy's callbacks read: allocated once, registered as persistent-zero, so that a sweep
+        # moves and writes the non-zeros only (og_jt_register_host)
+        self._JT_host = None
+        self.devices = devices if devices and len(devices) > 1 else None
+        self._multi = C.c_void_p()
+        if self.devices:
+            arr = (C.c_int32 * len(self.devices))(*self.devices)
+            _native.check(lib.og_comm_init(len(self.devices), arr), "og_comm_init")
+            _native.check(lib.og_multi_create(C.byref(desc), C.byref(self._multi)), "og_multi_create")
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -65,6 +80,9 @@ class HipEngine:
         if cache is not None:                       # QP work space of the SQP driver (sqp.py)
             cache[1].close()
             self._sqp_cache = None
+        if getattr(self, "_multi", None) is not None and self._multi.value:
+            self._lib.og_multi_destroy(self._multi)
+            self._multi = C.c_void_p()
         if getattr(self, "_handle", None) is not None and self._handle.value:
             self._lib.og_problem_destroy(self._handle)
             self._handle = C.c_void_p()
@@ -104,6 +122,46 @@ class HipEngine:
         JT = np.empty((col_hi - col_lo, self.m))
         _native.check(self._lib.og_jacobian_exact(self._handle, _native.dptr(x), int(col_lo), col_hi,
                                                   _native.dptr(JT), _native.dptr(F0)), "og_jacobian_exact")
+        return F0, JT
+
+    def pattern(self, col_lo=0, col_hi=None):
+        """Static pattern of J_T for the columns [col_lo, col_hi): ``(indptr, rows)`` (``og_pattern``)."""
+        col_hi = self.n if col_hi is None else int(col_hi)
+        nnz = C.c_int64()
+        _native.check(self._lib.og_pattern(self._handle, int(col_lo), col_hi, C.byref(nnz), None, None), "og_pattern")
+        indptr = np.empty(col_hi - col_lo + 1, dtype=np.int64)
+        rows = np.empty(nnz.value, dtype=np.int32)
+        _native.check(self._lib.og_pattern(self._handle, int(col_lo), col_hi, None,
+                                           indptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           rows.ctypes.data_as(C.POINTER(C.c_int32))), "og_pattern")
+        return indptr, rows
+
+    def sweep_persistent(self, x, h, exact=False):
+        """``(F0, JT)`` over all columns like :meth:`sweep_stacked`, but ``JT`` is the engine's ONE persistent
+        host matrix (registered with ``og_jt_register_host``: only the packed non-zeros cross PCIe and are
+        scattered into it).  The caller must be done with the previous result - SciPy's SLSQP is: it copies the
+        Jacobians it is handed.  With ``devices=[...]`` the sweep is column-sharded over those GPUs."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        F0 = np.empty(self.m)
+        if self._JT_host is None:
+            self._JT_host = np.empty((self.n, self.m))
+            if self._multi.value:
+                _native.check(self._lib.og_multi_jt_register_host(self._multi, _native.dptr(self._JT_host)),
+                              "og_multi_jt_register_host")
+            _native.check(self._lib.og_jt_register_host(self._handle, _native.dptr(self._JT_host), 0, self.n),
+                          "og_jt_register_host")
+        JT = self._JT_host
+        if exact:
+            _native.check(self._lib.og_jacobian_exact(self._handle, _native.dptr(x), 0, self.n, _native.dptr(JT),
+                                                      _native.dptr(F0)), "og_jacobian_exact")
+        elif self._multi.value:
+            h = np.ascontiguousarray(h, dtype=np.float64)
+            _native.check(self._lib.og_multi_fd_sweep(self._multi, _native.dptr(x), _native.dptr(h), _native.dptr(JT),
+                                                      _native.dptr(F0)), "og_multi_fd_sweep")
+        else:
+            h = np.ascontiguousarray(h, dtype=np.float64)
+            _native.check(self._lib.og_fd_sweep(self._handle, _native.dptr(x), _native.dptr(h), 0, self.n,
+                                                _native.dptr(JT), _native.dptr(F0)), "og_fd_sweep")
         return F0, JT
 
     @property
@@ -154,11 +212,8 @@ class HipEngine:
         key = np.asarray(p, dtype=np.float64).tobytes()
         if key != self._jac_key:
             h = _native.fd_step(p, lb, ub)           # (also in exact mode: quirk Q13 needs the last step)
-            if self.jacobian_mode == "exact":
-                F0, JT = self.exact_stacked(p)
-            else:
-                F0, JT = self.sweep_stacked(p, h)
-            J = JT.T
+            F0, JT = self.sweep_persistent(p, h, exact=self.jacobian_mode == "exact")
+            J = JT.T                                 # views of the persistent matrix (SciPy copies them)
             self._jac = ((np.ascontiguousarray(J[0]), J[1:1 + self.m_eq], J[1 + self.m_eq:]), h)
             self._jac_key = key
             self._val, self._val_key = self._split(F0), key

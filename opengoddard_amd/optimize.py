@@ -33,9 +33,9 @@ ENGINE_FACTORY = None
 DEFAULT_SQP_CORE = "scipy"
 
 
-def _default_engine(prob, obj):
+def _default_engine(prob, obj, devices=None):
     from .engine import HipEngine        # raises if the HIP library / a GPU is missing
-    return HipEngine(prob, obj)
+    return HipEngine(prob, obj, devices=devices)
 
 
 def _noop():
@@ -405,7 +405,15 @@ class Problem:
         if jacobian not in ("fd", "exact"):
             raise ValueError("jacobian must be 'fd' or 'exact', got %r" % (jacobian,))
 
-        engine = (ENGINE_FACTORY or _default_engine)(self, obj)
+        # devices=[0, 1, ...]: the FD columns of every sweep are split over these GPUs of the node (one process,
+        # RCCL all-gather of the packed non-zeros; include/ogpsx.h og_comm_init / og_multi_fd_sweep)
+        devices = options.pop("devices", None)
+        if devices is None and os.environ.get("OG_DEVICES"):
+            devices = [int(v) for v in os.environ["OG_DEVICES"].split(",")]
+        if ENGINE_FACTORY is not None:
+            engine = ENGINE_FACTORY(self, obj)
+        else:
+            engine = _default_engine(self, obj, devices=devices)
         self._engine = engine
         if jacobian == "exact":
             if not hasattr(engine, "exact_stacked"):

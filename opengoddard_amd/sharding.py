@@ -3,13 +3,28 @@
 The n FD columns are independent given x0 (``scipy/optimize/_numdiff.py:592-620`` has no
 cross-iteration dependency), so rank r of W evaluates the contiguous block
 ``[r*B, min(n, (r+1)*B))`` with ``B = ceil(n / W)``; F(x0) is recomputed on every rank (one
-extra column) instead of being broadcast.  The transposed Jacobian is row-major ``n x m``, so
-each rank's block is one contiguous slab and a single RCCL all-gather over xGMI reassembles
-it; the last block is padded to ``B`` rows so that all ranks contribute equal-sized messages
-(``all_gather_into_tensor``).  One process per GPU, ``torch.distributed`` (backend ``nccl`` is
-RCCL on ROCm; the CPU tests use ``gloo``).
+extra column) instead of being broadcast.  Every rank keeps a full ``n x m`` replica of the
+transposed Jacobian that was zeroed ONCE; per step it sweeps its own block into its rows of
+the replica (persistent-zero output: only the non-zeros are written), packs those non-zeros
+(static pattern, 1.5-9 % of the block), and ONE all-gather of equal-sized messages
+(``all_gather_into_tensor``: RCCL over xGMI with backend ``nccl``; ``gloo`` in the CPU tests)
+hands every rank the others' packed blocks, which it scatters into its replica.  The message is
+``block_vals * 8`` bytes per rank instead of ``B * m * 8`` (C3, W=2: 0.34 MB instead of 9.3 MB).
+
+Two ways to run it, same layout (:func:`plan`), same results bit for bit:
+
+* one process per GPU, ``torch.distributed`` - :class:`ShardedSweep` (``bench.py --gpus N``);
+* one process driving several GPUs - ``HipEngine(devices=[...])`` / ``Problem.solve(devices=...)``,
+  i.e. ``og_comm_init`` + ``og_multi_fd_sweep`` in ``libogpsx.so`` (``ncclCommInitAll`` + grouped
+  ``ncclAllGather``).
+
+:class:`ShardedSweep` talks to the device through a small backend object; :class:`HipBackend` is the
+product (C ABI: ``og_fd_sweep_dev``, ``og_shard_pack_dev``, ``og_shard_unpack_dev``), and the CPU test
+drives the very same class with a backend made of the oracle (``tests/test_sharding_gloo.py``).
 """
 from __future__ import annotations
+
+import numpy as np
 
 
 def block_rows(n, world):
@@ -23,13 +38,103 @@ def column_range(n, rank, world):
     return lo, min(int(n), lo + b)
 
 
-def gathered_shape(n, m, world):
-    return (block_rows(n, world) * world, int(m))
+def plan(indptr, world):
+    """Layout of the exchanged messages for a pattern ``indptr`` (n+1 prefix sums of entries per column):
+    ``(B, block_vals, offsets)`` - rank r's message holds the packed entries of its columns in pattern order,
+    padded to ``block_vals`` (the largest block), and ``offsets[j]`` is where column j's entries start in the
+    concatenation of all messages.  Identical to ``og_shard_plan`` (tested on the GPU)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    n = indptr.size - 1
+    B = block_rows(n, world)
+    starts = np.minimum(n, np.arange(world) * B)
+    ends = np.minimum(n, starts + B)
+    block_vals = int(max(0, (indptr[ends] - indptr[starts]).max()))
+    rank_of = np.arange(n) // B if n else np.zeros(0, dtype=np.int64)
+    offsets = rank_of * block_vals + indptr[:-1] - indptr[starts[rank_of]] if n else np.zeros(0, dtype=np.int64)
+    return B, block_vals, offsets.astype(np.int64)
 
 
-def all_gather_jt(local_block, out, group=None):
-    """All-gather the per-rank slabs (``block_rows x m`` each, zero-padded) into ``out``
-    (``block_rows*world x m``); the caller slices ``out[:n]``."""
-    import torch.distributed as dist
-    dist.all_gather_into_tensor(out, local_block, group=group)
-    return out
+class HipBackend:
+    """Device side of :class:`ShardedSweep` on one MI355X: torch tensors for memory and streams, every
+    operation a call into ``libogpsx.so``."""
+
+    def __init__(self, engine, torch_device):
+        import torch
+        self.torch, self.engine, self.device = torch, engine, torch_device
+        self.stream = torch.cuda.current_stream(torch_device).cuda_stream
+        self._lib = engine._lib
+
+    def pattern_indptr(self):
+        return self.engine.pattern()[0]
+
+    def zeros(self, *shape):
+        return self.torch.zeros(shape, dtype=self.torch.float64, device=self.device)
+
+    def empty(self, *shape):
+        return self.torch.empty(shape, dtype=self.torch.float64, device=self.device)
+
+    def upload(self, host_vector):
+        return self.torch.from_numpy(np.ascontiguousarray(host_vector, dtype=np.float64)).to(self.device)
+
+    def make_plan(self, world):
+        import ctypes as C
+        from . import _native
+        B, bv = C.c_int32(), C.c_int64()
+        _native.check(self._lib.og_shard_plan(self.engine._handle, int(world), C.byref(B), C.byref(bv)), "og_shard_plan")
+        return B.value, bv.value
+
+    def register_block(self, replica, lo, hi):
+        if hi > lo:
+            self.engine.register_jt_dev(replica[lo:hi].data_ptr(), lo, hi, self.stream)
+
+    def sweep(self, x, h, lo, hi, replica, F0):
+        if hi > lo:
+            self.engine.sweep_dev(x.data_ptr(), h.data_ptr(), lo, hi, replica[lo:hi].data_ptr(), F0.data_ptr(),
+                                  self.stream)
+        else:                        # more ranks than columns: this rank only evaluates F(x0)
+            self.engine.eval_dev(x.data_ptr(), F0.data_ptr(), self.stream)
+
+    def pack(self, rank, lo, hi, replica, send):
+        from . import _native
+        block = replica[lo:hi] if hi > lo else replica
+        _native.check(self._lib.og_shard_pack_dev(self.engine._handle, int(rank), block.data_ptr(), send.data_ptr(),
+                                                  self.stream), "og_shard_pack_dev")
+
+    def unpack(self, rank, recv, replica):
+        from . import _native
+        _native.check(self._lib.og_shard_unpack_dev(self.engine._handle, int(rank), recv.data_ptr(),
+                                                    replica.data_ptr(), self.stream), "og_shard_unpack_dev")
+
+
+class ShardedSweep:
+    """One rank's share of the column-sharded sweep: ``step(x, h)`` leaves the WHOLE transposed Jacobian in
+    ``self.replica`` (n x m) and F(x0) in ``self.F0`` on every rank."""
+
+    def __init__(self, backend, n, m, rank, world, group=None, exchange_alone=False):
+        self.backend, self.n, self.m, self.rank, self.world, self.group = backend, int(n), int(m), int(rank), int(world), group
+        self.exchange_alone = bool(exchange_alone)       # run pack / all-gather / unpack with one rank too (plumbing checks)
+        self.lo, self.hi = column_range(n, rank, world)
+        self.B, self.block_vals, self.offsets = plan(backend.pattern_indptr(), world)
+        made = backend.make_plan(world)
+        assert made == (self.B, self.block_vals), "shard plan of the library differs from sharding.plan: %r" % (made,)
+        self.replica = backend.zeros(self.n, self.m)
+        self.F0 = backend.empty(self.m)
+        self.send = backend.zeros(max(self.block_vals, 1))
+        self.recv = backend.empty(max(self.block_vals, 1) * self.world)
+        backend.register_block(self.replica, self.lo, self.hi)
+
+    @property
+    def message_bytes(self):
+        return 8 * self.block_vals
+
+    def step(self, x, h, gather=True):
+        """``x``, ``h``: device vectors of the backend.  ``gather=False`` stops after this rank's own block."""
+        be = self.backend
+        be.sweep(x, h, self.lo, self.hi, self.replica, self.F0)
+        if not gather or (self.world == 1 and not self.exchange_alone):
+            return self.replica
+        be.pack(self.rank, self.lo, self.hi, self.replica, self.send)
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        be.unpack(self.rank, self.recv, self.replica)
+        return self.replica

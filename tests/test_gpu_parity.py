@@ -121,14 +121,15 @@ def test_against_numpy_restatement_without_generated_code(name, golden):
     eng.close()
 
 
-@pytest.mark.parametrize("name", SMALL)
-def test_column_sharding_is_bitwise_invariant(name, golden):
-    """sharding FD columns must not change a single bit."""
+@pytest.mark.parametrize("name,splits", [(n, (2, 3, 8)) for n in SMALL] + [("low_thrust", (4,)), ("launch4", (8,))])
+def test_column_sharding_is_bitwise_invariant(name, splits, golden):
+    """sharding FD columns must not change a single bit - also on the two
+    configurations BASELINE.json shards (C4 over 4, C5 over 8)."""
     G = golden("cfg_" + name)
     prob, obj, eng, tw = _engine_and_twin(name)
     x, h = G["x"][1], G["h"][1]
     _, full = eng.sweep_stacked(x, h)
-    for parts in (2, 3, 8):
+    for parts in splits:
         edges = np.linspace(0, eng.n, parts + 1).astype(int)
         pieces = [eng.sweep_stacked(x, h, lo, hi)[1] for lo, hi in zip(edges[:-1], edges[1:])]
         assert np.array_equal(np.vstack(pieces), full)
@@ -344,6 +345,180 @@ def test_registered_buffer_keeps_its_structural_zeros(name, state, layout, monke
     lib = _native.lib()
     assert lib.og_jt_unregister_dev(eng._handle, reg_full.data_ptr()) != 0
     assert b"not registered" in lib.og_last_error()
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["goddard", "polar_tsto", "launch4"])
+def test_pattern_pack_and_unpack(name, golden):
+    """og_pattern is the tracer's static pattern (codegen.sparsity); og_pack_dev gathers exactly those entries
+    of a sweep's result and og_unpack_dev puts them back: everything outside the pattern is an exact zero."""
+    import ctypes as C
+    import torch
+    from opengoddard_amd import codegen
+    G = golden("cfg_" + name)
+    prob, obj, eng, tw = _engine_and_twin(name)
+    n, m = eng.n, eng.m
+    indptr, rows = eng.pattern()
+    want_ptr, want_rows = codegen.sparsity(eng.program)
+    assert np.array_equal(indptr, want_ptr) and np.array_equal(rows, want_rows)
+    lo, hi = n // 5, n // 5 + n // 2
+    ip, rw = eng.pattern(lo, hi)
+    assert np.array_equal(ip, indptr[lo:hi + 1] - indptr[lo]) and np.array_equal(rw, rows[indptr[lo]:indptr[hi]])
+    x, h = G["x"][-1], G["h"][-1]
+    F0, JT = eng.sweep_stacked(x, h)
+    dense = np.zeros((n, m), dtype=bool)
+    dense[np.repeat(np.arange(n), np.diff(indptr)), rows] = True
+    assert not JT[~dense].any()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    lib = _native.lib()
+    d_JT = torch.from_numpy(JT[lo:hi].copy()).to(dev)
+    d_vals = torch.empty(int(ip[-1]), dtype=torch.float64, device=dev)
+    _native.check(lib.og_pack_dev(eng._handle, d_JT.data_ptr(), lo, hi, d_vals.data_ptr(), stream), "og_pack_dev")
+    torch.cuda.synchronize()
+    vals = d_vals.cpu().numpy()
+    assert np.array_equal(vals, JT[lo:hi][np.repeat(np.arange(hi - lo), np.diff(ip)), rw])
+    d_out = torch.full((hi - lo, m), 5.0, dtype=torch.float64, device=dev)
+    _native.check(lib.og_unpack_dev(eng._handle, d_vals.data_ptr(), lo, hi, d_out.data_ptr(), stream), "og_unpack_dev")
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.array_equal(out[dense[lo:hi]], JT[lo:hi][dense[lo:hi]]) and np.all(out[~dense[lo:hi]] == 5.0)
+    eng.close()
+
+
+@pytest.mark.parametrize("name,state", [("goddard", 2), ("polar_tsto", 4)])
+def test_registered_host_matrix_receives_the_packed_nonzeros(name, state):
+    """og_jt_register_host (what Problem.solve's callbacks use): one persistent host matrix, packed non-zeros
+    over PCIe, scatter on the host - the same matrix as the dense transfer into a fresh array, through
+    finite -> non-finite -> finite points, FD and exact mode."""
+    from opengoddard_amd.engine import HipEngine
+    from oracle import np_path
+    prob, obj = problems.build(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    eng = HipEngine(prob, obj)
+    x_ok = np.clip(prob.p, lb, ub)
+    x_bad = x_ok.copy()
+    x_bad[prob.index_states(state, 0, 7)] = 0.0
+    rng = np.random.default_rng(9)
+    x_other = np.clip(x_ok + 1e-3 * rng.standard_normal(eng.n), lb, ub)
+    for step, x in enumerate((x_ok, x_bad, x_other, x_bad, x_bad, x_ok)):
+        h = _native.fd_step(x, lb, ub)
+        F_want, JT_want = eng.sweep_stacked(x, h)
+        F_got, JT_got = eng.sweep_persistent(x, h)
+        assert JT_got is eng._JT_host
+        assert np.array_equal(F_got, F_want, equal_nan=True), "F at step %d" % step
+        assert np.array_equal(JT_got, JT_want, equal_nan=True), "J_T at step %d" % step
+        if x is not x_bad:
+            Fe, JTe = eng.exact_stacked(x)
+            Fp, JTp = eng.sweep_persistent(x, h, exact=True)
+            assert np.array_equal(JTp, JTe) and np.array_equal(Fp, Fe)
+    (g, Jeq, Jineq), _ = eng.jacobians(x_other, lb, ub)
+    F_want, JT_want = eng.sweep_stacked(x_other, _native.fd_step(x_other, lb, ub))
+    assert np.array_equal(np.vstack([g[None, :], Jeq, Jineq]), JT_want.T)
+    eng.close()
+
+
+@pytest.mark.parametrize("gather,devices", [("peer", [0, 0]), ("peer", [0, 0, 0]), ("peer", [0] * 8), ("rccl", [0])])
+@pytest.mark.parametrize("name,state", [("goddard", 2), ("polar_tsto", 4)])
+def test_multi_device_handle_reassembles_the_jacobian(name, state, gather, devices, monkeypatch):
+    """og_comm_init + og_multi_fd_sweep (include/ogpsx.h): the columns split over G sub-handles of one process,
+    the packed non-zeros exchanged, every replica complete.  The 1-GPU box runs G = 2, 3, 8 as G sub-handles on
+    device 0 with peer copies (OGPSX_GATHER=peer) and G = 1 with RCCL (ncclCommInitAll + ncclAllGather), and the
+    result must be the single-device matrix bit for bit, through non-finite points as well."""
+    import ctypes as C
+    from opengoddard_amd.engine import HipEngine
+    from oracle import np_path
+    monkeypatch.setenv("OGPSX_GATHER", gather)
+    prob, obj = problems.build(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    single = HipEngine(prob, obj)
+    lib = _native.lib()
+    arr = (C.c_int32 * len(devices))(*devices)
+    _native.check(lib.og_comm_init(len(devices), arr), "og_comm_init")
+    assert lib.og_comm_size() == len(devices) and lib.og_comm_uses_rccl() == (1 if gather == "rccl" else 0)
+    desc = _native.OgDesc(abi_version=_native.OG_ABI_VERSION, device=0, n=single.n, m_eq=single.m_eq,
+                          m_ineq=single.m_ineq, n_phase=len(single.program.nodes), nodes=single._nodes, D=single._Dptr,
+                          cvec=single._cvec.ctypes.data_as(C.POINTER(C.c_double)) if single._cvec.size else None,
+                          n_cvec=int(single._cvec.size), module_path=single.module_path.encode())
+    mh = C.c_void_p()
+    _native.check(lib.og_multi_create(C.byref(desc), C.byref(mh)), "og_multi_create")
+    assert lib.og_multi_devices(mh) == len(devices)
+    x_ok = np.clip(prob.p, lb, ub)
+    x_bad = x_ok.copy()
+    x_bad[prob.index_states(state, 0, 7)] = 0.0
+    rng = np.random.default_rng(4)
+    x_other = np.clip(x_ok + 1e-3 * rng.standard_normal(single.n), lb, ub)
+    JT = np.empty((single.n, single.m))
+    _native.check(lib.og_multi_jt_register_host(mh, _native.dptr(JT)), "og_multi_jt_register_host")
+    F = np.empty(single.m)
+    for step, x in enumerate((x_ok, x_bad, x_bad, x_other, x_ok)):
+        h = _native.fd_step(x, lb, ub)
+        F_want, JT_want = single.sweep_stacked(x, h)
+        _native.check(lib.og_multi_fd_sweep(mh, _native.dptr(x), _native.dptr(h), _native.dptr(JT), _native.dptr(F)),
+                      "og_multi_fd_sweep")
+        assert np.array_equal(F, F_want, equal_nan=True)
+        assert np.array_equal(JT, JT_want, equal_nan=True), "step %d" % step
+        # every device's replica holds the whole matrix
+        for g in range(len(devices)):
+            d_full, d_F0, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            _native.check(lib.og_multi_replica_dev(mh, g, C.byref(d_full), C.byref(d_F0), C.byref(st)),
+                          "og_multi_replica_dev")
+            host = np.empty_like(JT)
+            _native.check(lib.og_device_read(devices[g], d_full, host.ctypes.data_as(C.c_void_p), host.nbytes),
+                          "og_device_read")
+            assert np.array_equal(host, JT_want, equal_nan=True), "replica %d at step %d" % (g, step)
+    lib.og_multi_destroy(mh)
+    lib.og_comm_finalize()
+    single.close()
+
+
+def test_engine_with_devices_runs_problem_solve(monkeypatch):
+    """HipEngine(devices=[...]) / Problem.solve(devices=...): SciPy's callbacks served by the sharded sweep."""
+    from opengoddard_amd.engine import HipEngine
+    from oracle import np_path
+    monkeypatch.setenv("OGPSX_GATHER", "peer")
+    prob, obj = problems.build("goddard")
+    lb, ub = np_path.bounds_arrays(prob)
+    x = np.clip(prob.p, lb, ub)
+    one = HipEngine(prob, obj)
+    many = HipEngine(prob, obj, devices=[0, 0, 0])
+    (g1, e1, i1), h1 = one.jacobians(x, lb, ub)
+    (g2, e2, i2), h2 = many.jacobians(x, lb, ub)
+    assert np.array_equal(g1, g2) and np.array_equal(e1, e2) and np.array_equal(i1, i2) and np.array_equal(h1, h2)
+    one.close()
+    many.close()
+    prob2, obj2 = problems.build("brachistochrone")
+    prob2.maxIterator = 1
+    prob2.solve(obj2, maxiter=100, devices=[0, 0])
+    assert prob2.last_result.status == 0 and abs(prob2.last_result.fun - 1.7724562) < 2e-5
+
+
+def test_sharded_sweep_class_on_the_device(golden):
+    """sharding.ShardedSweep with the HIP backend (what bench.py --gpus N runs per rank): the library's shard
+    plan equals sharding.plan, and rank r of W leaves its block and nothing else in its replica before the
+    exchange (the exchange itself needs W processes: tests/test_sharding_gloo.py drives the same class)."""
+    import torch
+    from opengoddard_amd import sharding
+    G = golden("cfg_polar_tsto")
+    prob, obj, eng, tw = _engine_and_twin("polar_tsto")
+    x, h = G["x"][0], G["h"][0]
+    _, full = eng.sweep_stacked(x, h)
+    dev = torch.device("cuda", 0)
+    be = sharding.HipBackend(eng, dev)
+    for world, rank in ((1, 0), (4, 2), (8, 7)):
+        sh = sharding.ShardedSweep(be, eng.n, eng.m, rank, world)
+        sh.step(be.upload(x), be.upload(h), gather=False)
+        torch.cuda.synchronize()
+        got = sh.replica.cpu().numpy()
+        assert np.array_equal(got[sh.lo:sh.hi], full[sh.lo:sh.hi])
+        assert not got[:sh.lo].any() and not got[sh.hi:].any()
+        # the rank's message: its packed non-zeros in pattern order
+        be.pack(rank, sh.lo, sh.hi, sh.replica, sh.send)
+        torch.cuda.synchronize()
+        indptr, rows = eng.pattern()
+        want = full[np.repeat(np.arange(sh.lo, sh.hi), np.diff(indptr[sh.lo:sh.hi + 1])), rows[indptr[sh.lo]:indptr[sh.hi]]]
+        assert np.array_equal(sh.send.cpu().numpy()[:want.size], want)
+        eng.unregister_jt_dev(sh.replica[sh.lo:sh.hi].data_ptr())
     eng.close()
 
 

@@ -113,10 +113,64 @@ OG_HD double log_(double x) {
 }
 
 // ---------------------------------------------------------------- sin / cos
-// reduce x to y0 + y1 in [-pi/4, pi/4], return quadrant (mod 4).  Three-stage Cody-Waite with
-// 33+33+53-bit pieces of pi/2: exact for |x| < 2^20 * pi/2; beyond that accuracy degrades
-// gracefully (trajectory angles never get there).
+// reduce x to y0 + y1 in [-pi/4, pi/4], return quadrant (mod 4).  Up to |x| < 2^20 * pi/2: three-stage
+// Cody-Waite with 33+33+53-bit pieces of pi/2 (exact there).  From there to 2^45: the multiple of pi/2 is
+// subtracted in double-double arithmetic from four 53-bit pieces of pi/2 (212 bits), every product exact
+// through an explicit fma (two-product) - an angle that large is already nonsense for a trajectory, but a bad
+// line-search step may produce one, and sin/cos must then still be what NumPy returns (<= 1 ulp), not noise
+// of the size of the FD step.  Beyond 2^45 (and for inf/nan) the reduction returns NaN, so that the row is
+// caught by the engine's non-finite detection instead of carrying |sin| > 1 into the solver.
+OG_HD void two_sum(double a, double b, double* s, double* e) {
+    const double t = a + b;
+    const double bb = t - a;
+    *s = t;
+    *e = (a - (t - bb)) + (b - bb);
+}
+
+// add one double to a non-overlapping expansion e[0..m) (increasing magnitude) exactly; it then has m+1 terms
+OG_HD void expansion_grow(double* e, const int m, const double t) {
+    double q = t;
+    for (int i = 0; i < m; ++i) two_sum(q, e[i], &q, &e[i]);
+    e[m] = q;
+}
+
+OG_HD int rem_pio2_large(double x, double* y0, double* y1) {
+    const double inv_pio2 = 6.36619772367581382433e-01;
+    const double pa = 1.5707963267948966e+00, pb = 6.123233995736766e-17,
+                 pc = -1.4973849048591698e-33, pd = 5.562271104316826e-50;
+    if (!(fabs_(x) < 35184372088832.0)) {                       // 2^45, inf, nan
+        *y0 = (x - x) / (x - x);                                // 0/0 or nan: NaN either way
+        *y1 = 0.0;
+        return 0;
+    }
+    const double fn = (double)(long long)(x * inv_pio2 + (x < 0.0 ? -0.5 : 0.5));
+    // x - fn*pi/2 = (x - ph_a) - pl_a - ph_b - pl_b - ph_c - pl_c - fn*pd with every product split exactly
+    // (fma), x - ph_a exact (the two agree to within pi/4).  The leading terms may cancel down to 2^-50, so
+    // they are summed as an exact expansion (Shewchuk) and only then rounded to y0 + y1.
+    double e[7];
+    double ph = fn * pa, pl = __builtin_fma(fn, pa, -ph);
+    e[0] = x - ph;
+    expansion_grow(e, 1, -pl);
+    ph = fn * pb, pl = __builtin_fma(fn, pb, -ph);
+    expansion_grow(e, 2, -ph);
+    expansion_grow(e, 3, -pl);
+    ph = fn * pc, pl = __builtin_fma(fn, pc, -ph);
+    expansion_grow(e, 4, -ph);
+    expansion_grow(e, 5, -pl);
+    expansion_grow(e, 6, -(fn * pd));
+    double hi = e[6], lo = 0.0, err;
+    for (int i = 5; i >= 0; --i) {
+        two_sum(hi, e[i], &hi, &err);
+        lo += err;
+    }
+    two_sum(hi, lo, &hi, &lo);
+    *y0 = hi;
+    *y1 = lo;
+    return (int)((long long)fn & 3);
+}
+
 OG_HD int rem_pio2(double x, double* y0, double* y1) {
+    if (!(fabs_(x) < 1647099.0)) return rem_pio2_large(x, y0, y1);      // 2^20 * pi/2
     const double inv_pio2 = 6.36619772367581382433e-01;
     const double p1 = 1.57079632673412561417e+00, p1t = 6.07710050650619224932e-11;
     const double p2 = 6.07710050630396597660e-11, p2t = 2.02226624879595063154e-21;

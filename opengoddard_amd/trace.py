@@ -107,9 +107,44 @@ class Sym:
 
     __array_priority__ = 1000.0
 
-    def __init__(self, graph, nid):
+    # NumPy aliasing, reproduced: a Sym is a *name* for a node of the graph.  ``y = x`` makes both names one
+    # object, so masked assignment and in-place arithmetic through either is seen by both (as with an ndarray);
+    # ``+x``, ``x ** 1``, ``np.positive(x)`` and ``x.copy()`` give a NEW object (NumPy copies there); a slice
+    # ``x[a:b]`` is a VIEW: writing through it rewrites the parent, and a later write to the parent shows in the
+    # view (the view re-derives its node when the parent has moved on).
+    def __init__(self, graph, nid, view_of=None):
         self.g = graph
-        self.id = nid
+        self._id = nid
+        self._version = 0
+        self._view_of = view_of            # (parent Sym, start, length) for slice views
+        self._seen = view_of[0]._version if view_of else 0
+
+    @property
+    def id(self):
+        v = self._view_of
+        if v is not None and v[0]._version != self._seen:
+            parent, start, ln = v
+            self._id = self.g.add(("slice", parent.id, start, ln), ln)
+            self._seen = parent._version
+        return self._id
+
+    @id.setter
+    def id(self, nid):
+        """In-place change of what this name stands for (masked assignment, ``+=`` ...)."""
+        self._id = nid
+        self._version += 1
+        v = self._view_of
+        if v is not None:
+            parent, start, ln = v
+            n = parent.length
+            pieces = []
+            if start > 0:
+                pieces.append(self.g.add(("slice", parent.id, 0, start), start))
+            pieces.append(nid)
+            if start + ln < n:
+                pieces.append(self.g.add(("slice", parent.id, start + ln, n - start - ln), n - start - ln))
+            parent.id = pieces[0] if len(pieces) == 1 else self.g.add(("cat", tuple(pieces)), n)
+            self._seen = parent._version
 
     # ------------------------------------------------------------------ basics
     @property
@@ -190,7 +225,7 @@ class Sym:
 
     def _unary(self, op):
         if op == "pos":
-            return self
+            return Sym(self.g, self.id)                 # NumPy: +x is a copy
         if op == "square":
             return self._binary("mul", self)
         if op == "recip":
@@ -214,7 +249,7 @@ class Sym:
 
     # ------------------------------------------------------------------ operators
     def __neg__(self): return self._unary("neg")
-    def __pos__(self): return self
+    def __pos__(self): return Sym(self.g, self.id)
     def __abs__(self): return self._unary("abs")
     def __add__(self, o): return self._binary("add", o)
     def __radd__(self, o): return self._binary("add", o, swap=True)
@@ -228,6 +263,23 @@ class Sym:
     def __le__(self, o): return self._compare("le", o)
     def __gt__(self, o): return self._compare("gt", o)
     def __ge__(self, o): return self._compare("ge", o)
+    def __eq__(self, o): return self._compare("eq", o)
+    def __ne__(self, o): return self._compare("ne", o)
+    __hash__ = None                                     # elementwise ==, like ndarray: not hashable
+
+    def _inplace(self, op, o):
+        out = self._binary(op, o)
+        if out is NotImplemented:
+            return NotImplemented
+        if out.length != self.length:
+            raise TraceError("in-place operation would change the shape of a traced vector")
+        self.id = out.id                                # every alias (and the parent of a view) sees it
+        return self
+
+    def __iadd__(self, o): return self._inplace("add", o)
+    def __isub__(self, o): return self._inplace("sub", o)
+    def __imul__(self, o): return self._inplace("mul", o)
+    def __itruediv__(self, o): return self._inplace("div", o)
     def __and__(self, o): return self._logical("and", o)
     def __or__(self, o): return self._logical("or", o)
 
@@ -239,21 +291,34 @@ class Sym:
 
     def __pow__(self, e):
         # NumPy's scalar-exponent fast paths (numpy/_core/src/multiarray/number.c fast_scalar_power):
-        # 2 -> square (x*x), 0.5 -> sqrt, 1 -> +x, -1 -> reciprocal.  Other exponents call libm
-        # pow(), which has no bit-reproducible device twin here.
+        # 2 -> square (x*x), 0.5 -> sqrt, 1 -> +x, -1 -> reciprocal: reproduced bit for bit.  Every other
+        # exponent goes to libm's pow() in NumPy, which has no bit-reproducible device twin; it is traced as
+        # repeated multiplication for small integers (|e| <= 16: x*x*x, 1/(x*x*x)) and as exp(e * log(x))
+        # otherwise - a few ulp from pow(), far inside the 1e-9 residual tolerance, NaN for a negative base
+        # with a fractional exponent exactly like pow().
         if isinstance(e, (numbers.Real, np.ndarray)) and np.ndim(e) == 0:
             e = float(e)
             if e == 2.0:
                 return self._binary("mul", self)
             if e == 1.0:
-                return self
+                return Sym(self.g, self.id)
             if e == 0.5:
                 return self._unary("sqrt")
             if e == -1.0:
                 return self._unary("recip")
             if e == 0.0:
                 return _ones_like(self)
-        raise TraceError("x ** %r is not traceable (supported exponents: 2, 1, 0.5, -1, 0)" % (e,))
+            if e == int(e) and abs(e) <= 16:
+                k, base, acc = int(abs(e)), self, None
+                while k:                                # square-and-multiply, left to right in the bits of k
+                    if k & 1:
+                        acc = base if acc is None else acc._binary("mul", base)
+                    k >>= 1
+                    if k:
+                        base = base._binary("mul", base)
+                return acc if e > 0 else acc._unary("recip")
+            return self._unary("log")._binary("mul", e)._unary("exp")
+        raise TraceError("x ** y with a traced or array-valued exponent is not traceable")
 
     # ------------------------------------------------------------------ indexing
     def __getitem__(self, key):
@@ -268,8 +333,8 @@ class Sym:
                 raise TraceError("only unit-step slices are traceable")
             ln = max(0, stop - start)
             if start == 0 and ln == n:
-                return self
-            return Sym(self.g, self.g.add(("slice", self.id, start, ln), ln))
+                return Sym(self.g, self.id, view_of=(self, 0, n))
+            return Sym(self.g, self.g.add(("slice", self.id, start, ln), ln), view_of=(self, start, ln))
         raise TraceError("unsupported index %r on a traced vector" % (key,))
 
     def __setitem__(self, key, value):
@@ -294,6 +359,11 @@ class Sym:
             return inputs[0]._binary("mul", _DEG2RAD)
         if ufunc is np.rad2deg or ufunc is np.degrees:
             return inputs[0]._binary("mul", _RAD2DEG)
+        if ufunc is np.sign:
+            x = inputs[0]
+            return where(x > 0.0, 1.0, where(x < 0.0, -1.0, x._binary("mul", 0.0)))
+        if ufunc in (np.fmax, np.fmin):                 # (NaN handling aside: a NaN row is caught either way)
+            ufunc = np.maximum if ufunc is np.fmax else np.minimum
         if ufunc is np.power:
             if isinstance(inputs[0], Sym):
                 return inputs[0].__pow__(inputs[1])

@@ -57,6 +57,10 @@ def ulps(a, b):
     ("v_cos", np.cos, lambda r: r.uniform(-100, 100, 200000), 1.0),
     ("v_sin", np.sin, lambda r: r.uniform(-1e5, 1e5, 200000), 1.0),
     ("v_cos", np.cos, lambda r: r.uniform(-1e5, 1e5, 200000), 1.0),
+    # beyond the Cody-Waite range (2^20 * pi/2): the double-double reduction, up to 2^45
+    ("v_sin", np.sin, lambda r: r.uniform(-1, 1, 200000) * 10.0 ** r.uniform(6.3, 13.5, 200000), 1.0),
+    ("v_cos", np.cos, lambda r: r.uniform(-1, 1, 200000) * 10.0 ** r.uniform(6.3, 13.5, 200000), 1.0),
+    ("v_tan", np.tan, lambda r: r.uniform(-1, 1, 200000) * 10.0 ** r.uniform(6.3, 13.5, 200000), 2.0),
     ("v_tan", np.tan, lambda r: r.uniform(-1.5, 1.5, 200000), 2.0),
     ("v_atan", np.arctan, lambda r: r.standard_normal(200000) * 10.0 ** r.integers(-10, 10, 200000), 1.0),
     ("v_asin", np.arcsin, lambda r: r.uniform(-1, 1, 200000), 1.0),
@@ -116,3 +120,15 @@ def test_special_values(lib):
     s = call(lib, "v_sin", [0.0, -0.0, 1e-300])
     assert s[0] == 0.0 and np.signbit(s[1]) and s[2] == 1e-300
     assert call(lib, "v_cos", [0.0, 1e-300]).tolist() == [1.0, 1.0]
+
+
+def test_trig_of_absurd_angles_is_nan_not_noise(lib):
+    """Above 2^45 the argument reduction gives up: NaN (caught by the engine's non-finite detection), never a
+    value outside [-1, 1]; the cast that used to be undefined behaviour above 9.2e18 is not reached."""
+    x = np.array([3.6e13, 1e17, -1e17, 9.3e18, 1e300, -1e305, np.inf, -np.inf, np.nan])
+    for name in ("v_sin", "v_cos", "v_tan"):
+        assert np.isnan(call(lib, name, x)).all(), name
+    near = np.array([3.5184e13, -3.5184e13, 1.7e6, -1.7e6, 1647098.9, 1647099.1])
+    for name, ref in (("v_sin", np.sin), ("v_cos", np.cos)):
+        y = call(lib, name, near)
+        assert np.all(np.abs(y) <= 1.0) and np.all(ulps(y, ref(near)) <= 1.0)

@@ -191,14 +191,70 @@ def test_tracer_masked_assignment_and_copy_semantics():
     assert np.array_equal(got, want)
 
 
+def _clip_top(v, at):
+    v[v > at] = at
+    return v
+
+
+@pytest.mark.parametrize("fn", [
+    # +x, np.positive(x) and x**1 are COPIES in NumPy: clipping the copy must not clip the original
+    lambda p: np.hstack([_clip_top(+(p[0:6] * 1.0), 1.2), p[0:6] * 1.0]),
+    lambda p: (lambda x: np.hstack([_clip_top(+x, 1.2), x]))(p[0:6] * 1.0),
+    lambda p: (lambda x: np.hstack([_clip_top(np.positive(x), 1.1), x]))(p[0:6] * 2.0),
+    lambda p: (lambda x: np.hstack([_clip_top(x ** 1, 1.3), x]))(p[0:6] + 0.0),
+    # a plain second name is the SAME array: clipping through it clips both
+    lambda p: (lambda x: np.hstack([_clip_top(x, 1.2), x]))(p[0:6] * 1.0),
+    # a slice is a VIEW: masked assignment through it writes the parent ...
+    lambda p: (lambda x: np.hstack([_clip_top(x[1:4], 1.0), x]))(p[0:8] * 1.0),
+    lambda p: (lambda x: np.hstack([_clip_top(x[:], 1.0), x]))(p[0:8] * 1.0),
+    lambda p: (lambda x: np.hstack([_clip_top(x[2:7][1:3], 0.9), x]))(p[0:8] * 1.0),
+    # ... and a later write to the parent shows through an existing view
+    lambda p: (lambda x, v: np.hstack([_clip_top(x, 1.1), v]))(*(lambda x: (x, x[2:6]))(p[0:8] * 1.0)),
+    # in-place arithmetic goes through every alias and through views
+    lambda p: (lambda x, y: (y.__imul__(2.0), np.hstack([x, y]))[1])(*(lambda x: (x, x))(p[0:5] + 0.0)),
+    lambda p: (lambda x, y: (y.__iadd__(p[8]), np.hstack([x, y]))[1])(*(lambda x: (x, x[1:3]))(p[0:5] + 0.0)),
+    lambda p: (lambda x, y: (y.__isub__(0.5), y.__itruediv__(4.0), np.hstack([x, y]))[2])(*(lambda x: (x, x[0:2]))(p[0:5] * 1.0)),
+    # a .copy() of a view is detached
+    lambda p: (lambda x: np.hstack([_clip_top(x[1:4].copy(), 1.0), x]))(p[0:8] * 1.0),
+    # == and != are elementwise comparisons, not Python identity
+    lambda p: (p[0:6] != 0.0) * p[6:12] + (p[0:6] == p[0:6]) * 1.0,
+    lambda p: np.where(p[0:6] == 0.0, 1.0, p[6:12]),
+    # sign / fmax / fmin
+    lambda p: np.sign(p[0:6] - 1.2) * np.fmax(p[0:6], 1.0) + np.fmin(p[6:12], 1.5),
+])
+def test_tracer_aliasing_is_numpys(fn):
+    """the tracer's aliasing must be NumPy's - copies where NumPy copies, views where NumPy views,
+    in-place operators in place - or the traced NLP silently differs from the one the callbacks define."""
+    for seed in range(4):
+        got, want = _trace_eval(fn, seed=seed)
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("fn,exact", [
+    (lambda p: p[0:6] ** 3, False), (lambda p: p[0:6] ** 4.0, False), (lambda p: p[0:6] ** -2, False),
+    (lambda p: p[0:6] ** 7, False), (lambda p: p[0:6] ** 1.5, False), (lambda p: np.power(p[0:6], 2.2), False),
+    (lambda p: p[0:6] ** -0.75, False), (lambda p: p[0:6] ** 2, True), (lambda p: p[0:6] ** 0.5, True),
+])
+def test_tracer_powers(fn, exact):
+    """x**2, x**0.5, x**1, x**-1 follow NumPy's fast paths bit for bit; other exponents (libm pow in NumPy) are
+    traced as repeated multiplication / exp(y log x): a few ulp, documented in trace.Sym.__pow__."""
+    got, want = _trace_eval(fn)
+    if exact:
+        assert np.array_equal(got, want)
+    else:
+        assert np.all(np.abs(got - want) <= 64 * np.spacing(np.abs(want)))
+
+
 def test_tracer_rejects_untraceable_callbacks():
     p = tr.new_decision_vector(8)
     with pytest.raises(tr.TraceError):
         bool(p[0] > 1.0)                       # Python control flow on a decision variable
     with pytest.raises(tr.TraceError):
-        p[0:4] ** 3.0                          # libm pow has no bit-reproducible device twin
+        p[0:4] ** p[4:8]                       # traced exponent
     with pytest.raises(tr.TraceError):
         np.hypot(p[0:2], p[2:4])
+    with pytest.raises(TypeError):
+        hash(p[0:2])                           # == is elementwise, like ndarray: not hashable
     with pytest.raises(tr.TraceError):
         np.sum(p[0:4])
     with pytest.raises(tr.TraceError):

@@ -503,6 +503,13 @@ def _cdouble(raw):
 class _Emitter:
     def __init__(self, program):
         self.P = program
+        # sequential sums (Python's sum() over the nodes of a running cost, say): every summed vector is a
+        # *term block* (length, body expression).  The generated loop asks the accessor for each term
+        # (OgGen::term_pick), so that a kernel can hand out base terms it computed cooperatively once instead
+        # of letting every lane re-evaluate all of them (csrc/ogk_kernels.hip: XColT).
+        self.term_blocks = []          # [(length, body eid)]
+        self.term_index = {}
+        self.sum_groups = set()        # groups whose code contains a sum
         self.eg = program.eg
 
     def _idx(self, base, stride, var):
@@ -605,7 +612,8 @@ class _Emitter:
 
     def _emit_sums(self, roots, lines, names, indent):
         pad = " " * indent
-        for e in self._collect_sums(roots):
+        found = self._collect_sums(roots)
+        for e in found:
             node = self.eg.nodes[e]
             name = "t%d" % e
             # Python's sum(): 0 + v[0] + v[1] + ... left to right
@@ -613,15 +621,83 @@ class _Emitter:
             for ln, body in node[1]:
                 if self._collect_sums([body]):
                     raise _tr.TraceError("nested sums are not supported")
-                # unrolled so that the loads of several terms are in flight; the additions stay in
-                # order (Python's left-to-right sum)
-                lines.append("%s_Pragma(\"unroll 8\")" % pad)
-                lines.append("%sfor (int q = 0; q < %d; ++q) {" % (pad, ln))
-                inner = {}
-                self._emit_expr([body], "q", lines, inner, indent + 4, {})
-                lines.append("%s    %s = %s + %s;" % (pad, name, name, inner[body]))
-                lines.append("%s}" % pad)
+                key = (ln, body)
+                if key not in self.term_index:
+                    self.term_index[key] = len(self.term_blocks)
+                    self.term_blocks.append(key)
+                tb = self.term_index[key]
+                # the additions stay in order (Python's left-to-right sum); where the terms come from is the
+                # accessor's business (default: evaluated in place, sum_term)
+                # (default: evaluated in place, sum_term).  An accessor that holds the block's base terms
+                # (term_cache) supplies them with the one term that reads its perturbed variable swapped in:
+                # the loop is then LDS reads and adds, no control flow inside
+                lines += ["%s{" % pad,
+                          "%s    const double* tcp = term_cache_of(x, %d, 0);" % (pad, tb),
+                          "%s    if (tcp) {" % pad,
+                          "%s        const int qd = term_q_of(x, %d, 0);" % (pad, tb),
+                          "%s        const S td = term_v_of(x, %d, 0);" % (pad, tb),
+                          "%s        _Pragma(\"unroll 8\")" % pad,
+                          "%s        for (int q = 0; q < %d; ++q) %s = %s + (q == qd ? td : S(tcp[q]));" % (pad, ln, name, name),
+                          "%s    } else {" % pad,
+                          "%s        _Pragma(\"unroll 8\")" % pad,
+                          "%s        for (int q = 0; q < %d; ++q) %s = %s + sum_term(%d, q, x, cv);" % (pad, ln, name, name, tb),
+                          "%s    }" % pad,
+                          "%s}" % pad]
             names[e] = name
+        return bool(found)
+
+    def term_functions(self):
+        """``sum_term(tb, q, x, cv)``: term q of block tb; ``sum_term_reads(tb, q, j)``: does it read p[j]?"""
+        eg = self.eg
+        offs, at = [], 0
+        for ln, _ in self.term_blocks:
+            offs.append(at)
+            at += ln
+        L = ["    static constexpr int N_TBLK = %d;" % len(self.term_blocks),
+             "    static constexpr int N_TERMS = %d;" % at,
+             _int_table("TERM_OFF", offs), _int_table("TERM_LEN", [ln for ln, _ in self.term_blocks]),
+             "    template <class X> OG_HDI static typename X::scalar sum_term(const int tb, const int q, const X& x, "
+             "const double* cv) {",
+             "        typedef typename X::scalar S;",
+             "        (void)q; (void)cv; (void)x;",
+             "        switch (tb) {"]
+        for tb, (ln, body) in enumerate(self.term_blocks):
+            L.append("        case %d: {" % tb)
+            inner = {}
+            self._emit_expr([body], "q", L, inner, 12, {})
+            L += ["            return %s;" % inner[body], "        }"]
+        L += ["        default: return S(0.0);", "        }", "    }",
+              # which term of block tb reads p[j]: its index, -1 none, -2 more than one (no caching for that lane)
+              "    OG_HDI static int sum_term_q(const int tb, const int j) {",
+              "        (void)j;",
+              "        switch (tb) {"]
+        for tb, (ln, body) in enumerate(self.term_blocks):
+            leaves = sorted({(node[1], node[2]) for node in _leaves(eg, body, ("P",))})
+            L.append("        case %d: {" % tb)
+            L.append("            int q = -1;")
+            for base, stride in leaves:
+                if stride == 0:
+                    L.append("            if (j == %d) return -2;" % base)
+                elif stride == 1:
+                    L.append("            if (j >= %d && j < %d) { if (q >= 0 && q != j - %d) return -2; q = j - %d; }"
+                             % (base, base + ln, base, base))
+                else:
+                    L.append("            if (j >= %d && j <= %d && (j - %d) %% %d == 0) return -2;"
+                             % (min(base, base + stride * (ln - 1)), max(base, base + stride * (ln - 1)), base, stride))
+            L += ["            return q;", "        }"]
+        L += ["        default: return -2;", "        }", "    }",
+              # an accessor with term_cache()/term_q()/term_v() members supplies cached terms; any other: in place
+              "    template <class X> OG_HDI static auto term_cache_of(const X& x, const int tb, int) -> "
+              "decltype(x.term_cache(tb)) { return x.term_cache(tb); }",
+              "    template <class X> OG_HDI static const double* term_cache_of(const X&, const int, long) { return nullptr; }",
+              "    template <class X> OG_HDI static auto term_q_of(const X& x, const int tb, int) -> "
+              "decltype(x.term_q(tb)) { return x.term_q(tb); }",
+              "    template <class X> OG_HDI static int term_q_of(const X&, const int, long) { return -1; }",
+              "    template <class X> OG_HDI static auto term_v_of(const X& x, const int tb, int) -> "
+              "decltype(x.term_v(tb)) { return x.term_v(tb); }",
+              "    template <class X> OG_HDI static typename X::scalar term_v_of(const X&, const int, long) "
+              "{ return typename X::scalar(0.0); }"]
+        return L
 
     def group_function(self, gi, grp):
         if grp.kind == "defect":
@@ -631,7 +707,8 @@ class _Emitter:
                      "        typedef typename X::scalar S;",
                      "        (void)k; (void)cv;"]
             names = {}
-            self._emit_sums(grp.tails, lines, names, 8)
+            if self._emit_sums(grp.tails, lines, names, 8):
+                self.sum_groups.add(gi)
             self._emit_expr(grp.tails, "k", lines, names, 8, {})
             for s, e in enumerate(grp.tails):
                 lines.append("        T[%d] = %s;" % (s, names[e]))
@@ -661,7 +738,8 @@ class _Emitter:
                      "        typedef typename X::scalar S;",
                      "        (void)k; (void)cv;"]
             names = {}
-            self._emit_sums(roots, lines, names, 8)
+            if self._emit_sums(roots, lines, names, 8):
+                self.sum_groups.add(gi)
             self._emit_expr(roots, "k", lines, names, 8, {})
             lines += ["        return %s;" % names[roots[0]], "    }",
                       "    template <class X> OG_HDI static void group%d(const int k, const X& x, "
@@ -673,7 +751,8 @@ class _Emitter:
                  "        typedef typename X::scalar S;",
                  "        (void)k; (void)y; (void)cv;"]
         names = {}
-        self._emit_sums(roots, lines, names, 8)
+        if self._emit_sums(roots, lines, names, 8):
+            self.sum_groups.add(gi)
         self._emit_expr(roots, "k", lines, names, 8, {})
         for o, (_, e) in enumerate(grp.outputs):
             lines.append("        out[%d] = %s;" % (o, names[e]))
@@ -867,6 +946,8 @@ def emit_header(P):
         L.append("")
     L += em.operand_function()
     L.append("")
+    L += em.term_functions()
+    L.append("")
     L.append("    template <class X> OG_HDI static void defect_tail(const int g, const int k, "
              "const X& x, const double* cv, typename X::scalar* T) {")
     L.append("        switch (g) {")
@@ -930,7 +1011,7 @@ def emit_header(P):
         L.append("        case %d: group%d(k, x, y, cv, out); break;" % (gi, gi))
     L += ["        default: break;", "        }", "    }", "};", ""]
     L += _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, slot_group,
-                        y0_off, mv_diag, mv_generic, g_dep0, g_ndep, light_groups)
+                        y0_off, mv_diag, mv_generic, g_dep0, g_ndep, light_groups, em.sum_groups)
     return "\n".join(L)
 
 
@@ -938,7 +1019,7 @@ SWEEP_WAVES = 8          # wavefronts per ogk_sweep workgroup (csrc/ogk_kernels.
 
 
 def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, slot_group, y0_off,
-                   mv_diag, mv_generic, g_dep0, g_ndep, light_groups):
+                   mv_diag, mv_generic, g_dep0, g_ndep, light_groups, sum_groups=()):
     """Wide, aligned device tables so that a workgroup of the structured sweep learns everything
     about its column / item / MFMA tile from ONE load each (every dependent global load costs
     a few hundred cycles, and the sweep of a small problem is a chain of them)."""
@@ -965,7 +1046,7 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     for gi, g in enumerate(P.groups):
         if g.kind == "rows":
             for k0 in range(0, g.length, 64):
-                rowwaves.append([gi, k0, g.length, 0])
+                rowwaves.append([gi, k0, g.length, 1 if gi in sum_groups else 0])   # .w: its code contains a sum
     evalblk = []
     for gi, g in enumerate(P.groups):
         if g.kind == "defect":
@@ -982,11 +1063,14 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     for j0, cnt, key in light_groups:
         for c in range(fused_cols(P.n)):
             lrng.append([col_ptr[j0 + c], col_ptr[j0 + c + 1], 0, 0] if c < cnt else [0, 0, 0, 0])
+        # bit 16 of the last field: some item of the workgroup contains a sum (base terms are then cached in LDS)
+        terms = int(any(elem_g[e] in sum_groups for e in range(col_ptr[j0], col_ptr[j0 + cnt]))) << 16
         if key:
             g = P.groups[key[0]]
-            lgrp.append([j0, cnt, y0_off[g.mv_slots[0]], key[1], g.mv_slots[0], len(g.mv_slots), g.length, g.phase])
+            lgrp.append([j0, cnt, y0_off[g.mv_slots[0]], key[1], g.mv_slots[0], len(g.mv_slots), g.length,
+                         g.phase | terms])
         else:
-            lgrp.append([j0, cnt, 0, 0, 0, 0, 0, 0])
+            lgrp.append([j0, cnt, 0, 0, 0, 0, 0, terms])
     # heavy columns of the fused launch are cut into parts that look like light workgroups: one part per
     # (defect group, 16-node tile) the column has items in - the tile's D^T panel and the group's operands go
     # through LDS, one wavefront runs the tile's base products - plus one tile-less part for its row items.
@@ -1007,7 +1091,7 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
                 hslot.append([len(helem), len(ks), 0, 0])
                 helem += [[gi, o, k, g.outputs[o][0] + k] for k in sorted(ks)]
             hpart.append([j, first_slot, len(hslot), y0_off[g.mv_slots[0]], nt_, g.mv_slots[0], len(g.mv_slots),
-                          g.length | (g.phase << 20)])
+                          g.length | (g.phase << 20) | ((1 << 30) if gi in sum_groups else 0)])
         rows_by_group = {}
         for gi, o, k in entries:
             if P.groups[gi].kind != "defect":
@@ -1020,7 +1104,8 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
                     chunk = ks[c0:c0 + 32]
                     hslot.append([len(helem), len(chunk), 0, 0])
                     helem += [[gi, o, k, P.groups[gi].outputs[max(o, 0)][0] + k] for k in chunk]
-            hpart.append([j, first_slot, len(hslot), 0, 0, 0, 0, 0])
+            hpart.append([j, first_slot, len(hslot), 0, 0, 0, 0,
+                          (1 << 30) if any(gi in sum_groups for gi, _ in rows_by_group) else 0])
     L += ["struct ogt_int8 { int v[8]; };",
           "static __device__ const ogt_int8 OGT_HPART[%d] = {" % max(len(hpart), 1),
           ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (hpart or [[0] * 8])),

@@ -92,6 +92,62 @@ struct XColL {
     __device__ __forceinline__ double ldy(const double* p) const { return yl[(int)(p - y0_first)]; }
 };
 
+// XCol with the base terms of the program's sequential sums (a running cost summed node by node like Python's
+// sum()) at hand: the workgroup computed them once, cooperatively, into LDS; a lane re-evaluates only the term
+// that reads its own perturbed variable.  The additions stay with the caller, in order - same bits, but a
+// chain of LDS reads and adds instead of N evaluations with their global loads per lane.
+constexpr int TB_SLOTS = OgGen::N_TBLK > 0 ? OgGen::N_TBLK : 1;
+struct XColT {
+    typedef double scalar;
+    const double* x0;
+    int j;
+    double xj;
+    const double* tc;           // [N_TERMS] base terms in LDS, or NULL: evaluate in place
+    int qd[TB_SLOTS];           // per term block: the term that reads p[j] (-1 none, -2 several: in place)
+    double td[TB_SLOTS];        // ... and its value at x0 + h e_j
+    __device__ __forceinline__ double operator()(const int i) const {
+        const double v = x0[i];
+        return i == j ? xj : v;
+    }
+    __device__ __forceinline__ double ldy(const double* p) const { return *p; }
+    __device__ __forceinline__ const double* term_cache(const int tb) const {
+        return (tc && qd[tb] != -2) ? tc + OgGen::TERM_OFF(tb) : nullptr;
+    }
+    __device__ __forceinline__ int term_q(const int tb) const { return qd[tb]; }
+    __device__ __forceinline__ double term_v(const int tb) const { return td[tb]; }
+};
+__device__ __forceinline__ XColT make_xcolt(const ogk_args& a, const int j, const double xj, const double* tc) {
+    XColT x;
+    x.x0 = a.x0, x.j = j, x.xj = xj, x.tc = tc;
+    const XCol plain{a.x0, j, xj};
+#pragma unroll
+    for (int tb = 0; tb < TB_SLOTS; ++tb) {
+        x.qd[tb] = -1, x.td[tb] = 0.0;
+        if (tc && tb < OgGen::N_TBLK && j >= 0) {
+            x.qd[tb] = OgGen::sum_term_q(tb, j);
+            if (x.qd[tb] >= 0) x.td[tb] = OgGen::sum_term(tb, x.qd[tb], plain, a.cvec);
+        }
+    }
+    return x;
+}
+constexpr bool TERM_CACHE = OgGen::N_TERMS > 0 && OgGen::N_TERMS <= 2048;      // LDS doubles a workgroup spends on it
+constexpr int TERM_DOUBLES = TERM_CACHE ? OgGen::N_TERMS : 0;
+
+// all threads of a workgroup: the base terms into LDS (the caller's barrier publishes them)
+template <int THREADS>
+__device__ __forceinline__ void fill_terms(const ogk_args& a, double* tc) {
+    struct XBase {
+        typedef double scalar;
+        const double* x0;
+        __device__ __forceinline__ double operator()(const int i) const { return x0[i]; }
+    };
+    const XBase xb{a.x0};
+#pragma unroll
+    for (int tb = 0; tb < OgGen::N_TBLK; ++tb)
+        for (int q = (int)threadIdx.x; q < OgGen::TERM_LEN(tb); q += THREADS)
+            tc[OgGen::TERM_OFF(tb) + q] = OgGen::sum_term(tb, q, xb, a.cvec);
+}
+
 // Persistent-zero output (ogk.h: jt_sparse / jt_gen / jt_state).  A buffer that is known to hold zeros at
 // its structural zeros is only written where something can be non-zero; the fill is needed when the
 // buffer is not registered, or when the previous launch into it left a NaN fill behind.
@@ -454,21 +510,28 @@ __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx
         v4f64 acc = {0.0, 0.0, 0.0, 0.0};
         const double* xrow = xt + (srow < OgGen::MAX_NMV ? srow : 0) * NP;
         const bool live = srow < nmv;
-        int ks = 0;
-        for (; ks + 4 <= KS; ks += 4) {
-            double av[4], bv[4];
+        // LDS operands of the next chunk are requested before this chunk's MFMAs issue
+        constexpr int CH = 8;
+        double bv[CH], av[CH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                av[u] = live ? xrow[(ks + u) * 4 + lk] : 0.0;
-                bv[u] = dpanel[(ks + u) * 64 + lane];
+        for (int u = 0; u < CH; ++u) {
+            bv[u] = u < KS ? dpanel[u * 64 + lane] : 0.0;
+            av[u] = (u < KS && live) ? xrow[u * 4 + lk] : 0.0;
+        }
+        for (int ks0 = 0; ks0 < KS; ks0 += CH) {
+            double bn[CH], an[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int ks = ks0 + CH + u;
+                bn[u] = ks < KS ? dpanel[ks * 64 + lane] : 0.0;
+                an[u] = (ks < KS && live) ? xrow[ks * 4 + lk] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < CH; ++u)
+                if (ks0 + u < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { bv[u] = bn[u]; av[u] = an[u]; }
         }
-        for (; ks < KS; ++ks)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(live ? xrow[ks * 4 + lk] : 0.0,
-                                                       dpanel[ks * 64 + lane], acc, 0, 0, 0);
         // C/D layout: node = lane & 15, state = (lane >> 4) + 4 * reg
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) ybuf[(lk + 4 * reg) * 16 + (lane & 15)] = acc[reg];
@@ -497,13 +560,27 @@ __device__ __forceinline__ void eval_defect_body(const ogk_args& a, const int bx
 }
 
 template <bool FUSED>
-__device__ __forceinline__ void eval_rows_body(const ogk_args& a, const int bx) {
+__device__ __forceinline__ void eval_rows_body(const ogk_args& a, const int bx, double* lds) {
+    // a row whose code contains a sequential sum (the cost with its running-cost quadrature) would be one lane
+    // evaluating every term with its loads: the workgroup computes the terms into LDS first
+    bool terms = false;
+    if (TERM_CACHE) {
+#pragma unroll
+        for (int u = 0; u < SWEEP_WAVES; ++u) {
+            const int w2 = bx * SWEEP_WAVES + u;
+            if (w2 < OGT_N_ROWWAVES) terms = terms || OGT_ROWWAVE[w2].w != 0;
+        }
+        if (terms) {                                      // workgroup-uniform
+            fill_terms<SWEEP_THREADS>(a, lds);
+            __syncthreads();
+        }
+    }
     const int w = bx * SWEEP_WAVES + ((int)threadIdx.x >> 6);
     if (w >= OGT_N_ROWWAVES) return;
-    const int4 rw = OGT_ROWWAVE[w];                       // {group, first element, group length}
+    const int4 rw = OGT_ROWWAVE[w];                       // {group, first element, group length, has a sum}
     const int k = rw.y + ((int)threadIdx.x & 63);
     if (k >= rw.z) return;
-    const XCol base{a.x0, -1, 0.0};
+    const XColT base = make_xcolt(a, -1, 0.0, terms ? lds : nullptr);
     int row;
     const double v = OgGen::item_value(rw.x, 0, k, base, a.y0, a.cvec, &row);
     publish_row<FUSED>(a, row, v);
@@ -516,7 +593,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, cons
     // makes this visible to the next launch)
     if (id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
     if (id < ndef) eval_defect_body<false>(a, id, lds);
-    else eval_rows_body<false>(a, id - ndef);
+    else eval_rows_body<false>(a, id - ndef, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -985,7 +1062,9 @@ constexpr int FZ_ROUNDS = 2;                                    // items per col
 constexpr int FZ_ITEM_WAVES = SWEEP_WAVES - 1;                 // item slots of a light workgroup (the last wavefront
                                                                // runs the MFMA chain instead)
 // LDS of a light workgroup: D panel of the tile [KS][64] | operands [state][NP] | base products [state][N]
-constexpr size_t FZ_LDS_BYTES = ((size_t)(FZ_NP / 4) * 64 + (size_t)OgGen::MAX_NMV * (FZ_NP + FZ_MAXN)) * sizeof(double);
+constexpr size_t FZ_TILE_DOUBLES = (size_t)(FZ_NP / 4) * 64 + (size_t)OgGen::MAX_NMV * (FZ_NP + FZ_MAXN);
+// ... | base terms of the program's sequential sums [N_TERMS] (workgroups with such items)
+constexpr size_t FZ_LDS_BYTES = (FZ_TILE_DOUBLES + TERM_DOUBLES) * sizeof(double);
 
 // flag the service wavefront raises in LDS for the other wavefronts of its workgroup
 __device__ __forceinline__ void lds_flag_raise(int* flag, const int value) {
@@ -1068,7 +1147,9 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
     //  items), nodes, phase}
     const ogt_int8 grp = OGT_LGRP[b];
     const int first_j = grp.v[0], cnt = grp.v[1], y0_first = grp.v[2], nt = grp.v[3];
-    const int mv0 = grp.v[4], nmv = grp.v[5], N = grp.v[6], phase = grp.v[7];
+    const int mv0 = grp.v[4], nmv = grp.v[5], N = grp.v[6], phase = grp.v[7] & 0xffff;
+    const bool terms = TERM_CACHE && (grp.v[7] >> 16) != 0;     // some item contains a sequential sum
+    double* tc = lds + FZ_TILE_DOUBLES;
     const bool has_tile = nmv > 0;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1089,6 +1170,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
     const FzTile t = fz_tile_lds(lds);
     if (tid == 0) s_flag = 0;
     if (has_tile && !(OGK_FZ & 4)) fz_stage_tile(a, t, nt, mv0, nmv, N, phase);
+    if (terms) fill_terms<SWEEP_THREADS>(a, tc);
     lds_barrier();            // (only LDS data crosses it: global loads in flight stay in flight)
     FZ_STAMP(1);
     if (service) {
@@ -1105,7 +1187,7 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
         const double xj = xb + hh;
         const double dx = xj - xb;
         double* jrow = a.jt + (long)(ji - a.col_lo) * OgGen::M;
-        const XCol xa{a.x0, base_role ? -1 : ji, xj};
+        const XColT xa = make_xcolt(a, base_role ? -1 : ji, xj, terms ? tc : nullptr);
         // The long part of an item - its dynamics term, or the whole value of a row item - does not depend on
         // the base products: the first FZ_ROUNDS items of every column are evaluated while the service
         // wavefront is still in its chain; only the subtraction from the product waits for the flag.
@@ -1148,7 +1230,9 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
     const int j = rec.v[0];
     if (j < a.col_lo || j >= a.col_hi) return;
     const int y0_first = rec.v[3], nt = rec.v[4], mv0 = rec.v[5], nmv = rec.v[6];
-    const int N = rec.v[7] & 0xfffff, phase = rec.v[7] >> 20;
+    const int N = rec.v[7] & 0xfffff, phase = (rec.v[7] >> 20) & 0x3ff;
+    const bool terms = TERM_CACHE && ((rec.v[7] >> 30) & 1) != 0;
+    double* tc = lds + FZ_TILE_DOUBLES;
     const bool has_tile = nmv > 0;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1166,6 +1250,7 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
     const FzTile t = fz_tile_lds(lds);
     if (tid == 0) s_flag = 0;
     if (has_tile) fz_stage_tile(a, t, nt, mv0, nmv, N, phase);
+    if (terms) fill_terms<SWEEP_THREADS>(a, tc);
     lds_barrier();
     FZ_STAMP(1);
     if (service) {
@@ -1182,7 +1267,7 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
         const double xj = xb + hh;
         const double dx = xj - xb;
         double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
-        const XCol xa{a.x0, base_role ? -1 : j, xj};
+        const XColT xa = make_xcolt(a, base_role ? -1 : j, xj, terms ? tc : nullptr);
         // as in the light workgroups: the items' long chains run while the service wavefront is in its own
         for (int s0 = rec.v[1] + wave; s0 < rec.v[2]; s0 += FZ_ROUNDS * FZ_ITEM_WAVES) {
             double tv[FZ_ROUNDS];
@@ -1221,7 +1306,7 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
 // ONCE per workgroup by the last wavefront (and the one before it when it is free), in parallel, and handed
 // over through LDS; the column wavefronts meet it only at their epilogue.
 __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, double* lds) {
-    __shared__ int s_flags[2];          // [0] base products of the node tile, [1] base dynamics terms
+    __shared__ int s_flags[3];          // [0] base products of the node tile, [1] base dynamics terms, [2] diagonal terms
     FZ_TRACE_DECL(3);
     const int4 tile = OGT_FTILE[bx];                   // {slot, first column tile, node tile, column tiles}
     const int slot = tile.x, ct0 = tile.y, nt = tile.z, nct = tile.w;
@@ -1235,16 +1320,21 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
     double* xt = lds;                                   // [NP] the slot's operand vector
     double* yb = lds + FZ_NP;                           // [16] base products of the node tile
     double* tb = yb + 16;                               // [16] base dynamics terms
+    double* td = tb + 16;                               // [16] dynamics terms with the node's own sample perturbed
     const XCol xbase{a.x0, -1, 0.0};
     for (int l = tid; l < KS * 4; l += SWEEP_THREADS)
         xt[l] = l < N ? OgGen::mv_operand(slot, l, xbase, a.cvec) : 0.0;
-    if (tid < 2) s_flags[tid] = 0;
+    if (tid < 3) s_flags[tid] = 0;
     const int k = nt * 16 + kk;                         // output node of this lane
     const bool k_on = k < N;
     const double* bsrc = a.dfrag + a.dfrag_off[rec.v[5]] + (long)nt * KS * 64 + lane;
     constexpr int CH = 10;                              // k-steps per chunk
     const int prod_wave = SWEEP_WAVES - 1;
     const int term_wave = nct < SWEEP_WAVES - 1 ? SWEEP_WAVES - 2 : SWEEP_WAVES - 1;
+    // the diagonal column tile (perturbed node = output node) also needs the dynamics term at x0 + h e_j for its
+    // 16 (node, own sample) pairs: a third free wavefront takes that chain off the column wavefront's path
+    const bool diag_here = diag && nt >= ct0 && nt < ct0 + nct;
+    const int diag_wave = nct < SWEEP_WAVES - 2 ? SWEEP_WAVES - 3 : -1;
     const bool col_wave = wave < nct;
     double bv[CH];
     if (col_wave || wave == prod_wave) {
@@ -1254,6 +1344,15 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
     lds_barrier();
     FZ_STAMP(1);
     if (!col_wave) {
+        if (wave == diag_wave) {
+            if (diag_here && lk == 0 && k_on && leaf + k >= a.col_lo && leaf + k < a.col_hi) {
+                const int jd = leaf + k;
+                const double xbd = a.x0[jd];
+                const XCol xd{a.x0, jd, xbd + a.h[jd]};
+                td[kk] = OgGen::tail_one(slot, k, xd, a.cvec);
+            }
+            if (lane == 0) lds_flag_raise(&s_flags[2], 1);
+        }
         if (wave == term_wave && lk == 0) tb[kk] = k_on ? OgGen::tail_one(slot, k, xbase, a.cvec) : 0.0;
         if (wave == term_wave && lane == 0) lds_flag_raise(&s_flags[1], 1);
         if (wave == prod_wave) {
@@ -1304,7 +1403,7 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
         const int reg = (lc - l0 - lk) >> 2;
         have_diag = diag && k_on && lc >= l0 + lk && ((lc - l0 - lk) & 3) == 0 && reg < 4 && lc < N &&
                     leaf + lc >= a.col_lo && leaf + lc < a.col_hi;
-        if (have_diag) {
+        if (have_diag && diag_wave < 0) {               // no free wavefront in this workgroup: own chain
             const int jd = leaf + lc;
             const double xbd = a.x0[jd];
             const XCol xd{a.x0, jd, xbd + a.h[jd]};
@@ -1338,6 +1437,10 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
     FZ_STAMP(2);
     lds_flag_wait(&s_flags[1]);
     lds_flag_wait(&s_flags[0]);
+    if (diag_wave >= 0 && l0 == nt * 16) {              // (the diagonal tile: wavefront-uniform)
+        lds_flag_wait(&s_flags[2]);
+        if (have_diag) t_diag = td[kk];
+    }
     FZ_STAMP(3);
     if (!k_on) return;
     const double t_base = tb[kk];
@@ -1369,7 +1472,10 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
     FZ_TRACE_OUT(a);
 }
 
-__global__ __launch_bounds__(SWEEP_THREADS) void ogk_fused(const ogk_args a, const int ndef, const int n_eval,
+#ifndef OGK_FUSED_ATTR
+#define OGK_FUSED_ATTR
+#endif
+__global__ __launch_bounds__(SWEEP_THREADS) OGK_FUSED_ATTR void ogk_fused(const ogk_args a, const int ndef, const int n_eval,
                                                            const int group_lo, const int n_light) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int id = (int)blockIdx.x;
@@ -1378,7 +1484,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_fused(const ogk_args a, con
         if (id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
         if (!(OGK_FZ & 16)) {
             if (id < ndef) eval_defect_body<true>(a, id, lds);
-            else eval_rows_body<true>(a, id - ndef);
+            else eval_rows_body<true>(a, id - ndef, lds);
         }
         FZ_STAMP(1);
         finish_eval(a, (unsigned)n_eval, reinterpret_cast<unsigned*>(lds));
@@ -1488,7 +1594,8 @@ size_t defect_lds_bytes() {
         const size_t need = ((size_t)KS * 64 + (size_t)OgGen::MAX_NMV * KS * 4 + 256) * sizeof(double);
         worst = need > worst ? need : worst;
     }
-    return worst;
+    const size_t terms = (size_t)TERM_DOUBLES * sizeof(double);      // evaluation row blocks: cached sum terms
+    return worst > terms ? worst : terms;
 }
 
 size_t sweep_lds_bytes() { return (size_t)LIGHT_COLS * ROW_WORDS * sizeof(unsigned); }

@@ -291,6 +291,7 @@ def test_fused_launch_work_lists_partition_the_sweep(name):
     heavy = {j for j in range(P.n) if col[j][3] & (1 << 30)}
     owner = {}
     for b, (j0, cnt, y0off, nt, mv0, nmv, N, phase) in enumerate(lgrp):
+        phase &= 0xffff                              # (bit 16: an item of the workgroup contains a sequential sum)
         assert 1 <= cnt <= cols
         for c in range(cnt):
             j = j0 + c
@@ -306,7 +307,7 @@ def test_fused_launch_work_lists_partition_the_sweep(name):
     n_hpart = int(re.search(r"OGT_N_HPART = (\d+)", src).group(1))
     for j, s0, s1, y0off, nt, mv0, nmv, packed in hpart[:n_hpart]:
         assert j in heavy and s1 > s0
-        N, phase = packed & 0xfffff, packed >> 20
+        N, phase = packed & 0xfffff, (packed >> 20) & 0x3ff       # (bit 30: contains a sequential sum)
         for e0, cnt, _, _ in hslot[s0:s1]:
             assert 0 < cnt <= 32
             items = helem[e0:e0 + cnt]

@@ -335,3 +335,21 @@ def test_fused_launch_work_lists_partition_the_sweep(name):
         t16 = (rec[0] + 15) // 16
         want |= {(si, c, nt) for c in range(t16) for nt in range(t16)}
     assert covered == want
+
+
+@pytest.mark.parametrize("name", ["goddard", "polar_tsto_shipped", "table_ascent", "low_thrust_shipped"])
+def test_batch_last_baseline_matches_the_column_loop(name):
+    """oracle/batch_last.py (bench.py's cpu_baseline_batch_last): ONE evaluation of the unmodified callbacks on
+    an (n, B) array must give SciPy's column loop within the forward-difference noise floor - the same F(x0)
+    to a few ulp (D @ X is one GEMM instead of n GEMVs) and a Jacobian within 5e-7 of max|J|."""
+    from oracle import batch_last
+    prob, obj = problems.build(name)
+    pb, ob = batch_last.build(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    x = np.clip(prob.p, lb, ub)
+    cols = np.arange(0, x.size, 3)
+    F0, h, JT = np_path.sweep(prob, obj, x, cols)
+    G0, h2, KT = batch_last.sweep(pb, ob, x, cols)
+    assert np.array_equal(h, h2)
+    assert np.all(np.abs(F0 - G0) <= 1e-11 * np.maximum(1.0, np.abs(F0)))
+    assert np.abs(JT - KT).max() <= 5e-7 * np.abs(JT).max()          # SURVEY.md 7.4: 2e-8..1e-7 of max|J| observed

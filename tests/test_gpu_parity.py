@@ -582,6 +582,70 @@ def test_hardware_probe():
     assert out.returncode == 0, out.stdout
 
 
+def test_cabi_error_paths_of_the_round2_entry_points():
+    """Registration, pattern, pack / unpack, shard and multi-device entry points report misuse through return
+    codes + og_last_error(), never by crashing."""
+    import ctypes as C
+    import torch
+    from opengoddard_amd.engine import HipEngine
+    lib = _native.lib()
+    prob, obj = problems.build("brachistochrone")
+    eng = HipEngine(prob, obj)
+    n, m, hnd = eng.n, eng.m, eng._handle
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros((n, m), dtype=torch.float64, device=dev)
+    vals = torch.zeros(n * m, dtype=torch.float64, device=dev)
+    err = lambda: lib.og_last_error()
+    assert lib.og_jt_register_dev(hnd, None, 0, n, None) != 0 and b"null" in err()
+    assert lib.og_jt_register_dev(hnd, buf.data_ptr(), 3, 3, None) != 0 and b"bad column range" in err()
+    assert lib.og_jt_register_dev(hnd, buf.data_ptr(), 0, n + 1, None) != 0
+    assert lib.og_jt_unregister_dev(hnd, buf.data_ptr()) != 0 and b"not registered" in err()
+    assert lib.og_jt_register_dev(hnd, buf.data_ptr(), 0, n, None) == 0
+    assert lib.og_jt_register_dev(hnd, buf.data_ptr(), 0, n // 2, None) == 0          # re-registration: new range
+    assert lib.og_jt_unregister_dev(hnd, buf.data_ptr()) == 0
+    host = np.empty((n, m))
+    assert lib.og_jt_register_host(hnd, None, 0, n) != 0
+    assert lib.og_jt_register_host(hnd, _native.dptr(host), 0, 0) != 0 and b"bad column range" in err()
+    assert lib.og_jt_unregister_host(hnd, _native.dptr(host)) != 0 and b"not registered" in err()
+    nnz = C.c_int64(-1)
+    assert lib.og_pattern(hnd, 5, 2, C.byref(nnz), None, None) != 0 and b"bad column range" in err()
+    assert lib.og_pattern(hnd, 4, 4, C.byref(nnz), None, None) == 0 and nnz.value == 0
+    assert lib.og_pack_dev(hnd, None, 0, n, vals.data_ptr(), None) != 0
+    assert lib.og_pack_dev(hnd, buf.data_ptr(), -1, n, vals.data_ptr(), None) != 0
+    assert lib.og_unpack_dev(hnd, vals.data_ptr(), 0, n + 1, buf.data_ptr(), None) != 0
+    assert lib.og_shard_pack_dev(hnd, 0, buf.data_ptr(), vals.data_ptr(), None) != 0 and b"no shard plan" in err()
+    assert lib.og_shard_plan(hnd, 0, None, None) != 0
+    B, bv = C.c_int32(), C.c_int64()
+    assert lib.og_shard_plan(hnd, 3, C.byref(B), C.byref(bv)) == 0 and B.value == -(-n // 3) and bv.value > 0
+    assert lib.og_shard_pack_dev(hnd, 3, buf.data_ptr(), vals.data_ptr(), None) != 0 and b"rank out of range" in err()
+    # unpack into a replica whose own block was never registered
+    assert lib.og_shard_unpack_dev(hnd, 1, vals.data_ptr(), buf.data_ptr(), None) != 0 and b"not a registered" in err()
+    # more ranks than columns: trailing ranks own nothing and still plan / pack / unpack
+    assert lib.og_shard_plan(hnd, n + 5, C.byref(B), C.byref(bv)) == 0 and B.value == 1
+    assert lib.og_shard_pack_dev(hnd, n + 4, buf.data_ptr(), vals.data_ptr(), None) == 0
+    lib.og_comm_finalize()
+    mh = C.c_void_p()
+    assert lib.og_multi_create(None, C.byref(mh)) != 0
+    desc = _native.OgDesc(abi_version=_native.OG_ABI_VERSION, device=0, n=n, m_eq=eng.m_eq, m_ineq=eng.m_ineq,
+                          n_phase=1, nodes=eng._nodes, D=eng._Dptr, cvec=None, n_cvec=int(eng._cvec.size),
+                          module_path=eng.module_path.encode())
+    assert lib.og_multi_create(C.byref(desc), C.byref(mh)) != 0 and b"og_comm_init first" in err()
+    bad = (C.c_int32 * 2)(0, 99)
+    assert lib.og_comm_init(2, bad) != 0 and b"out of range" in err()
+    twice = (C.c_int32 * 2)(0, 0)
+    os_env = __import__("os").environ
+    saved = os_env.pop("OGPSX_GATHER", None)
+    assert lib.og_comm_init(2, twice) != 0 and b"listed twice" in err()
+    if saved is not None:
+        os_env["OGPSX_GATHER"] = saved
+    assert lib.og_comm_size() == 0 or lib.og_comm_size() == 2
+    lib.og_comm_finalize()
+    assert lib.og_multi_fd_sweep(None, None, None, None, None) != 0
+    assert lib.og_trace_read(hnd, _native.dptr(host), 8) != 0 and b"OGPSX_TRACE" in err()
+    torch.cuda.synchronize()
+    eng.close()
+
+
 def test_cabi_error_paths_on_device(golden):
     """The C ABI reports misuse through return codes + og_last_error(), never by crashing."""
     import ctypes as C

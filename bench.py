@@ -225,6 +225,8 @@ def main():
     x0 = np.clip(prob.p, lb, ub)
     h = _native.fd_step(x0, lb, ub)
     backend = sharding.HipBackend(eng, dev)
+    if collective and not os.environ.get("OG_BENCH_TORCH_ALLGATHER"):
+        backend.init_direct_rccl(rank, world)       # ncclCommInitRank in libogpsx.so; falls back by itself
     d_x, d_h = backend.upload(x0), backend.upload(h)
     stream = backend.stream
     # Output buffers: every rank keeps full n x m replicas of J_T that were zeroed once; its own block of rows is
@@ -348,8 +350,8 @@ def main():
             "n": n, "m_eq": eng.m_eq, "m_ineq": eng.m_ineq,
             "evals_per_step": 3 * n + 2,
             "output_buffers": "%d registered persistent-zero replicas of %.1f MB in rotation" % (nbuf, replica_bytes / 1e6),
-            "parallelism": "fd-columns x%d%s" % (world, " + RCCL all-gather of the packed non-zeros (%d bytes per rank)"
-                                                  % sweeps[0].message_bytes if collective else "")},
+            "parallelism": "fd-columns x%d%s" % (world, " + RCCL all-gather of the packed non-zeros (%d bytes per rank; %s)"
+                                                  % (sweeps[0].message_bytes, backend.direct_note) if collective else "")},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None,

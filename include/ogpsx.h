@@ -155,6 +155,17 @@ int og_unpack_dev(og_handle h, const double* d_vals, int32_t col_lo, int32_t col
  * Call order per step on one stream: og_fd_sweep_dev (own block), og_shard_pack_dev, all-gather,
  * og_shard_unpack_dev.  Results are bitwise independent of `world`. */
 int og_shard_plan(og_handle h, int32_t world, int32_t* block_cols, int64_t* block_vals);
+/* The all-gather itself, for one process per GPU, on the caller's stream with no detour through another
+ * runtime's streams: rank 0 makes a unique id (og_shard_comm_unique_id: 128 bytes = ncclGetUniqueId), the
+ * launcher hands it to every rank (bench.py: torch.distributed.broadcast), every rank calls og_shard_comm_init
+ * (ncclCommInitRank on the handle's device; also makes the shard plan for `world`), and per step
+ * og_shard_all_gather_dev = ncclAllGather of *block_vals doubles from d_send into d_recv (world * *block_vals).
+ * librccl is resolved at run time (the copy already in the process wins).  og_problem_destroy destroys the
+ * communicator. */
+int og_shard_comm_unique_id(uint8_t* id128);
+int og_shard_comm_init(og_handle h, const uint8_t* id128, int32_t rank, int32_t world);
+void og_shard_comm_destroy(og_handle h);
+int og_shard_all_gather_dev(og_handle h, const double* d_send, double* d_recv, void* hip_stream);
 int og_shard_pack_dev(og_handle h, int32_t rank, const double* d_JT_block, double* d_send, void* hip_stream);
 int og_shard_unpack_dev(og_handle h, int32_t rank, const double* d_recv, double* d_JT_full, void* hip_stream);
 

@@ -122,6 +122,8 @@ struct og_problem_s {
     int shard_world = 0;
     int64_t shard_block_vals = 0;
     int64_t* d_shard_off = nullptr;
+    void* shard_comm = nullptr;         // ncclComm_t of this rank (og_shard_comm_init), one process per GPU
+    int shard_rank = -1;
 };
 static const int OG_MAX_JT_REGS = 63;
 static const size_t OG_TRACE_DOUBLES = (size_t)1 << 20;     // 16384 workgroups x 8 wavefronts x 8 stamps
@@ -510,6 +512,7 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
 void og_problem_destroy(og_handle p) {
     if (!p) return;
     hipSetDevice(p->device);
+    og_shard_comm_destroy(p);
     if (p->stream) hipStreamDestroy(p->stream);
     hipFree(p->d_dfrag);
     hipFree(p->d_cvec);
@@ -856,9 +859,12 @@ int og_jacobian_exact(og_handle p, const double* x, int32_t lo, int32_t hi, doub
 namespace {
 
 typedef void* ogn_comm;
+struct ogn_unique_id { char internal[128]; };      // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
 struct rccl_api {
     void* lib = nullptr;
     int (*CommInitAll)(ogn_comm*, int, const int*) = nullptr;
+    int (*GetUniqueId)(ogn_unique_id*) = nullptr;
+    int (*CommInitRank)(ogn_comm*, int, ogn_unique_id, int) = nullptr;
     int (*CommDestroy)(ogn_comm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ogn_comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -883,6 +889,8 @@ bool load_rccl(rccl_api* api) {
         if (!sym) continue;
         api->lib = lib;
         api->CommInitAll = (int (*)(ogn_comm*, int, const int*))sym;
+        api->GetUniqueId = (int (*)(ogn_unique_id*))dlsym(lib, "ncclGetUniqueId");
+        api->CommInitRank = (int (*)(ogn_comm*, int, ogn_unique_id, int))dlsym(lib, "ncclCommInitRank");
         api->CommDestroy = (int (*)(ogn_comm))dlsym(lib, "ncclCommDestroy");
         api->AllGather = (int (*)(const void*, void*, size_t, int, ogn_comm, hipStream_t))dlsym(lib, "ncclAllGather");
         api->GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
@@ -907,6 +915,55 @@ struct og_multi_s {
 };
 
 extern "C" {
+
+// ---- one process per GPU: this rank's own RCCL communicator (the launcher distributes the unique id) ----
+int og_shard_comm_unique_id(uint8_t* id128) {
+    if (!id128) return fail(1, "og_shard_comm_unique_id: null argument");
+    if (!g_comm.api.lib && !load_rccl(&g_comm.api)) return fail(7, "og_shard_comm_unique_id: librccl could not be loaded");
+    if (!g_comm.api.GetUniqueId) return fail(7, "og_shard_comm_unique_id: ncclGetUniqueId not found");
+    ogn_unique_id id;
+    const int rc = g_comm.api.GetUniqueId(&id);
+    if (rc != 0) return fail(7, std::string("og_shard_comm_unique_id: ") + (g_comm.api.GetErrorString ? g_comm.api.GetErrorString(rc) : "?"));
+    memcpy(id128, id.internal, sizeof id.internal);
+    return 0;
+}
+
+int og_shard_comm_init(og_handle p, const uint8_t* id128, int32_t rank, int32_t world) {
+    if (!p || !id128) return fail(1, "og_shard_comm_init: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(1, "og_shard_comm_init: bad rank / world");
+    if (!g_comm.api.lib && !load_rccl(&g_comm.api)) return fail(7, "og_shard_comm_init: librccl could not be loaded");
+    if (!g_comm.api.CommInitRank) return fail(7, "og_shard_comm_init: ncclCommInitRank not found");
+    if (p->shard_world != world) {
+        const int rcp = og_shard_plan(p, world, nullptr, nullptr);
+        if (rcp) return rcp;
+    }
+    og_shard_comm_destroy(p);
+    OG_HIP(hipSetDevice(p->device));
+    ogn_unique_id id;
+    memcpy(id.internal, id128, sizeof id.internal);
+    ogn_comm comm = nullptr;
+    const int rc = g_comm.api.CommInitRank(&comm, world, id, rank);
+    if (rc != 0) return fail(7, std::string("og_shard_comm_init: ncclCommInitRank: ") +
+                                    (g_comm.api.GetErrorString ? g_comm.api.GetErrorString(rc) : "?"));
+    p->shard_comm = comm;
+    p->shard_rank = rank;
+    return 0;
+}
+
+void og_shard_comm_destroy(og_handle p) {
+    if (p && p->shard_comm && g_comm.api.CommDestroy) g_comm.api.CommDestroy((ogn_comm)p->shard_comm);
+    if (p) p->shard_comm = nullptr;
+}
+
+int og_shard_all_gather_dev(og_handle p, const double* d_send, double* d_recv, void* hip_stream) {
+    if (!p || !d_send || !d_recv) return fail(1, "og_shard_all_gather_dev: null argument");
+    if (!p->shard_comm) return fail(1, "og_shard_all_gather_dev: call og_shard_comm_init first");
+    const int rc = g_comm.api.AllGather(d_send, d_recv, (size_t)p->shard_block_vals, OGN_FLOAT64, (ogn_comm)p->shard_comm,
+                                        (hipStream_t)hip_stream);
+    if (rc != 0) return fail(7, std::string("og_shard_all_gather_dev: ncclAllGather: ") +
+                                    (g_comm.api.GetErrorString ? g_comm.api.GetErrorString(rc) : "?"));
+    return 0;
+}
 
 int og_comm_init(int32_t G, const int32_t* devs) {
     if (G < 1 || !devs) return fail(1, "og_comm_init: need at least one device");

@@ -105,6 +105,53 @@ class HipBackend:
         _native.check(self._lib.og_shard_unpack_dev(self.engine._handle, int(rank), recv.data_ptr(),
                                                     replica.data_ptr(), self.stream), "og_shard_unpack_dev")
 
+    # ---- the exchange: RCCL directly on this backend's stream when a communicator could be made ----
+    direct = False
+    direct_note = "torch.distributed.all_gather_into_tensor"
+
+    def init_direct_rccl(self, rank, world, group=None):
+        """``ncclCommInitRank`` inside ``libogpsx.so`` (``og_shard_comm_init``): the all-gather then runs on the
+        stream the sweep, pack and unpack kernels are on, without the process group's own stream and events in
+        between.  The unique id travels through ``torch.distributed`` (any backend).  Falls back silently to
+        ``all_gather_into_tensor`` - every rank takes the same decision."""
+        import ctypes as C
+        import torch.distributed as dist
+        torch = self.torch
+        from . import _native
+        ok = 1
+        buf = (C.c_uint8 * 128)()
+        if rank == 0:
+            ok = 1 if self._lib.og_shard_comm_unique_id(buf) == 0 else 0
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.tensor([ok] + list(bytes(buf)), dtype=torch.int32, device=self.device if on_gpu else "cpu")
+        dist.broadcast(t, src=0, group=group)
+        host = t.cpu().tolist()
+        if host[0] == 1:
+            ident = (C.c_uint8 * 128)(*[int(v) & 0xff for v in host[1:]])
+            ok = 1 if self._lib.og_shard_comm_init(self.engine._handle, ident, int(rank), int(world)) == 0 else 0
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self.direct = bool(int(flag.item()) == 1)
+        if self.direct:
+            self.direct_note = "ncclAllGather on the sweep's stream (og_shard_all_gather_dev)"
+        else:
+            self._lib.og_shard_comm_destroy(self.engine._handle)
+            msg = self._lib.og_last_error()
+            self.direct_note = "torch.distributed.all_gather_into_tensor (direct RCCL unavailable: %s)" % (
+                msg.decode() if msg else "?")
+        return self.direct
+
+    def all_gather(self, send, recv, group=None):
+        if self.direct:
+            from . import _native
+            _native.check(self._lib.og_shard_all_gather_dev(self.engine._handle, send.data_ptr(), recv.data_ptr(),
+                                                            self.stream), "og_shard_all_gather_dev")
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(recv, send, group=group)
+
 
 class ShardedSweep:
     """One rank's share of the column-sharded sweep: ``step(x, h)`` leaves the WHOLE transposed Jacobian in
@@ -134,7 +181,10 @@ class ShardedSweep:
         if not gather or (self.world == 1 and not self.exchange_alone):
             return self.replica
         be.pack(self.rank, self.lo, self.hi, self.replica, self.send)
-        import torch.distributed as dist
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        if hasattr(be, "all_gather"):
+            be.all_gather(self.send, self.recv, group=self.group)
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         be.unpack(self.rank, self.recv, self.replica)
         return self.replica

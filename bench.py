@@ -282,6 +282,9 @@ def main():
     def timed(launch, reps, batch):
         pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                  for _ in range(reps)]
+        for _ in range(batch):                     # one untimed batch: the first launches after another phase
+            launch()                               # (a collective, a different kernel) are not representative
+        torch.cuda.synchronize()
         for e0, e1 in pairs:
             e0.record()
             for _ in range(batch):

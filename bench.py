@@ -423,6 +423,32 @@ def main():
         result["host_api_note"] = ("og_fd_sweep incl. H2D of x,h and D2H: host_api_ms_per_sweep into a registered "
                                    "persistent host matrix (packed non-zeros, %.2f MB), host_api_dense_transfer "
                                    "into a fresh n x m array (%.1f MB)" % (8e-6 * int(indptr[-1]), replica_bytes / 1e6))
+    if world == 1 and rank == 0 and fused and not a.quick:
+        # the same K steps as ONE hipGraph (the launch arguments are pointers only): what the loop costs without the
+        # host's per-launch work
+        try:
+            side = torch.cuda.Stream()
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                cs = torch.cuda.current_stream().cuda_stream
+                for i in range(a.steps):
+                    sh = sweeps[i % nbuf]
+                    eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, sh.replica[lo:hi].data_ptr(), sh.F0.data_ptr(), cs)
+            graph.replay()
+            torch.cuda.synchronize()
+            reps = []
+            for _ in range(a.reps):
+                t0 = time.perf_counter()
+                graph.replay()
+                torch.cuda.synchronize()
+                reps.append(time.perf_counter() - t0)
+            result["hip_graph_replay"] = {"ms_per_step_median": float(np.median(reps)) / a.steps * 1e3,
+                                          "ms_per_step_min": float(np.min(reps)) / a.steps * 1e3, "steps_per_graph": a.steps,
+                                          "evals_per_s": (3 * n + 2) * a.steps / float(np.median(reps))}
+            del graph
+        except Exception as exc:
+            result["hip_graph_replay"] = {"error": repr(exc)}
     if world == 1 and rank == 0 and not a.no_cpu_baseline and not a.quick:
         base = cpu_baseline(a.workload, "serial", a.cpu_seconds, a.nodes)
         base["compiled_cpp_dense_loop_evals_per_s"] = compiled_loop_context(a.workload, a.nodes)

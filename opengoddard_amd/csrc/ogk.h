@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define OGK_ABI 9
+#define OGK_ABI 10
 #define OGK_MAX_PHASE 32
 
 // MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
@@ -31,6 +31,7 @@ typedef struct ogk_info {
     int32_t n_y0;           // doubles of scratch for the unperturbed collocation products
     int32_t phase_nodes[OGK_MAX_PHASE];
     int32_t n_eval_blocks;  // evaluation workgroups of one launch (what the mode-5 ticket counts)
+    int32_t fused_ok;       // mode 5 runs as ONE launch on this module (its LDS fits); else the caller uses modes 0 + 1
 } ogk_info;
 
 typedef struct ogk_args {
@@ -50,12 +51,20 @@ typedef struct ogk_args {
     // Persistent-zero output (og_jt_register_dev, include/ogpsx.h).  jt_sparse != 0: the structural zeros of
     // `jt` are known to hold zeros already, so the sweep writes ONLY the positions that can be non-zero (row
     // items and collocation tiles).  The exception is kept on the device, because the asynchronous entry
-    // points never learn it: a sweep whose F(x0) has non-finite rows fills its rows completely (NaN where
-    // dense FD gives NaN) and stores its own generation number into *jt_state; the next sweep into the same
-    // buffer finds *jt_state == jt_gen - 1 and fills completely once more (zeros), which cleans it.
+    // points never learn it - and entirely on the device, so that the launch arguments are the same for
+    // every sweep into a buffer (a captured hipGraph can be replayed): jt_launches counts the launches into the
+    // buffer; a sweep whose F(x0) has non-finite rows fills its rows completely (NaN where dense FD gives NaN)
+    // and stores its own launch number into *jt_state; the next sweep finds *jt_state == its number - 1 and
+    // fills completely once more (zeros), which cleans the buffer.  Who counts: the last evaluation workgroup
+    // of a mode-5 launch (one thread); thread 0 of a mode-0 launch when jt_bump is set (the evaluation that
+    // precedes a mode 1 / 2 / 4 launch); a one-thread kernel (mode 10) before a lone mode-1 launch.
     int32_t jt_sparse;
-    uint32_t jt_gen;        // number of this launch among the launches into this registered buffer (1, 2, ...)
-    uint32_t* jt_state;     // generation of the last launch into the buffer that left NaN fill behind
+    int32_t jt_bump;        // mode 0: count one launch into *jt_launches
+    uint32_t* jt_launches;  // launches into the registered buffer so far
+    uint32_t* jt_state;     // number of the last launch into the buffer that left NaN fill behind
+    // mode 5 counts the non-finite rows of F(x0) in *nonfinite (zero between launches: its last evaluation
+    // workgroup moves the total to *nonfinite_result and clears the counter)
+    int* nonfinite_result;
     int32_t col_lo, col_hi; // FD columns handled by this launch
     // Packed non-zeros (modes 6-9).  The static pattern of J_T is the tracer's: column j can be non-zero in
     // the collocation block its state slice owns (N consecutive rows) and at its row items, in that order.
@@ -79,7 +88,7 @@ int ogk_get_info(ogk_info* out);
 // mode 6 / 7: the static pattern (entries per column / row indices).  mode 8: gather the pattern entries of
 // the columns [col_lo, col_hi) of `jt` into pvals.  mode 9: scatter pvals into the rows [ulo, uhi) of a full
 // matrix `jt` (row 0 = column 0), filling those rows from z first when F(x0) has non-finite rows or the
-// previous step left such a fill behind.
+// previous step left such a fill behind.  mode 10: count one launch into *jt_launches.
 // Only enqueues kernels on `stream`; returns a hipError_t value (0 = success).
 int ogk_launch(const ogk_args* args, int mode, void* stream);
 #ifdef __cplusplus

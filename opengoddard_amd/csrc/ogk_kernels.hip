@@ -148,16 +148,17 @@ __device__ __forceinline__ void fill_terms(const ogk_args& a, double* tc) {
             tc[OgGen::TERM_OFF(tb) + q] = OgGen::sum_term(tb, q, xb, a.cvec);
 }
 
-// Persistent-zero output (ogk.h: jt_sparse / jt_gen / jt_state).  A buffer that is known to hold zeros at
+// Persistent-zero output (ogk.h: jt_sparse / jt_launches / jt_state).  A buffer that is known to hold zeros at
 // its structural zeros is only written where something can be non-zero; the fill is needed when the
 // buffer is not registered, or when the previous launch into it left a NaN fill behind.
 __device__ __forceinline__ bool jt_needs_fill(const ogk_args& a) {
-    const unsigned st = *a.jt_state;            // written by an earlier kernel (agent scope): plain load
-    return !a.jt_sparse | (st == a.jt_gen - 1u);
+    // both written by earlier kernels (agent scope): plain loads.  *jt_launches already counts this launch
+    const unsigned st = *a.jt_state, gen = *a.jt_launches;
+    return !a.jt_sparse | (st == gen - 1u);
 }
 // this launch fills with NaN: the next launch into the buffer must clean up
 __device__ __forceinline__ void jt_mark_nan_fill(const ogk_args& a) {
-    if (a.jt_sparse) __hip_atomic_store(a.jt_state, a.jt_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.jt_sparse) __hip_atomic_store(a.jt_state, *a.jt_launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int ROWS_COLS_PER_THREAD = 8;
@@ -591,7 +592,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, cons
     const int id = (int)blockIdx.x;
     // the evaluation after this one counts into the other slot: clear it now (stream order
     // makes this visible to the next launch)
-    if (id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
+    if (id == 0 && threadIdx.x == 0) {
+        *a.nonfinite_next = 0;
+        if (a.jt_bump) __hip_atomic_store(a.jt_launches, *a.jt_launches + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (id < ndef) eval_defect_body<false>(a, id, lds);
     else eval_rows_body<false>(a, id - ndef, lds);
 }
@@ -989,9 +993,15 @@ __device__ __forceinline__ void finish_eval(const ogk_args& a, const unsigned n_
             // Two independent loads, one round trip; the ticket's reset needs no answer.
             const int bad = __hip_atomic_load(a.nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned st = __hip_atomic_load(a.jt_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned gen = __hip_atomic_load(a.jt_launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             __hip_atomic_store(a.ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (bad != 0) jt_mark_nan_fill(a);
-            last = (bad != 0 || st == a.jt_gen - 1u) ? 1 : 0;
+            // this launch's number; the count of non-finite rows moves to where later kernels and the host read
+            // it, the counter is zero again for the next launch (nothing of this is a launch argument)
+            __hip_atomic_store(a.jt_launches, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.nonfinite_result, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.nonfinite, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bad != 0) __hip_atomic_store(a.jt_state, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (bad != 0 || st == gen - 1u) ? 1 : 0;
         }
         s_last = last;
     }
@@ -1481,7 +1491,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) OGK_FUSED_ATTR void ogk_fused(const 
     int id = (int)blockIdx.x;
     if (id < n_eval) {
         FZ_TRACE_DECL(0);
-        if (id == 0 && threadIdx.x == 0) *a.nonfinite_next = 0;
         if (!(OGK_FZ & 16)) {
             if (id < ndef) eval_defect_body<true>(a, id, lds);
             else eval_rows_body<true>(a, id - ndef, lds);
@@ -1531,6 +1540,11 @@ __device__ __forceinline__ int pattern_row(const int4 col, const int own, const 
     return i < own ? col.z + i : OGT_ELEM[col.x + (i - own)].w;
 }
 
+__global__ void ogk_count_launch(const ogk_args a) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        __hip_atomic_store(a.jt_launches, *a.jt_launches + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(PACK_THREADS) void ogk_pattern(const ogk_args a, const int rows_pass) {
     const int j = (int)(blockIdx.x * (PACK_THREADS / 64) + (threadIdx.x >> 6));
     const int lane = (int)threadIdx.x & 63;
@@ -1570,7 +1584,7 @@ __global__ __launch_bounds__(PACK_THREADS) void ogk_unpack(const ogk_args a) {
     double* jrow = a.jt + (long)j * OgGen::M;
     // every rank evaluated the same F(x0): its z says which rows are NaN in every column; a fill (NaN now, or
     // zeros to clean up after one) goes first, the wavefront's own stores to one row stay in order
-    const bool fill = a.jt_sparse && (*a.nonfinite != 0 || *a.jt_state == a.jt_gen - 1u);
+    const bool fill = a.jt_sparse && (*a.nonfinite != 0 || *a.jt_state == *a.jt_launches - 1u);
     if (fill) {
         for (int r = lane; r < OgGen::M; r += 64) jrow[r] = a.z[r];
         __builtin_amdgcn_s_waitcnt(0);
@@ -1605,6 +1619,12 @@ size_t sweep_lds_bytes() { return (size_t)LIGHT_COLS * ROW_WORDS * sizeof(unsign
 extern "C" int ogk_get_info(ogk_info* out) {
     out->abi = OGK_ABI;
     out->n_eval_blocks = defect_blocks() + (OGT_N_ROWWAVES + SWEEP_WAVES - 1) / SWEEP_WAVES;
+    {
+        size_t lds_bytes = defect_lds_bytes() > FZ_LDS_BYTES ? defect_lds_bytes() : FZ_LDS_BYTES;
+        const size_t fill_lds = (size_t)ROW_WORDS * sizeof(unsigned);
+        if (fill_lds > lds_bytes) lds_bytes = fill_lds;
+        out->fused_ok = (lds_bytes <= 64 * 1024 && out->n_eval_blocks > 0) ? 1 : 0;
+    }
     out->n = OgGen::N_VAR;
     out->m = OgGen::M;
     out->m_eq = OgGen::M_EQ;
@@ -1631,6 +1651,10 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         return (int)hipGetLastError();
     }
     const int ncols = args->col_hi - args->col_lo;
+    if (mode == 10) {
+        hipLaunchKernelGGL(ogk_count_launch, dim3(1), dim3(64), 0, stream, *args);
+        return (int)hipGetLastError();
+    }
     if (mode == 6 || mode == 7) {
         hipLaunchKernelGGL(ogk_pattern, dim3((OgGen::N_VAR + PACK_THREADS / 64 - 1) / (PACK_THREADS / 64)),
                            dim3(PACK_THREADS), 0, stream, *args, mode == 7 ? 1 : 0);
@@ -1665,13 +1689,9 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
         size_t lds_bytes = defect_lds_bytes() > FZ_LDS_BYTES ? defect_lds_bytes() : FZ_LDS_BYTES;
         const size_t fill_lds = (size_t)ROW_WORDS * sizeof(unsigned);      // finish_eval's bitmap of one row
         if (fill_lds > lds_bytes) lds_bytes = fill_lds;
-        if (!args->jt_sparse || lds_bytes > 64 * 1024 || ndef + eval_row_blocks == 0) {
-            // the one-launch form writes the non-zeros only: it needs a registered (persistent-zero) output
-            // buffer (og_jt_register_dev).  Also when a tile's panel and operands do not fit the default LDS
-            // window (hundreds of nodes x 16 states): the same work as two launches.
-            const int rc0 = ogk_launch(args, 0, stream_);
-            return rc0 ? rc0 : ogk_launch(args, 1, stream_);
-        }
+        // the one-launch form writes the non-zeros only: it needs a registered (persistent-zero) output buffer
+        // (og_jt_register_dev) and its LDS window (ogk_info.fused_ok); the caller runs modes 0 + 1 otherwise
+        if (!args->jt_sparse || lds_bytes > 64 * 1024 || ndef + eval_row_blocks == 0) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(ogk_fused, dim3(ndef + eval_row_blocks + OGT_N_FTILES + OGT_N_HPART + (ghi - glo)),
                            dim3(SWEEP_THREADS), lds_bytes, stream, *args, ndef, ndef + eval_row_blocks, glo, ghi - glo);
         return (int)hipGetLastError();

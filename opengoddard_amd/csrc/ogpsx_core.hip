@@ -95,12 +95,12 @@ struct og_problem_s {
     struct jt_reg {
         double* ptr;
         int lo, hi;
-        int slot;
-        unsigned launches;
+        int slot;                       // d_state[2*slot] = state word, d_state[2*slot + 1] = launch counter
     };
     std::vector<jt_reg> regs;
-    int last_reg = -1;                  // registration the most recent fill_args matched (-1: none)
     uint32_t* d_state = nullptr;
+    bool fused_ok = false;              // the module can run evaluation + sweep as one launch
+    int* nf_read = nullptr;             // where the most recent evaluation left its count of non-finite rows
     // static pattern of J_T (og_pattern): entries of column j are indptr[j]..indptr[j+1] of the packed order
     bool have_pattern = false;
     std::vector<int64_t> indptr;
@@ -149,28 +149,28 @@ void fill_args(og_problem_s* p, ogk_args* a, const double* x, const double* h, d
     a->jt = jt;
     a->col_lo = lo;
     a->col_hi = hi;
-    // a registered buffer (exactly this block of columns at this address) is written sparsely
+    // a registered buffer (exactly this block of columns at this address) is written sparsely; its two words
+    // (state, launch counter) live on the device - nothing about the history of the buffer is a launch argument
     a->jt_sparse = 0;
-    a->jt_gen = 1;
+    a->jt_bump = 0;
     a->jt_state = p->d_state;
-    p->last_reg = -1;
+    a->jt_launches = p->d_state + 1;
+    a->nonfinite_result = p->d_flags + 4;
+    if (!new_launch && p->nf_read) a->nonfinite = p->nf_read;     // pack / unpack: the count the last evaluation left
     if (jt)
         for (size_t i = 0; i < p->regs.size(); ++i) {
             auto& r = p->regs[i];
             if (r.ptr == jt && r.lo == lo && r.hi == hi) {
                 a->jt_sparse = 1;
-                a->jt_gen = new_launch ? ++r.launches : r.launches;
-                a->jt_state = p->d_state + r.slot;
-                p->last_reg = new_launch ? (int)i : -1;
+                a->jt_state = p->d_state + 2 * r.slot;
+                a->jt_launches = a->jt_state + 1;
                 break;
             }
         }
     memcpy(a->dfrag_off, p->dfrag_off, sizeof(a->dfrag_off));
 }
 
-// a launch that was not accepted has not happened as far as the buffer's generation count goes
-int launch_failed(og_problem_s* p, int rc, const char* where) {
-    if (p->last_reg >= 0) p->regs[(size_t)p->last_reg].launches -= 1;
+int launch_failed(og_problem_s*, int rc, const char* where) {
     return fail(100 + rc, std::string(where) + ": " + hipGetErrorString((hipError_t)rc));
 }
 
@@ -481,15 +481,17 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     if (e == hipSuccess) e = hipMalloc(&p->d_xop, sizeof(double) * (size_t)(info.n_y0 > 0 ? info.n_y0 : 1));
     if (e == hipSuccess) e = hipMalloc(&p->d_t0, sizeof(double) * (size_t)p->m);
     if (e == hipSuccess) e = hipMalloc(&p->d_z, sizeof(double) * (size_t)p->m);
-    if (e == hipSuccess) e = hipMalloc(&p->d_flags, 4 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 4 * sizeof(int));
+    // {non-finite counters of the two-launch form (alternating), ticket, counter of the one-launch form, its result}
+    if (e == hipSuccess) e = hipMalloc(&p->d_flags, 8 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, 8 * sizeof(int));
     if (e == hipSuccess && getenv("OGPSX_TRACE")) {
         e = hipMalloc(&p->d_trace, sizeof(double) * OG_TRACE_DOUBLES);
         if (e == hipSuccess) e = hipMemset(p->d_trace, 0, sizeof(double) * OG_TRACE_DOUBLES);
     }
-    if (e == hipSuccess) e = hipMalloc(&p->d_state, (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(p->d_state, 0xff, (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&p->d_state, 2 * (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(p->d_state, 0xff, 2 * (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
     p->n_eval_blocks = info.n_eval_blocks;
+    p->fused_ok = info.fused_ok != 0;
     const char* mode_env = getenv("OGPSX_SWEEP");
     // One launch (evaluation + structured sweep) whenever the output is a registered persistent-zero buffer;
     // measured against the two-launch form with such a buffer (bench step, us, one launch / two): C2 4.8 / 8.1,
@@ -572,14 +574,14 @@ int og_jt_register_dev(og_handle p, double* d_JT, int32_t lo, int32_t hi, void* 
         for (auto& r : p->regs) used[r.slot] = 1;
         int slot = 1;
         while (used[slot]) ++slot;
-        p->regs.push_back({d_JT, lo, hi, slot, 0u});
+        p->regs.push_back({d_JT, lo, hi, slot});
         reg = &p->regs.back();
     }
     reg->lo = lo;
     reg->hi = hi;
-    reg->launches = 0;
     OG_HIP(hipMemsetAsync(d_JT, 0, sizeof(double) * (size_t)(hi - lo) * (size_t)p->m, s));
-    OG_HIP(hipMemsetAsync(p->d_state + reg->slot, 0xff, sizeof(uint32_t), s));
+    OG_HIP(hipMemsetAsync(p->d_state + 2 * reg->slot, 0xff, sizeof(uint32_t), s));        // state: no NaN fill
+    OG_HIP(hipMemsetAsync(p->d_state + 2 * reg->slot + 1, 0, sizeof(uint32_t), s));       // launches so far
     return 0;
 }
 
@@ -743,6 +745,7 @@ int og_eval_dev(og_handle p, const double* d_x, double* d_F, void* hip_stream) {
     ogk_args a;
     p->flag_slot ^= 1;                      // this evaluation counts non-finite rows into a fresh slot
     fill_args(p, &a, d_x, nullptr, d_F, nullptr, 0, 0);
+    p->nf_read = a.nonfinite;
     int rc = p->launch(&a, 0, hip_stream);
     if (rc) return fail(100 + rc, std::string("og_eval_dev: ") + hipGetErrorString((hipError_t)rc));
     return 0;
@@ -753,14 +756,21 @@ int og_fd_sweep_dev(og_handle p, const double* d_x, const double* d_h, int32_t l
     if (!p || !d_x || !d_h || !d_JT || !d_F0) return fail(1, "og_fd_sweep_dev: null argument");
     if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_fd_sweep_dev: bad column range");
     ogk_args a;
-    p->flag_slot ^= 1;
     fill_args(p, &a, d_x, d_h, d_F0, d_JT, lo, hi);
     int rc;
-    if (p->sweep_mode == 5 && hi > lo) {
-        // one launch (the module falls back to two when d_JT is not a registered buffer)
+    if (p->sweep_mode == 5 && p->fused_ok && a.jt_sparse && hi > lo) {
+        // ONE launch.  Its arguments depend on nothing but the pointers: the count of non-finite rows, the ticket
+        // and the buffer's launch number are kept by the kernel itself (a captured graph can be replayed)
+        a.nonfinite = p->d_flags + 3;
+        p->nf_read = a.nonfinite_result;
         rc = p->launch(&a, 5, hip_stream);
     } else {
-        rc = p->launch(&a, 0, hip_stream);          // F(x0) first: the sweep subtracts it
+        p->flag_slot ^= 1;
+        a.nonfinite = p->d_flags + p->flag_slot;
+        a.nonfinite_next = p->d_flags + (p->flag_slot ^ 1);
+        p->nf_read = a.nonfinite;
+        a.jt_bump = a.jt_sparse;                    // F(x0) first: the sweep subtracts it; it also counts the launch
+        rc = p->launch(&a, 0, hip_stream);
         if (!rc) rc = p->launch(&a, p->sweep_mode == 5 ? 1 : p->sweep_mode, hip_stream);
     }
     if (rc) return launch_failed(p, rc, "og_fd_sweep_dev");
@@ -773,7 +783,8 @@ int og_fd_columns_dev(og_handle p, const double* d_x, const double* d_h, int32_t
     if (lo < 0 || hi > p->n || lo > hi) return fail(1, "og_fd_columns_dev: bad column range");
     ogk_args a;
     fill_args(p, &a, d_x, d_h, const_cast<double*>(d_F0), d_JT, lo, hi);
-    int rc = p->launch(&a, p->sweep_mode == 5 ? 1 : p->sweep_mode, hip_stream);
+    int rc = a.jt_sparse ? p->launch(&a, 10, hip_stream) : 0;       // count this launch into the registered buffer
+    if (!rc) rc = p->launch(&a, p->sweep_mode == 5 ? 1 : p->sweep_mode, hip_stream);
     if (rc) return launch_failed(p, rc, "og_fd_columns_dev");
     return 0;
 }
@@ -785,6 +796,8 @@ int og_jacobian_exact_dev(og_handle p, const double* d_x, int32_t lo, int32_t hi
     ogk_args a;
     p->flag_slot ^= 1;
     fill_args(p, &a, d_x, nullptr, d_F0, d_JT, lo, hi);
+    p->nf_read = a.nonfinite;
+    a.jt_bump = a.jt_sparse;
     int rc = p->launch(&a, 0, hip_stream);          // F(x0) and the base collocation products
     if (!rc) rc = p->launch(&a, p->exact_mode, hip_stream);   // forward-mode derivatives, column by column
     if (rc) return launch_failed(p, rc, "og_jacobian_exact_dev");

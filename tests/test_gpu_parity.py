@@ -522,6 +522,56 @@ def test_sharded_sweep_class_on_the_device(golden):
     eng.close()
 
 
+@pytest.mark.parametrize("name,state", [("goddard", 2), ("polar_tsto", 4)])
+def test_one_launch_sweep_replays_from_a_captured_graph(name, state):
+    """The launch arguments of a sweep into a registered buffer are pointers only - the count of non-finite rows,
+    the ticket and the buffer's launch number live on the device - so the launch can be captured once into a
+    hipGraph and replayed at new points (written into the same device vectors), through non-finite points too."""
+    import torch
+    from opengoddard_amd.engine import HipEngine
+    from oracle import np_path, twin
+    prob, obj = problems.build(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    eng = HipEngine(prob, obj)
+    assert eng.sweep_mode == "fused"
+    tw = twin.Twin(prob, obj, program=eng.program, header=eng.header)
+    n, m = eng.n, eng.m
+    dev = torch.device("cuda", 0)
+    d_x = torch.zeros(n, dtype=torch.float64, device=dev)
+    d_h = torch.zeros(n, dtype=torch.float64, device=dev)
+    d_F = torch.empty(m, dtype=torch.float64, device=dev)
+    d_JT = torch.empty((n, m), dtype=torch.float64, device=dev)
+    x_ok = np.clip(prob.p, lb, ub)
+    x_bad = x_ok.copy()
+    x_bad[prob.index_states(state, 0, 7)] = 0.0
+    rng = np.random.default_rng(2)
+    x_other = np.clip(x_ok + 1e-3 * rng.standard_normal(n), lb, ub)
+
+    def load(x):
+        d_x.copy_(torch.from_numpy(x))
+        d_h.copy_(torch.from_numpy(_native.fd_step(x, lb, ub)))
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.register_jt_dev(d_JT.data_ptr(), 0, n, side.cuda_stream)
+        load(x_ok)
+        eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), 0, n, d_JT.data_ptr(), d_F.data_ptr(), side.cuda_stream)   # warm
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), 0, n, d_JT.data_ptr(), d_F.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+    for step, x in enumerate((x_other, x_bad, x_bad, x_ok, x_other, x_bad, x_ok)):
+        load(x)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        F_want, JT_want = tw.sweep(x, _native.fd_step(x, lb, ub))
+        assert np.array_equal(d_F.cpu().numpy(), F_want, equal_nan=True), "F at replay %d" % step
+        assert np.array_equal(d_JT.cpu().numpy(), JT_want, equal_nan=True), "J_T at replay %d" % step
+    eng.close()
+
+
 def test_sweep_is_deterministic(golden):
     G = golden("cfg_polar_tsto")
     prob, obj, eng, tw = _engine_and_twin("polar_tsto")

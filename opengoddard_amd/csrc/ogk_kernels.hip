@@ -1502,15 +1502,34 @@ __global__ __launch_bounds__(SWEEP_THREADS) OGK_FUSED_ATTR void ogk_fused(const 
         return;
     }
     id -= n_eval;
-    // nothing in the sweep workgroups waits for the evaluation workgroups (finish_eval); the light workgroups
-    // have the longest life and are dispatched right behind them, heavy parts and MFMA tiles last
-    if (id < n_light) {
-        fz_light_body(a, group_lo + id, lds);
-    } else if (id < n_light + OGT_N_HPART) {
-        if (!(OGK_FZ & 32)) fz_heavy_part(a, id - n_light, lds);
+    // nothing in the sweep workgroups waits for the evaluation workgroups (finish_eval).  Grid order (OGK_ORDER,
+    // timing experiments): 0 = light, heavy parts, MFMA tiles; 1 = MFMA tiles, heavy parts, light; 2 = tiles and
+    // light workgroups interleaved, heavy parts first
+#ifndef OGK_ORDER
+#define OGK_ORDER 0
+#endif
+    const int n_tile = OGT_N_FTILES, n_heavy = OGT_N_HPART;
+    int kind, idx;                                     // 0 light, 1 heavy, 2 tile
+    if (OGK_ORDER == 0) {
+        if (id < n_light) kind = 0, idx = id;
+        else if (id < n_light + n_heavy) kind = 1, idx = id - n_light;
+        else kind = 2, idx = id - n_light - n_heavy;
+    } else if (OGK_ORDER == 1) {
+        if (id < n_tile) kind = 2, idx = id;
+        else if (id < n_tile + n_heavy) kind = 1, idx = id - n_tile;
+        else kind = 0, idx = id - n_tile - n_heavy;
     } else {
-        fz_tile_body(a, id - n_light - OGT_N_HPART, lds);
+        if (id < n_heavy) kind = 1, idx = id;
+        else {
+            const int r = id - n_heavy, pairs = n_light < n_tile ? n_light : n_tile;
+            if (r < 2 * pairs) kind = (r & 1) ? 0 : 2, idx = r >> 1;
+            else if (n_light > n_tile) kind = 0, idx = r - pairs;
+            else kind = 2, idx = r - pairs;
+        }
     }
+    if (kind == 0) fz_light_body(a, group_lo + idx, lds);
+    else if (kind == 1) { if (!(OGK_FZ & 32)) fz_heavy_part(a, idx, lds); }
+    else fz_tile_body(a, idx, lds);
 }
 
 __global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a) {

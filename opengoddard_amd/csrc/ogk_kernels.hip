@@ -14,26 +14,28 @@
 // ((n+1) x n doubles in the reference's formulation) is never materialised: every read of the
 // decision vector goes through XCol, which returns x0[i] except at i == j.
 //
-// Three launch modes (ogk_launch):
-//   0  ogk_eval          F(x0) -> f0, plus scratch the sweep reuses: the unperturbed collocation
+// Launch modes (ogk_launch; ogk.h lists all):
+//   0  ogk_eval          F(x0) -> f0, plus scratch the two-launch sweep reuses: the unperturbed collocation
 //                        products y0, the dynamics terms t0 = (tf-t0)/2 f, and z = F0 - F0
 //                        (0, or NaN where a row is not finite: what dense FD would produce).
-//   1  ogk_sweep         structured forward-difference sweep (default).  Dense FD evaluates
+//   1  ogk_sweep         structured forward-difference sweep, second of two launches.  Dense FD evaluates
 //                        every row for every column although a row changes only when it reads
 //                        the perturbed variable; because base and perturbed values come from
 //                        the same device functions, every other difference quotient is exactly
 //                        (F0-F0)/dx.  This kernel therefore
 //                          - lets a workgroup own a few J_T rows (= FD columns): it streams
-//                            zeros into them and re-evaluates only the (group, output, element)
+//                            zeros into them (unless the buffer is a registered persistent-zero one) and
+//                            re-evaluates only the (group, output, element)
 //                            items whose traced leaves include p[j] (tables OGT_COL/OGT_ELEM);
 //                          - runs the collocation product for the N perturbed vectors of each
 //                            state slice on v_mfma_f64_16x16x4_f64 (A = 16 perturbed state
 //                            vectors, B = the D^T operand image), writing the dense N x N
 //                            block d(defect_s)/d(state_s) directly.
-//                        The result is identical to mode 2 (tests compare them and the CPU twin).
+//   5  ogk_fused         modes 0 + 1 as ONE launch writing only the non-zeros (the default; see below).
+//                        The results of modes 1, 5 and 2 are identical (tests compare them and the CPU twin).
 //
 // D is kept in HBM/L2 in MFMA B-operand order (ogk.h).  Kernels that reuse a panel across
-// wavefronts or states (modes 0 and 2) stage it in LDS; the tiles of mode 1 use each panel once
+// wavefronts or states stage it in LDS; the MFMA tiles use each panel once
 // per wavefront and read it straight from L2 (measured: no LDS round trip, no barrier, same speed).
 //   2  ogk_dense         the literal dense sweep: all rows for all columns (validation, and the
 //                        shape SURVEY.md section 7.2 describes).
@@ -910,43 +912,33 @@ __device__ __forceinline__ void tile_body(const ogk_args& a, const int bx) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Mode 5 (ogk_fused): modes 0 and 1 as ONE launch.  The first workgroups of the grid are the
-// evaluation workgroups (they produce F(x0) for the caller, as in mode 0); the sweep workgroups
-// that follow do not consume anything from them on the way: what a difference quotient needs of
-// the base point - the base value of a row item, the base collocation products of a node tile -
-// is recomputed by the workgroup that uses it, with the same device functions and the same MFMA
-// chain, hence the same bits.  A kernel boundary (drain, cache write-back / invalidate, dispatch)
-// between the evaluation and the sweep costs a third of a step at the sizes of this engine; loads
-// from another workgroup's results inside one kernel would have to bypass the (per-XCD, mutually
-// incoherent) L2s and queue behind the J_T write stream, which is slower still (both measured).
-//   fz_light_body   a run of <= LIGHT_COLS neighbouring columns whose defect items lie in one
-//                   (defect group, 16-node tile): the whole workgroup stages the group's operands
-//                   in LDS, one wavefront runs the tile's MFMA chain while the others stream the
-//                   zero fill, then lane = column, wavefront = item slot as in mode 1.
-//   fz_heavy_body   a column with many items, or items in several tiles: all base products, into
-//                   a private global scratch (same CU: coherent through the shared L1/L2 path).
-//   fz_tile_body    as tile_body, with a second accumulator for the unperturbed operand.
-// Only one thing still depends on the evaluation: when F(x0) has non-finite rows the fill is NaN
-// there, not 0.  The evaluation workgroups count themselves into a ticket; the wavefront of a
-// sweep workgroup that runs out of work first polls it (by then it is complete) and the non-finite
-// counter, and in that rare case the workgroup rewrites its fill from z.
+// Mode 5 (ogk_fused): modes 0 and 1 as ONE launch into a registered persistent-zero buffer.  The first
+// workgroups of the grid are the evaluation workgroups (they produce F(x0) for the caller, as in mode 0); the
+// sweep workgroups that follow do not consume anything from them: what a difference quotient needs of the
+// base point - the base value of a row item, the base collocation products of a node tile - is recomputed by
+// the workgroup that uses it, with the same device functions and the same MFMA chain, hence the same bits.  A
+// kernel boundary (drain, cache write-back / invalidate, dispatch) between the evaluation and the sweep costs a
+// third of a step at the sizes of this engine; loads from another workgroup's results inside one kernel would
+// have to bypass the (per-XCD, mutually incoherent) L2s, which is slower still (both measured, round 1).
+//   fz_light_body   a run of <= 16 neighbouring columns whose defect items lie in one (defect group, 16-node
+//                   tile): the whole workgroup stages the tile's D^T panel and the group's operands in LDS,
+//                   one wavefront runs the tile's MFMA chain, the others evaluate the items' long parts
+//                   meanwhile (lane = column, perturbed | base; wavefront = item slot).
+//   fz_heavy_part   one (defect group, node tile) of a column with many items, staged the same way; slots of
+//                   items that share their code, one wavefront each (lanes = items, perturbed | base).
+//   fz_tile_body    d(defect_s)/d(state_s): <= 7 column tiles per workgroup share ONE base product / base
+//                   dynamics term / diagonal term, computed by otherwise idle wavefronts.
+// Nothing is filled and nobody waits: the sweep workgroups write the positions that can be non-zero; when F(x0)
+// has non-finite rows (or the previous launch left a NaN fill) the LAST evaluation workgroup to finish fills
+// the rows from z around those positions (finish_eval).  The launch arguments are pointers only.
 // ------------------------------------------------------------------------------------------
-// Timing experiments only (tools/fz_exp.sh): -DOGK_FZ=<mask> removes pieces of ogk_fused - 1 = no verdict
-// poll, 2 = no base-product chain in the light workgroups, 4 = no operand staging there, 16 = evaluation
-// workgroups do nothing, 32 = heavy columns skipped, 64 = mode 1's tile body, 2048 = no light items.
-// Results are wrong with any bit set.
+// Timing experiments only: -DOGK_FZ=<mask> removes pieces of ogk_fused - 2 = no base-product chain in the light
+// workgroups, 4 = no operand staging there, 16 = evaluation workgroups do nothing, 32 = heavy columns skipped,
+// 2048 = no light items.  Results are wrong with any bit set.
 #ifndef OGK_FZ
 #define OGK_FZ 0
 #endif
-// the wavefront whose MFMA chain a whole workgroup waits for asks for issue priority over its neighbours
-#ifndef OGK_PRIO
-#define OGK_PRIO 1
-#endif
-#if OGK_PRIO
-#define OGK_SERVICE_PRIO() __builtin_amdgcn_s_setprio(3)
-#else
-#define OGK_SERVICE_PRIO() do { } while (0)
-#endif
+
 
 // barrier that orders LDS traffic only: the global stores of the fill keep draining underneath
 // (__syncthreads() would wait for them)
@@ -1184,7 +1176,6 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
     lds_barrier();            // (only LDS data crosses it: global loads in flight stay in flight)
     FZ_STAMP(1);
     if (service) {
-        OGK_SERVICE_PRIO();
         if (has_tile && !(OGK_FZ & 2))
             base_products_tile(t.dpanel, N, nt, nmv, t.xt, ((N + 3) >> 2) << 2,
                                [&](const int st, const int k, const double v) { t.yb[st * N + k] = v; });
@@ -1264,7 +1255,6 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
     lds_barrier();
     FZ_STAMP(1);
     if (service) {
-        OGK_SERVICE_PRIO();
         if (has_tile)
             base_products_tile(t.dpanel, N, nt, nmv, t.xt, ((N + 3) >> 2) << 2,
                                [&](const int st, const int k, const double v) { t.yb[st * N + k] = v; });
@@ -1366,8 +1356,7 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
         if (wave == term_wave && lk == 0) tb[kk] = k_on ? OgGen::tail_one(slot, k, xbase, a.cvec) : 0.0;
         if (wave == term_wave && lane == 0) lds_flag_raise(&s_flags[1], 1);
         if (wave == prod_wave) {
-            OGK_SERVICE_PRIO();
-            v4f64 accb = {0.0, 0.0, 0.0, 0.0};
+                v4f64 accb = {0.0, 0.0, 0.0, 0.0};
             for (int ks0 = 0; ks0 < KS; ks0 += CH) {
                 double bn[CH];
 #pragma unroll

@@ -42,6 +42,13 @@ def fused_cols(n):
     return int(env) if env else 16
 
 
+def tile_cols():
+    """Column tiles per MFMA-tile workgroup of the fused launch (at most SWEEP_WAVES - 1 = 7: the last wavefront
+    computes the node tile's base products).  ``OG_TILE_COLS`` overrides (timing experiments)."""
+    env = os.environ.get("OG_TILE_COLS")
+    return max(1, min(7, int(env))) if env else 7
+
+
 MAX_GROUP_OUTPUTS = int(os.environ.get("OG_MAX_GROUP_OUTPUTS", "1"))
 
 
@@ -1131,7 +1138,7 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     ftiles = []
     for si, sl in enumerate(P.mv):
         t16 = (sl.length + 15) // 16
-        ngrp = -(-t16 // (SWEEP_WAVES - 1))
+        ngrp = -(-t16 // tile_cols())
         per = -(-t16 // ngrp)
         for c0 in range(0, t16, per):
             for nt in range(t16):

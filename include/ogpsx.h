@@ -167,6 +167,11 @@ int og_shard_comm_init(og_handle h, const uint8_t* id128, int32_t rank, int32_t 
 void og_shard_comm_destroy(og_handle h);
 int og_shard_all_gather_dev(og_handle h, const double* d_send, double* d_recv, void* hip_stream);
 int og_shard_pack_dev(og_handle h, int32_t rank, const double* d_JT_block, double* d_send, void* hip_stream);
+/* og_fd_sweep_dev of rank's block and og_shard_pack_dev in ONE launch: the sweep kernel stores every non-zero
+ * into the block of the replica and into the message (needs the block registered; otherwise it runs the two
+ * calls). */
+int og_shard_sweep_dev(og_handle h, int32_t rank, const double* d_x, const double* d_hstep, double* d_JT_block,
+                       double* d_F0, double* d_send, void* hip_stream);
 int og_shard_unpack_dev(og_handle h, int32_t rank, const double* d_recv, double* d_JT_full, void* hip_stream);
 
 /* ---- several GPUs of one node from one process ---------------------------------------------------

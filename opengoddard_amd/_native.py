@@ -58,6 +58,8 @@ SIGNATURES = {
     "og_shard_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "og_shard_comm_destroy": (None, [C.c_void_p]),
     "og_shard_all_gather_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "og_shard_sweep_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "og_shard_pack_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_shard_unpack_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_comm_init": (C.c_int, [C.c_int32, _c_int32_p]),

@@ -1069,7 +1069,10 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     lgrp, lrng = [], []
     for j0, cnt, key in light_groups:
         for c in range(fused_cols(P.n)):
-            lrng.append([col_ptr[j0 + c], col_ptr[j0 + c + 1], 0, 0] if c < cnt else [0, 0, 0, 0])
+            # {items begin, end, entries of the column's own collocation block (they precede its items in the
+            #  packed order)}
+            lrng.append([col_ptr[j0 + c], col_ptr[j0 + c + 1], own_hi[j0 + c] - own_lo[j0 + c], 0]
+                        if c < cnt else [0, 0, 0, 0])
         # bit 16 of the last field: some item of the workgroup contains a sum (base terms are then cached in LDS)
         terms = int(any(elem_g[e] in sum_groups for e in range(col_ptr[j0], col_ptr[j0 + cnt]))) << 16
         if key:
@@ -1087,6 +1090,8 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     hpart, hslot, helem = [], [], []
     for j in heavy:
         entries = [(elem_g[e], elem_o[e], elem_k[e]) for e in range(col_ptr[j], col_ptr[j + 1])]
+        # position of an item in the column's packed order (codegen.sparsity): own block first, then OGT_ELEM order
+        ppos = {ent: (own_hi[j] - own_lo[j]) + i for i, ent in enumerate(entries)}
         tiles_of = {}
         for gi, o, k in entries:
             if P.groups[gi].kind == "defect":
@@ -1096,7 +1101,7 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
             first_slot = len(hslot)
             for o, ks in sorted(by_out.items()):
                 hslot.append([len(helem), len(ks), 0, 0])
-                helem += [[gi, o, k, g.outputs[o][0] + k] for k in sorted(ks)]
+                helem += [[gi, o, k, ppos[(gi, o, k)]] for k in sorted(ks)]
             hpart.append([j, first_slot, len(hslot), y0_off[g.mv_slots[0]], nt_, g.mv_slots[0], len(g.mv_slots),
                           g.length | (g.phase << 20) | ((1 << 30) if gi in sum_groups else 0)])
         rows_by_group = {}
@@ -1110,7 +1115,7 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
                 for c0 in range(0, len(ks), 32):
                     chunk = ks[c0:c0 + 32]
                     hslot.append([len(helem), len(chunk), 0, 0])
-                    helem += [[gi, o, k, P.groups[gi].outputs[max(o, 0)][0] + k] for k in chunk]
+                    helem += [[gi, o, k, ppos[(gi, o, k)]] for k in chunk]
             hpart.append([j, first_slot, len(hslot), 0, 0, 0, 0,
                           (1 << 30) if any(gi in sum_groups for gi, _ in rows_by_group) else 0])
     L += ["struct ogt_int8 { int v[8]; };",
@@ -1122,6 +1127,7 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
           "static __device__ const ogt_int8 OGT_LGRP[%d] = {" % max(len(lgrp), 1),
           ",\n".join("    {{%s}}" % ", ".join(str(int(v)) for v in r) for r in (lgrp or [[0] * 8])),
           "};"]
+    # OGT_HELEM: {group, output, element, position in the column's packed order}
     L += table("int4", "OGT_HSLOT", hslot)    # {first item in OGT_HELEM, items} per slot of a heavy part
     L += table("int4", "OGT_HELEM", helem)
     L += table("int4", "OGT_LRNG", lrng)      # {items begin, end} per (group, column)

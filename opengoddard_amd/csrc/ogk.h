@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define OGK_ABI 10
+#define OGK_ABI 11
 #define OGK_MAX_PHASE 32
 
 // MFMA operand image of a differentiation matrix D (N x N, row-major [k][l]) for
@@ -69,6 +69,8 @@ typedef struct ogk_args {
     // Packed non-zeros (modes 6-9).  The static pattern of J_T is the tracer's: column j can be non-zero in
     // the collocation block its state slice owns (N consecutive rows) and at its row items, in that order.
     const int64_t* poff;    // [n] offset of column j's entries in the packed array (modes 7-9)
+    const int64_t* pind;    // [n+1] the pattern's own prefix sums (modes 8, 9): column j has pind[j+1]-pind[j] entries
+    const int32_t* prow;    // [nnz] row index of every pattern entry, flat (modes 8, 9): no table walks there
     int32_t* pint;          // mode 6: [n] entries per column (out); mode 7: row index of every packed entry (out)
     double* pvals;          // packed values: mode 8 writes them, mode 9 reads them
     double* ptail;          // mode 8: m + 1 doubles that receive F(x0) and the count of non-finite rows, or NULL

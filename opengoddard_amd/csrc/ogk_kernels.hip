@@ -1051,11 +1051,15 @@ constexpr int FZ_COLS = OGT_LGRP_COLS;          // columns of a light workgroup 
 // (F(x0 + h e_j) - F(x0)) / dx for one row item, with the base value from the partner lane (FZ_COLS further on, same item, unperturbed x)
 template <class XA>
 __device__ __forceinline__ void eval_item_paired(const ogk_args& a, const int4 item, const XA& xa, const bool base_role,
-                                                 const double dx, double* jrow) {
+                                                 const double dx, double* jrow, double* packed) {
     int row;
     const double v = OgGen::item_value(item.x, item.y, item.z, xa, a.y0, a.cvec, &row);
     const double v0 = __shfl_down(v, FZ_COLS);
-    if (!base_role) jrow[row] = (v - v0) / dx;
+    if (!base_role) {
+        const double q = (v - v0) / dx;
+        jrow[row] = q;
+        if (packed) *packed = q;
+    }
 }
 
 constexpr int FZ_MAXN = OgGen::MAX_NODES;                      // longest phase
@@ -1188,6 +1192,9 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
         const double xj = xb + hh;
         const double dx = xj - xb;
         double* jrow = a.jt + (long)(ji - a.col_lo) * OgGen::M;
+        // sharded sweeps: every value also goes straight into this rank's message (the column's packed entries:
+        // its collocation block first, then its items in work-list order) - no separate gather kernel
+        double* pcol = a.pvals ? a.pvals + a.poff[ji] + (coli.z - coli.x) : nullptr;
         const XColT xa = make_xcolt(a, base_role ? -1 : ji, xj, terms ? tc : nullptr);
         // The long part of an item - its dynamics term, or the whole value of a row item - does not depend on
         // the base products: the first FZ_ROUNDS items of every column are evaluated while the service
@@ -1209,12 +1216,17 @@ __device__ __forceinline__ void fz_light_body(const ogk_args& a, const int b, do
         for (int r = 0; r < FZ_ROUNDS; ++r) {
             const double v = tyo[r] >= 0 ? t.yb[tyo[r] - y0_first] - tv[r] : tv[r];
             const double v0 = __shfl_down(v, FZ_COLS);
-            if (!base_role && coli.x + wave + r * FZ_ITEM_WAVES < coli.y) jrow[trow[r]] = (v - v0) / dx;
+            const int e = coli.x + wave + r * FZ_ITEM_WAVES;
+            if (!base_role && e < coli.y) {
+                const double q = (v - v0) / dx;
+                jrow[trow[r]] = q;
+                if (pcol) pcol[e] = q;
+            }
         }
         // item_value indexes y0 by slot offset + node; the accessor turns that into the LDS tile
         const XColL xl{a.x0, base_role ? -1 : ji, xj, a.y0 + y0_first, t.yb};
         for (int e = coli.x + wave + FZ_ROUNDS * FZ_ITEM_WAVES; e < coli.y; e += FZ_ITEM_WAVES)
-            eval_item_paired(a, OGT_ELEM[e], xl, base_role, dx, jrow);
+            eval_item_paired(a, OGT_ELEM[e], xl, base_role, dx, jrow, pcol ? pcol + e : nullptr);
     }
     FZ_STAMP(4);
     FZ_TRACE_OUT(a);
@@ -1267,19 +1279,21 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
         const double xj = xb + hh;
         const double dx = xj - xb;
         double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
+        double* pcol = a.pvals ? a.pvals + a.poff[j] : nullptr;
         const XColT xa = make_xcolt(a, base_role ? -1 : j, xj, terms ? tc : nullptr);
         // as in the light workgroups: the items' long chains run while the service wavefront is in its own
         for (int s0 = rec.v[1] + wave; s0 < rec.v[2]; s0 += FZ_ROUNDS * FZ_ITEM_WAVES) {
             double tv[FZ_ROUNDS];
-            int trow[FZ_ROUNDS], tyo[FZ_ROUNDS], cnt[FZ_ROUNDS];
+            int trow[FZ_ROUNDS], tyo[FZ_ROUNDS], cnt[FZ_ROUNDS], tpos[FZ_ROUNDS];
 #pragma unroll
             for (int r = 0; r < FZ_ROUNDS; ++r) {
                 const int s = s0 + r * FZ_ITEM_WAVES;
-                tv[r] = 0.0, trow[r] = 0, tyo[r] = -1, cnt[r] = 0;
+                tv[r] = 0.0, trow[r] = 0, tyo[r] = -1, cnt[r] = 0, tpos[r] = 0;
                 if (s < rec.v[2]) {
                     const int4 sl = (r == 0 && s0 == rec.v[1] + wave) ? slot : OGT_HSLOT[s];
                     const int4 it = (r == 0 && s0 == rec.v[1] + wave) ? item : OGT_HELEM[sl.x + (il < sl.y ? il : 0)];
                     cnt[r] = sl.y;
+                    tpos[r] = it.w;                     // the item's place among the column's packed entries
                     tv[r] = OgGen::item_tail(it.x, it.y, it.z, xa, a.cvec, &trow[r], &tyo[r]);
                 }
             }
@@ -1291,7 +1305,11 @@ __device__ __forceinline__ void fz_heavy_part(const ogk_args& a, const int pidx,
             for (int r = 0; r < FZ_ROUNDS; ++r) {
                 const double v = tyo[r] >= 0 ? t.yb[tyo[r] - y0_first] - tv[r] : tv[r];
                 const double v0 = __shfl_down(v, 32);
-                if (!base_role && il < cnt[r]) jrow[trow[r]] = (v - v0) / dx;
+                if (!base_role && il < cnt[r]) {
+                    const double q = (v - v0) / dx;
+                    jrow[trow[r]] = q;
+                    if (pcol) pcol[tpos[r]] = q;
+                }
             }
         }
     }
@@ -1465,7 +1483,9 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
             }
         }
         const double val = acc[reg] - t;
-        a.jt[(long)(j - a.col_lo) * OgGen::M + row] = (val - f_base) / dx;
+        const double q = (val - f_base) / dx;
+        a.jt[(long)(j - a.col_lo) * OgGen::M + row] = q;
+        if (a.pvals) a.pvals[a.poff[j] + k] = q;        // the column's own block leads its packed entries
     }
     FZ_STAMP(4);
     FZ_TRACE_OUT(a);
@@ -1566,39 +1586,45 @@ __global__ __launch_bounds__(PACK_THREADS) void ogk_pattern(const ogk_args a, co
     for (int i = lane; i < cnt; i += 64) a.pint[a.poff[j] + i] = pattern_row(col, own, i);
 }
 
+// Pack / unpack: one workgroup per column, its entries taken from the flat row-index array of the pattern
+// (coalesced; the only dependent access is the J_T entry itself).  A phase's final time has a thousand entries,
+// an ordinary column a few dozen: a workgroup per column keeps the long ones from becoming the kernel's tail.
 __global__ __launch_bounds__(PACK_THREADS) void ogk_pack(const ogk_args a) {
-    const int j = a.col_lo + (int)(blockIdx.x * (PACK_THREADS / 64) + (threadIdx.x >> 6));
-    const int lane = (int)threadIdx.x & 63;
+    const int j = a.col_lo + (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
     if (blockIdx.x == 0 && a.ptail) {
-        for (int r = (int)threadIdx.x; r < OgGen::M; r += PACK_THREADS) a.ptail[r] = a.f0[r];
-        if (threadIdx.x == 0) a.ptail[OgGen::M] = (double)*a.nonfinite;
+        for (int r = tid; r < OgGen::M; r += PACK_THREADS) a.ptail[r] = a.f0[r];
+        if (tid == 0) a.ptail[OgGen::M] = (double)*a.nonfinite;
     }
     if (j >= a.col_hi) return;
-    const int4 col = OGT_COL[j];
-    const int own = (col.w & ~HEAVY_FLAG) - col.z, cnt = own + (col.y - col.x);
+    const long base = a.pind[j];
+    const int cnt = (int)(a.pind[j + 1] - base);
     const double* jrow = a.jt + (long)(j - a.col_lo) * OgGen::M;
     double* out = a.pvals + a.poff[j];
-    for (int i = lane; i < cnt; i += 64) out[i] = jrow[pattern_row(col, own, i)];
+    const int32_t* rows = a.prow + base;
+    for (int i = tid; i < cnt; i += PACK_THREADS) out[i] = jrow[rows[i]];
 }
 
 __global__ __launch_bounds__(PACK_THREADS) void ogk_unpack(const ogk_args a) {
-    // rows [ulo, uhi) of the full matrix except this rank's own block; one wavefront per row
-    int j = a.ulo + (int)(blockIdx.x * (PACK_THREADS / 64) + (threadIdx.x >> 6));
+    // rows [ulo, uhi) of the full matrix except this rank's own block
+    int j = a.ulo + (int)blockIdx.x;
     if (j >= a.col_lo) j += a.col_hi - a.col_lo;
-    const int lane = (int)threadIdx.x & 63;
+    const int tid = (int)threadIdx.x;
     if (j >= a.uhi) return;
-    const int4 col = OGT_COL[j];
-    const int own = (col.w & ~HEAVY_FLAG) - col.z, cnt = own + (col.y - col.x);
+    const long base = a.pind[j];
+    const int cnt = (int)(a.pind[j + 1] - base);
     double* jrow = a.jt + (long)j * OgGen::M;
     // every rank evaluated the same F(x0): its z says which rows are NaN in every column; a fill (NaN now, or
-    // zeros to clean up after one) goes first, the wavefront's own stores to one row stay in order
+    // zeros to clean up after one) goes first, then the barrier, then the column's entries
     const bool fill = a.jt_sparse && (*a.nonfinite != 0 || *a.jt_state == *a.jt_launches - 1u);
-    if (fill) {
-        for (int r = lane; r < OgGen::M; r += 64) jrow[r] = a.z[r];
+    if (fill) {                                         // workgroup-uniform
+        for (int r = tid; r < OgGen::M; r += PACK_THREADS) jrow[r] = a.z[r];
         __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
     }
     const double* in = a.pvals + a.poff[j];
-    for (int i = lane; i < cnt; i += 64) jrow[pattern_row(col, own, i)] = in[i];
+    const int32_t* rows = a.prow + base;
+    for (int i = tid; i < cnt; i += PACK_THREADS) jrow[rows[i]] = in[i];
 }
 
 int defect_blocks() {
@@ -1670,15 +1696,13 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     }
     if (mode == 8) {
         if (ncols <= 0 && !args->ptail) return 0;
-        hipLaunchKernelGGL(ogk_pack, dim3(ncols > 0 ? (ncols + PACK_THREADS / 64 - 1) / (PACK_THREADS / 64) : 1), dim3(PACK_THREADS),
-                           0, stream, *args);
+        hipLaunchKernelGGL(ogk_pack, dim3(ncols > 0 ? ncols : 1), dim3(PACK_THREADS), 0, stream, *args);
         return (int)hipGetLastError();
     }
     if (mode == 9) {
         const int others = (args->uhi - args->ulo) - ncols;
         if (others > 0)
-            hipLaunchKernelGGL(ogk_unpack, dim3((others + PACK_THREADS / 64 - 1) / (PACK_THREADS / 64)),
-                               dim3(PACK_THREADS), 0, stream, *args);
+            hipLaunchKernelGGL(ogk_unpack, dim3(others), dim3(PACK_THREADS), 0, stream, *args);
         return (int)hipGetLastError();
     }
     if (ncols <= 0) return 0;

@@ -106,6 +106,7 @@ struct og_problem_s {
     std::vector<int64_t> indptr;
     std::vector<int32_t> rows;
     int64_t* d_indptr = nullptr;
+    int32_t* d_rows = nullptr;          // the pattern's row indices, flat (pack / unpack read them coalesced)
     // host-pointer entry points: pinned staging ([x | h] up, [packed non-zeros | F | non-finite count] down)
     double* h_up = nullptr;
     double* h_down = nullptr;
@@ -225,8 +226,11 @@ int ensure_pattern(og_problem_s* p) {
     e = rc ? (hipError_t)rc : hipMemcpyAsync(p->rows.data(), d_rows, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost,
                                              p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-    hipFree(d_rows);
-    if (e != hipSuccess) return fail(100 + (int)e, std::string("og_pattern: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        hipFree(d_rows);
+        return fail(100 + (int)e, std::string("og_pattern: ") + hipGetErrorString(e));
+    }
+    p->d_rows = d_rows;
     p->have_pattern = true;
     return 0;
 }
@@ -286,6 +290,8 @@ int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, cons
     ogk_args a;
     fill_args(p, &a, p->d_x, p->d_h, p->d_f0, const_cast<double*>(d_src), lo, hi, false);
     a.poff = p->d_indptr;
+    a.pind = p->d_indptr;
+    a.prow = p->d_rows;
     a.pvals = p->d_down - first;
     a.ptail = p->d_down + nnz;
     rc = p->launch(&a, 8, p->stream);
@@ -529,6 +535,7 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_state);
     hipFree(p->d_trace);
     hipFree(p->d_indptr);
+    hipFree(p->d_rows);
     hipFree(p->d_down);
     hipFree(p->d_shard_off);
     if (p->h_up) hipHostFree(p->h_up);
@@ -641,6 +648,8 @@ int og_pack_dev(og_handle p, const double* d_JT, int32_t lo, int32_t hi, double*
     ogk_args a;
     fill_args(p, &a, nullptr, nullptr, p->d_f0, const_cast<double*>(d_JT), lo, hi, false);
     a.poff = p->d_indptr;
+    a.pind = p->d_indptr;
+    a.prow = p->d_rows;
     a.pvals = d_vals - p->indptr[(size_t)lo];
     rc = p->launch(&a, 8, hip_stream);
     if (rc) return fail(100 + rc, std::string("og_pack_dev: ") + hipGetErrorString((hipError_t)rc));
@@ -657,6 +666,8 @@ int og_unpack_dev(og_handle p, const double* d_vals, int32_t lo, int32_t hi, dou
     a.jt = d_JT - (size_t)lo * (size_t)p->m;       // the kernel indexes rows by absolute column
     a.jt_sparse = 0;                               // plain scatter: no fill
     a.poff = p->d_indptr;
+    a.pind = p->d_indptr;
+    a.prow = p->d_rows;
     a.pvals = const_cast<double*>(d_vals) - p->indptr[(size_t)lo];
     a.ulo = lo;
     a.uhi = hi;
@@ -702,10 +713,36 @@ int og_shard_pack_dev(og_handle p, int32_t rank, const double* d_JT_block, doubl
     ogk_args a;
     fill_args(p, &a, nullptr, nullptr, p->d_f0, const_cast<double*>(d_JT_block), lo, hi, false);
     a.poff = p->d_shard_off;
+    a.pind = p->d_indptr;
+    a.prow = p->d_rows;
     a.pvals = d_send - (int64_t)rank * p->shard_block_vals;
     int rc = p->launch(&a, 8, hip_stream);
     if (rc) return fail(100 + rc, std::string("og_shard_pack_dev: ") + hipGetErrorString((hipError_t)rc));
     return 0;
+}
+
+int og_shard_sweep_dev(og_handle p, int32_t rank, const double* d_x, const double* d_h, double* d_JT_block,
+                       double* d_F0, double* d_send, void* hip_stream) {
+    if (!p || !d_x || !d_h || !d_JT_block || !d_F0 || !d_send) return fail(1, "og_shard_sweep_dev: null argument");
+    if (!p->shard_world || rank < 0 || rank >= p->shard_world)
+        return fail(1, "og_shard_sweep_dev: no shard plan, or rank out of range");
+    const int n = p->n, B = (n + p->shard_world - 1) / p->shard_world;
+    const int lo = std::min(n, rank * B), hi = std::min(n, lo + B);
+    if (hi <= lo) return og_eval_dev(p, d_x, d_F0, hip_stream);        // more ranks than columns: F(x0) only
+    ogk_args a;
+    fill_args(p, &a, d_x, d_h, d_F0, d_JT_block, lo, hi);
+    if (p->sweep_mode == 5 && p->fused_ok && a.jt_sparse) {
+        // ONE launch: F(x0), the block's non-zeros into J_T and, the same values, into this rank's message
+        a.nonfinite = p->d_flags + 3;
+        p->nf_read = a.nonfinite_result;
+        a.poff = p->d_shard_off;
+        a.pvals = d_send - (int64_t)rank * p->shard_block_vals;
+        const int rc = p->launch(&a, 5, hip_stream);
+        if (rc) return launch_failed(p, rc, "og_shard_sweep_dev");
+        return 0;
+    }
+    const int rc = og_fd_sweep_dev(p, d_x, d_h, lo, hi, d_JT_block, d_F0, hip_stream);
+    return rc ? rc : og_shard_pack_dev(p, rank, d_JT_block, d_send, hip_stream);
 }
 
 int og_shard_unpack_dev(og_handle p, int32_t rank, const double* d_recv, double* d_JT_full, void* hip_stream) {
@@ -723,6 +760,8 @@ int og_shard_unpack_dev(og_handle p, int32_t rank, const double* d_recv, double*
     a.jt = d_JT_full;
     a.jt_sparse = 1;
     a.poff = p->d_shard_off;
+    a.pind = p->d_indptr;
+    a.prow = p->d_rows;
     a.pvals = const_cast<double*>(d_recv);
     a.ulo = 0;
     a.uhi = n;
@@ -1122,13 +1161,15 @@ static int multi_enqueue(og_multi_s* mh, const double* x, const double* hstep) {
         if (rc) return rc;
         const int lo = std::min(n, g * B), hi = std::min(n, lo + B);
         double* block = mh->d_full[(size_t)g] + (size_t)lo * (size_t)mh->m;
-        if (hi > lo) rc = og_fd_sweep_dev(p, p->d_x, p->d_h, lo, hi, block, p->d_f0, p->stream);
-        else rc = og_eval_dev(p, p->d_x, p->d_f0, p->stream);          // more devices than columns: F(x) only
-        if (rc) return rc;
         if (G > 1 || mh->rccl) {         // (one device with RCCL: the collective still runs - a plumbing check)
-            rc = og_shard_pack_dev(p, g, block, mh->d_send[(size_t)g], p->stream);
+            // sweep of the device's block, its non-zeros straight into its message (one launch)
+            rc = og_shard_sweep_dev(p, g, p->d_x, p->d_h, block, p->d_f0, mh->d_send[(size_t)g], p->stream);
             if (rc) return rc;
             if (!mh->rccl) OG_HIP(hipEventRecord(mh->packed[(size_t)g], p->stream));
+        } else {
+            if (hi > lo) rc = og_fd_sweep_dev(p, p->d_x, p->d_h, lo, hi, block, p->d_f0, p->stream);
+            else rc = og_eval_dev(p, p->d_x, p->d_f0, p->stream);
+            if (rc) return rc;
         }
     }
     if (G == 1 && !mh->rccl) return 0;

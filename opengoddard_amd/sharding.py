@@ -94,6 +94,14 @@ class HipBackend:
         else:                        # more ranks than columns: this rank only evaluates F(x0)
             self.engine.eval_dev(x.data_ptr(), F0.data_ptr(), self.stream)
 
+    def sweep_and_pack(self, rank, x, h, lo, hi, replica, F0, send):
+        """The rank's block and its message in ONE launch (``og_shard_sweep_dev``)."""
+        from . import _native
+        block = replica[lo:hi] if hi > lo else replica
+        _native.check(self._lib.og_shard_sweep_dev(self.engine._handle, int(rank), x.data_ptr(), h.data_ptr(),
+                                                   block.data_ptr(), F0.data_ptr(), send.data_ptr(), self.stream),
+                      "og_shard_sweep_dev")
+
     def pack(self, rank, lo, hi, replica, send):
         from . import _native
         block = replica[lo:hi] if hi > lo else replica
@@ -177,10 +185,14 @@ class ShardedSweep:
     def step(self, x, h, gather=True):
         """``x``, ``h``: device vectors of the backend.  ``gather=False`` stops after this rank's own block."""
         be = self.backend
-        be.sweep(x, h, self.lo, self.hi, self.replica, self.F0)
         if not gather or (self.world == 1 and not self.exchange_alone):
+            be.sweep(x, h, self.lo, self.hi, self.replica, self.F0)
             return self.replica
-        be.pack(self.rank, self.lo, self.hi, self.replica, self.send)
+        if hasattr(be, "sweep_and_pack"):
+            be.sweep_and_pack(self.rank, x, h, self.lo, self.hi, self.replica, self.F0, self.send)
+        else:
+            be.sweep(x, h, self.lo, self.hi, self.replica, self.F0)
+            be.pack(self.rank, self.lo, self.hi, self.replica, self.send)
         if hasattr(be, "all_gather"):
             be.all_gather(self.send, self.recv, group=self.group)
         else:

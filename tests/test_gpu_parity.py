@@ -518,6 +518,12 @@ def test_sharded_sweep_class_on_the_device(golden):
         indptr, rows = eng.pattern()
         want = full[np.repeat(np.arange(sh.lo, sh.hi), np.diff(indptr[sh.lo:sh.hi + 1])), rows[indptr[sh.lo]:indptr[sh.hi]]]
         assert np.array_equal(sh.send.cpu().numpy()[:want.size], want)
+        # the one-launch form of sweep + pack (og_shard_sweep_dev) writes the same block and the same message
+        sh.send.fill_(-1.0)
+        be.sweep_and_pack(rank, be.upload(x), be.upload(h), sh.lo, sh.hi, sh.replica, sh.F0, sh.send)
+        torch.cuda.synchronize()
+        assert np.array_equal(sh.send.cpu().numpy()[:want.size], want)
+        assert np.array_equal(sh.replica.cpu().numpy()[sh.lo:sh.hi], full[sh.lo:sh.hi])
         eng.unregister_jt_dev(sh.replica[sh.lo:sh.hi].data_ptr())
     eng.close()
 

@@ -298,6 +298,7 @@ def test_fused_launch_work_lists_partition_the_sweep(name):
             assert j not in heavy and j not in owner
             owner[j] = b
             assert lrng[b * cols + c][:2] == col[j][:2]
+            assert lrng[b * cols + c][2] == (col[j][3] & ~(1 << 30)) - col[j][2]
             for g, o, k, row in elem[col[j][0]:col[j][1]]:
                 if P.groups[g].kind == "defect":
                     assert nmv > 0 and P.groups[g].mv_slots[0] == mv0 and len(P.groups[g].mv_slots) == nmv
@@ -312,8 +313,9 @@ def test_fused_launch_work_lists_partition_the_sweep(name):
             assert 0 < cnt <= 32
             items = helem[e0:e0 + cnt]
             assert len({(g, o) for g, o, k, row in items}) == 1                  # one piece of code per slot
-            for g, o, k, row in items:
-                assert row == P.groups[g].outputs[o][0] + k
+            for g, o, k, ppos in items:
+                own = (col[j][3] & ~(1 << 30)) - col[j][2]
+                assert elem[col[j][0] + ppos - own][:3] == [g, o, k]          # its place in the packed order
                 if nmv:
                     gr = P.groups[g]
                     assert gr.kind == "defect" and gr.mv_slots[0] == mv0 and len(gr.mv_slots) == nmv

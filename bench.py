@@ -484,12 +484,21 @@ def main():
             assert all(torch.equal(g, gathered[0]) for g in gathered), "replicas differ between ranks"
             assert all(torch.equal(sh.replica, sweeps[0].replica) for sh in sweeps)
             result["self_check"] = {"replicas_equal_across_ranks": True}
+    eng.close()
+    # The JSON line is the LAST thing on stdout.  RCCL prints its banner through C stdio, which a pipe buffers
+    # until exit: every rank flushes that first, then all ranks meet, then rank 0 prints.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if collective:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    eng.close()
     if collective:
         dist.destroy_process_group()
-
 
 if __name__ == "__main__":
     main()

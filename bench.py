@@ -92,7 +92,9 @@ def measured_traffic(workload, kernel, custom_size):
         except (OSError, ValueError):
             continue
         if entry and entry.get("hbm_bytes_per_launch"):
-            best = {"bytes": entry["hbm_bytes_per_launch"], "source": os.path.basename(path)}
+            best = {"bytes": entry["hbm_bytes_per_launch"], "source": os.path.basename(path),
+                    "mfma": {k: entry[k] for k in ("mfma_f64_instructions_per_launch", "mfma_busy_cycles_per_launch",
+                                                   "mfma_util_pct") if k in entry}}
     return best
 
 
@@ -359,6 +361,9 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": traffic["source"] if traffic else None,
+                     # the D.X path on the matrix cores (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES,
+                     # same committed pass): v_mfma_f64_16x16x4_f64 per launch and busy cycles / (GRBM_GUI_ACTIVE x 1024 SIMDs)
+                     "mfma": (traffic or {}).get("mfma") or None,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      # what a launch really stores: the structural non-zeros of its block, F(x0) and the sweep scratch
                      "bytes_actually_written_per_launch": 8.0 * (nnz_block + 4 * m),

@@ -79,6 +79,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_MFMA_*"))):
         lines.append("| %s | `%s` | %.0f | %.0f | %.3f %% |" % (
             os.path.basename(d)[len("pmc_MFMA_"):], k, g.get("SQ_INSTS_VALU_MFMA_F64", 0.0),
             g.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), util))
+        traffic.setdefault(os.path.basename(d)[len("pmc_MFMA_"):], {}).setdefault(k, {}).update(
+            mfma_f64_instructions_per_launch=g.get("SQ_INSTS_VALU_MFMA_F64", 0.0),
+            mfma_busy_cycles_per_launch=g.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), mfma_util_pct=util)
 lines += ["", "The collocation product is a few thousand 64-cycle MFMAs per sweep (6000 for C3 = 12 state "
           "slices x 25 tiles x 20 k-steps): by design a negligible share of the chip; the sweep is "
           "bounded by the J_T write and by latency chains (DESIGN.md section 4.2).  GRBM_GUI_ACTIVE is "

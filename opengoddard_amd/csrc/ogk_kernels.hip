@@ -991,6 +991,7 @@ __device__ __forceinline__ void finish_eval(const ogk_args& a, const unsigned n_
             // it, the counter is zero again for the next launch (nothing of this is a launch argument)
             __hip_atomic_store(a.jt_launches, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.nonfinite_result, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.ptail) a.ptail[OgGen::M] = (double)bad;      // host transfer: the count travels with F(x0)
             __hip_atomic_store(a.nonfinite, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (bad != 0) __hip_atomic_store(a.jt_state, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = (bad != 0 || st == gen - 1u) ? 1 : 0;

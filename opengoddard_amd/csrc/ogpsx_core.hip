@@ -271,7 +271,8 @@ og_problem_s::host_reg* find_host_reg(og_problem_s* p, const double* JT, int lo,
 // After a sweep / exact Jacobian into the handle's own registered buffer: bring the result to the host.  A
 // registered host matrix receives the packed non-zeros (one pinned copy together with F and the count of
 // non-finite rows) and a scatter; anything else, and any sweep with non-finite rows, the dense block.
-int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, const double* d_src = nullptr) {
+int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, const double* d_src = nullptr,
+                   bool already_packed = false) {
     const size_t need = (size_t)(hi - lo) * (size_t)p->m;
     if (!d_src) d_src = p->d_jt;
     og_problem_s::host_reg* reg = find_host_reg(p, JT, lo, hi);
@@ -287,15 +288,17 @@ int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, cons
     const size_t down = (size_t)nnz + (size_t)p->m + 1;
     rc = ensure_staging(p, down);
     if (rc) return rc;
-    ogk_args a;
-    fill_args(p, &a, p->d_x, p->d_h, p->d_f0, const_cast<double*>(d_src), lo, hi, false);
-    a.poff = p->d_indptr;
-    a.pind = p->d_indptr;
-    a.prow = p->d_rows;
-    a.pvals = p->d_down - first;
-    a.ptail = p->d_down + nnz;
-    rc = p->launch(&a, 8, p->stream);
-    if (rc) return fail(100 + rc, std::string("og_fd_sweep: pack: ") + hipGetErrorString((hipError_t)rc));
+    if (!already_packed) {              // (the one-launch sweep of og_fd_sweep wrote d_down itself)
+        ogk_args a;
+        fill_args(p, &a, p->d_x, p->d_h, p->d_f0, const_cast<double*>(d_src), lo, hi, false);
+        a.poff = p->d_indptr;
+        a.pind = p->d_indptr;
+        a.prow = p->d_rows;
+        a.pvals = p->d_down - first;
+        a.ptail = p->d_down + nnz;
+        rc = p->launch(&a, 8, p->stream);
+        if (rc) return fail(100 + rc, std::string("og_fd_sweep: pack: ") + hipGetErrorString((hipError_t)rc));
+    }
     OG_HIP(hipMemcpyAsync(p->h_down, p->d_down, sizeof(double) * down, hipMemcpyDeviceToHost, p->stream));
     OG_HIP(hipStreamSynchronize(p->stream));
     const bool bad = p->h_down[(size_t)nnz + (size_t)p->m] != 0.0;
@@ -872,6 +875,27 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
     }
     int rc = upload_point(p, x, hstep);
     if (rc) return rc;
+    if (find_host_reg(p, JT, lo, hi) && p->sweep_mode == 5 && p->fused_ok) {
+        // registered host matrix: ONE launch leaves the packed non-zeros, F(x0) and the count of non-finite rows
+        // contiguous in the staging buffer, one pinned copy brings them down
+        rc = ensure_pattern(p);
+        if (rc) return rc;
+        const int64_t first = p->indptr[(size_t)lo], nnz = p->indptr[(size_t)hi] - first;
+        rc = ensure_staging(p, (size_t)nnz + (size_t)p->m + 1);
+        if (rc) return rc;
+        ogk_args a;
+        fill_args(p, &a, p->d_x, p->d_h, p->d_down + nnz, p->d_jt, lo, hi);
+        if (a.jt_sparse) {
+            a.nonfinite = p->d_flags + 3;
+            p->nf_read = a.nonfinite_result;
+            a.poff = p->d_indptr;
+            a.pvals = p->d_down - first;
+            a.ptail = p->d_down + nnz;
+            rc = p->launch(&a, 5, p->stream);
+            if (rc) return launch_failed(p, rc, "og_fd_sweep");
+            return download_block(p, lo, hi, JT, F0, nullptr, true);
+        }
+    }
     rc = og_fd_sweep_dev(p, p->d_x, p->d_h, lo, hi, p->d_jt, p->d_f0, p->stream);
     if (rc) return rc;
     return download_block(p, lo, hi, JT, F0);

@@ -1969,6 +1969,7 @@ struct og_qp_s {
     unsigned* bar = nullptr;
     int* abort_flag = nullptr;
     int coop_mode = 1;                 // 0 never, 1 by size, 2 always (when it fits)
+    int last_iters = 1000;             // active-set changes of the previous subproblem on this handle (a solve starts with many)
     double *d = nullptr, *bm = nullptr, *tvec = nullptr, *rhs = nullptr, *lam = nullptr, *vz = nullptr;
     double *svec = nullptr, *vvec = nullptr, *coef = nullptr, *outn = nullptr;
     int *isact = nullptr, *act = nullptr, *flag = nullptr;
@@ -2283,7 +2284,11 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     // 7.96 / 8.28 ms, single / cooperative).  The single-workgroup kernel is also the one whose sums run in the
     // restatement's order (with exact Jacobians it walks SciPy's path iteration for iteration), so it stays the
     // default there; from 512 on (C4, C5) the cooperative kernel is 1.5-3x faster per subproblem.
-    const bool use_coop = qp->coop_mode == 2 || (qp->coop_mode == 1 && nr >= 512);
+    // Between 256 and 512 free directions the choice follows the previous subproblem: early in a solve (or after a
+    // restart) hundreds of rows move per subproblem and the cooperative kernel's 40 us per change beat the 72-83 us
+    // of single launches; later a handful move and the single-workgroup kernel's cheaper start wins.
+    const bool use_coop = qp->coop_mode == 2 ||
+                          (qp->coop_mode == 1 && (nr >= 512 || (nr >= 256 && qp->last_iters > 96)));
     bool coop_done = false;
     if (nr > 0 && use_coop && coop_slices <= 64 && coop_lds <= LDS_LIMIT) {
         // the whole active-set loop in one cooperative launch
@@ -2355,6 +2360,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         if (hst.phase < 2) hst.phase = 2;   // nothing to move: feasibility was settled by k_ldp_setup
     }
     if (iterations) *iterations = hst.iters;
+    qp->last_iters = hst.iters;
     if (debug_stages())
         fprintf(stderr, "[ogsqp] LDP finished: phase %d after %d iterations, %d active, unfixable-row flag %d\n",
                 hst.phase, hst.iters, hst.q, hflag[1]);

@@ -361,6 +361,10 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": traffic["source"] if traffic else None,
+                     # the honest bandwidth statement: bytes the PMC counters saw per launch over the launch's duration,
+                     # against the peak - small, because the launch is a latency chain that moves only the non-zeros
+                     "hbm_frac_on_measured_traffic": (traffic["bytes"] / (kern_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                      if traffic else None),
                      # the D.X path on the matrix cores (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES,
                      # same committed pass): v_mfma_f64_16x16x4_f64 per launch and busy cycles / (GRBM_GUI_ACTIVE x 1024 SIMDs)
                      "mfma": (traffic or {}).get("mfma") or None,

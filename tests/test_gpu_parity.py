@@ -118,6 +118,20 @@ def test_against_numpy_restatement_without_generated_code(name, golden):
     err, bound = np.abs(JT[cols] - JT_np), fd_noise_bound(JT_np, scale, h[cols])
     assert np.all(err <= bound), "worst ratio %.3g" % np.max(err / np.maximum(bound, 1e-300))
     assert_zero_pattern(eng.program, cols, JT[cols], JT_np)
+    if eng.n <= 320:
+        # and SciPy's own approx_derivative (the third-party code the reference really runs: scipy/optimize/
+        # _slsqp_py.py:299-313 -> _numdiff.approx_derivative) on the NumPy callbacks, here on the GPU box
+        try:
+            from scipy.optimize._numdiff import approx_derivative
+        except Exception:
+            approx_derivative = None
+        if approx_derivative is not None:
+            def stacked(p):
+                return np_path.stacked_values(prob, obj, np.array(p, dtype=float))
+            J_sp = approx_derivative(stacked, x, method="2-point", abs_step=np_path.ABS_STEP, bounds=(lb, ub))
+            err, bound = np.abs(JT - J_sp.T), fd_noise_bound(J_sp.T, scale, h)
+            assert np.all(err <= bound), "vs scipy approx_derivative: worst ratio %.3g" % np.max(err / np.maximum(bound, 1e-300))
+            assert np.array_equal(J_sp.T, np_path.sweep(prob, obj, x)[2])      # the restatement IS SciPy's loop
     eng.close()
 
 

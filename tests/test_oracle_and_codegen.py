@@ -355,3 +355,20 @@ def test_batch_last_baseline_matches_the_column_loop(name):
     assert np.array_equal(h, h2)
     assert np.all(np.abs(F0 - G0) <= 1e-11 * np.maximum(1.0, np.abs(F0)))
     assert np.abs(JT - KT).max() <= 5e-7 * np.abs(JT).max()          # 2e-8..1e-7 of max|J| observed
+
+
+@pytest.mark.parametrize("name", ["brachistochrone", "goddard", "polar_tsto_shipped", "table_ascent"])
+def test_restated_column_loop_is_scipys_approx_derivative(name):
+    """oracle/np_path.py restates ``_dense_difference`` ('2-point', scipy/optimize/_numdiff.py:584-625) and SciPy's
+    step rule: on the SciPy that is installed it must reproduce ``approx_derivative`` - the third-party code the
+    reference really runs through ``minimize(method='SLSQP')`` without ``jac`` - bit for bit."""
+    approx_derivative = pytest.importorskip("scipy.optimize._numdiff").approx_derivative
+    prob, obj = problems.build(name)
+    lb, ub = np_path.bounds_arrays(prob)
+    rng = np.random.default_rng(1)
+    x0 = np.clip(prob.p, lb, ub)
+    for x in (x0, np.clip(x0 + 1e-3 * rng.standard_normal(x0.size), lb, ub)):
+        J = approx_derivative(lambda p: np_path.stacked_values(prob, obj, np.array(p, dtype=float)), x,
+                              method="2-point", abs_step=np_path.ABS_STEP, bounds=(lb, ub))
+        F0, h, JT = np_path.sweep(prob, obj, x)
+        assert np.array_equal(np.atleast_2d(J).T, JT)

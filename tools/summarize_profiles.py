@@ -82,10 +82,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_MFMA_*"))):
         traffic.setdefault(os.path.basename(d)[len("pmc_MFMA_"):], {}).setdefault(k, {}).update(
             mfma_f64_instructions_per_launch=g.get("SQ_INSTS_VALU_MFMA_F64", 0.0),
             mfma_busy_cycles_per_launch=g.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), mfma_util_pct=util)
-lines += ["", "The collocation product is a few thousand 64-cycle MFMAs per sweep (6000 for C3 = 12 state "
-          "slices x 25 tiles x 20 k-steps): by design a negligible share of the chip; the sweep is "
-          "bounded by the J_T write and by latency chains (DESIGN.md section 4.2).  GRBM_GUI_ACTIVE is "
-          "inflated by counter collection, so MfmaUtil here is a lower bound.", ""]
+lines += ["", "The collocation products are a few thousand 64-cycle MFMAs per launch (C3: 9 100 = 60 tile workgroups x "
+          "(5 column tiles + 1 shared base product) x 20 k-steps, 90 light and 15 heavy-part service chains, 10 "
+          "evaluation tiles): by design a negligible share of the chip's FP64 matrix peak; the launch is bounded by "
+          "latency chains (DESIGN.md section 4.3).  GRBM_GUI_ACTIVE is inflated by counter collection, so MfmaUtil "
+          "here is a lower bound.", ""]
 with open(os.path.join(dst, "%s_traffic.json" % rnd), "w") as fh:
     json.dump(traffic, fh, indent=1)
 with open(os.path.join(dst, "%s_summary.md" % rnd), "w") as fh:

@@ -125,8 +125,50 @@ def smooth_knots():
     return prob, Params()
 
 
+def running_cost_shapes():
+    """Sequential sums of every shape the cached-term path distinguishes (codegen ``sum_term_q``, kernels
+    ``XColT``): a two-phase running cost whose integrand reads two variables at the same node (one perturbed
+    term per column), the phase's final time (every term is perturbed: evaluated in place), and a constant
+    vector; plus a user sum inside a constraint row."""
+    def dynamics(prob, obj, section):
+        dx = Dynamics(prob, section)
+        dx[0] = prob.states(1, section)
+        dx[1] = prob.controls(0, section) - 0.3 * prob.states(0, section)
+        return dx()
+
+    def equality(prob, obj):
+        rows = Condition()
+        rows.equal(prob.states(0, 0)[0], 0.1)
+        rows.equal(prob.states(1, 0)[0], 0.0)
+        return rows()
+
+    def inequality(prob, obj):
+        rows = Condition()
+        rows.upper_bound(prob.controls_all_section(0), 2.0)
+        rows.lower_bound(prob.time_final(0), 0.2)
+        rows.lower_bound(prob.time_final(1), 1.2)
+        return rows()
+
+    def running(prob, obj):
+        u = prob.controls_all_section(0)
+        v = prob.states_all_section(1)
+        tf = prob.time_final(-1)
+        return (0.5 * u ** 2 + 0.1 * u * v) * tf + obj.k * np.cos(v)
+
+    prob = Problem([0.0, 1.0, 2.0], [20, 37], [2, 2], [1, 1], 3)
+    rng = np.random.default_rng(8)
+    prob.p[:-2] = rng.uniform(-1.0, 1.0, prob.number_of_variables - 2)
+    prob.dynamics = [dynamics, dynamics]
+    prob.knot_states_smooth = [True]
+    prob.cost = lambda prob, obj: prob.time_final(-1)
+    prob.running_cost = running
+    prob.equality = equality
+    prob.inequality = inequality
+    return prob, Params()
+
+
 CASES = {"bryson_denham": bryson_denham, "ragged_two_phase": ragged_two_phase,
-         "smooth_knots": smooth_knots}
+         "smooth_knots": smooth_knots, "running_cost_shapes": running_cost_shapes}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

@@ -377,6 +377,7 @@ def main():
                      "measured_fill_peak_GBs": peaks["fill"] if peaks else None,
                      "measured_copy_peak_GBs": peaks["copy"] if peaks else None,
                      "frac_of_measured_fill_peak": achieved / peaks["fill"] if peaks else None,
+                     "frac_of_measured_copy_peak": achieved / peaks["copy"] if peaks else None,
                      # the two-launch form of the same step (OGPSX_SWEEP=split, or an unregistered buffer), timed
                      # in this run: the FD sweep kernel on its own, and evaluation + sweep as a step
                      "split_eval_kernel_ms_mean": eval_ms_mean,

@@ -63,8 +63,10 @@ int og_problem_dims(og_handle h, int32_t* n, int32_t* m, int32_t* m_eq, int32_t*
 
 /* How og_fd_sweep(_dev) runs on this handle: 5 = evaluation and structured sweep in ONE launch (ogk_fused),
  * 1 = the same two kernels as two launches, 2 = evaluation + literal dense sweep (validation).  Chosen at
- * og_problem_create: OGPSX_SWEEP=fused|split|dense, default by size (one launch while the Jacobian is at
- * most 100 MB - there the kernel boundary is a third of the step; above, the two launches are faster).
+ * og_problem_create: OGPSX_SWEEP=fused|split|dense; the default is 5 at every size.  The one-launch form writes
+ * the non-zeros only, so it needs a persistent-zero output (og_jt_register_dev / _host; the host-pointer entry
+ * points register their own staging buffer): a sweep into an unregistered device buffer runs as the two launches
+ * of mode 1 from the same handle, with identical results.
  * No reference counterpart: SciPy's approx_derivative has one way to run (scipy/optimize/_numdiff.py:584-625). */
 int og_sweep_mode(og_handle h);
 

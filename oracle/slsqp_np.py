@@ -45,14 +45,22 @@ CONSISTENT = 1e-9        # ... redundant if its residual is below this * (1 + ma
 # ----------------------------------------------------------------------------------------------
 # least-distance problem, Goldfarb-Idnani
 # ----------------------------------------------------------------------------------------------
-def ldp_gi(W, b, full_norms=None, reference=None, max_iter=None):
+def ldp_gi(W, b, full_norms=None, reference=None, max_iter=None, warm=None, active_out=None):
     """``min 1/2 |y|^2  s.t.  W y + b >= 0``.  Returns ``(y, u, status, iterations)`` with
     multipliers ``u >= 0`` (``y = W' u``); status 1 solved, 4 incompatible, 3 iteration limit.
 
     ``full_norms[j]`` is the length of constraint ``j``'s normal before it was projected onto the
     null space of the equalities: a row whose projection is shorter than ``DEPENDENT`` times that
     is a combination of the equalities (e.g. an inequality that repeats an equality) and cannot
-    be influenced by ``y``; it is left out."""
+    be influenced by ``y``; it is left out.
+
+    ``warm``: rows to start from instead of the empty active set (the rows active at the solution of the previous
+    subproblem of an SQP run).  The dual method may start from any S-pair - a point that minimises ``|y|^2`` on
+    the rows of a linearly independent set taken as equalities, with non-negative multipliers: the warm rows are
+    factorised in the given order (rows that depend on the ones before them are left out), the minimiser on
+    them and its multipliers are computed, and while a multiplier is negative the row with the most negative
+    one is taken out (one iteration each, like a partial step).  What is left is an S-pair; the solution is the
+    same, reached in fewer changes.  ``active_out`` (a list) receives the rows active at the solution."""
     mt, nr = W.shape
     y = np.zeros(nr)
     u = np.zeros(mt)
@@ -71,10 +79,39 @@ def ldp_gi(W, b, full_norms=None, reference=None, max_iter=None):
     is_active = np.zeros(mt, dtype=bool)
     iters = 0
     limit = max_iter if max_iter is not None else 10 * (mt + nr) + 100
+    if warm:
+        for p in warm:
+            p = int(p)
+            if not usable[p] or is_active[p] or len(active) >= nr:
+                continue
+            d = Q.T @ W[p]
+            q = len(active)
+            if float(d[q:] @ d[q:]) <= (DEPENDENT * norms[p]) ** 2:
+                continue
+            Q, R = _append_column(Q, R, d[:q], d[q:])
+            active.append(p)
+            is_active[p] = True
+        while active:
+            q = len(active)
+            y1 = _forward_substitute(R, -b[active])         # R' y1 = -b_A: the warm rows hold as equalities
+            ua = _back_substitute(R, y1)                    # y = N u
+            k = int(np.argmin(ua))
+            if not ua[k] < 0.0:
+                y = Q[:, :q] @ y1
+                u[active] = ua
+                s = W @ y + b
+                s[active] = 0.0
+                break
+            iters += 1
+            is_active[active[k]] = False
+            Q, R = _delete_column(Q, R, k)
+            del active[k]
     while True:
         viol = np.where(usable & ~is_active, s / scale + own + FEASIBLE * np.sqrt(y @ y), np.inf)
         p = int(np.argmin(viol))
         if not viol[p] < 0.0:
+            if active_out is not None:
+                active_out[:] = active
             return y, u, 1, iters
         normal = W[p]
         up = 0.0
@@ -116,6 +153,15 @@ def ldp_gi(W, b, full_norms=None, reference=None, max_iter=None):
             is_active[active[k]] = False
             Q, R = _delete_column(Q, R, k)
             del active[k]
+
+
+def _forward_substitute(R, rhs):
+    """Solve ``R' x = rhs`` (``R`` upper triangular)."""
+    q = R.shape[0]
+    out = np.zeros(q)
+    for i in range(q):
+        out[i] = (rhs[i] - R[:i, i] @ out[:i]) / R[i, i]
+    return out
 
 
 def _back_substitute(R, rhs):
@@ -165,23 +211,49 @@ def _delete_column(Q, R, k):
 # ----------------------------------------------------------------------------------------------
 # QP subproblem
 # ----------------------------------------------------------------------------------------------
-def qp_solve(Z, g, C, c, G, h, lb, ub):
+def _lq_lapack(C, Z):
+    """``[C Z; Z] Q = [L 0; J]`` with LAPACK's Householder QR of ``(C Z)'`` - the same factorisation as the
+    loop in :func:`qp_solve` up to the signs of the columns (the QP solution does not depend on them), two orders
+    of magnitude faster at n > 1000.  Returns ``None`` when a pivot is small enough for the redundancy rule of the
+    loop to matter (the caller then runs the loop)."""
+    import scipy.linalg as sl
+    meq = C.shape[0]
+    Q, R = sl.qr((C @ Z).T, mode="full")
+    diag = np.abs(np.diag(R)[:meq])
+    if meq and not diag.min() > 1e3 * REDUNDANT * diag.max():
+        return None
+    T = np.empty((meq + Z.shape[0], Z.shape[1]))
+    T[:meq, :meq] = R[:meq, :meq].T
+    T[:meq, meq:] = 0.0
+    T[meq:] = Z @ Q
+    return T
+
+
+def qp_solve(Z, g, C, c, G, h, lb, ub, lq="loop", warm=None):
     """``min 1/2 d'Bd + g'd`` with ``B^-1 = Z Z'``; ``C d + c = 0``; ``G d + h >= 0``;
     ``lb <= d <= ub`` (non-finite entries: no bound).
 
     Returns ``(d, lam, mu_g, mode, Znew, info)``: multipliers of the equalities (free sign) and of
     the general inequalities (>= 0) in the convention ``grad L = B d + g - C'lam - G'mu - ...``;
     ``mode`` 1 solved / 4 incompatible / 6 singular C; ``Znew = Z Q`` is an equally valid inverse
-    factor whose first ``meq`` columns are B-conjugate to the null space of ``C``."""
+    factor whose first ``meq`` columns are B-conjugate to the null space of ``C``.
+
+    ``lq="lapack"``: the LQ sweep through LAPACK (:func:`_lq_lapack`) - for the BASELINE sizes, where the
+    reflector-by-reflector loop below takes minutes.  ``warm``: constraint ids ``("g", j)`` / ``("l", i)`` /
+    ``("u", i)`` the active-set method starts from (see :func:`ldp_gi`); ``info["active"]`` returns the ids
+    active at the solution."""
     n = Z.shape[0]
     meq = C.shape[0]
     info = {"ldp_iterations": 0}
     if meq > n:
         return np.zeros(n), np.zeros(meq), np.zeros(G.shape[0]), 2, Z, info
     # LQ of C Z with the same orthogonal transformations applied to Z
-    T = np.vstack([C @ Z, Z])
+    T = _lq_lapack(C, Z) if lq == "lapack" else None
+    fast = T is not None
+    if not fast:
+        T = np.vstack([C @ Z, Z])
     dmax = 0.0
-    for k in range(meq):
+    for k in range(0 if not fast else meq, meq):
         row = T[k, k:]
         sigma = float(np.sqrt(row @ row))
         # what is left of a row that depends on the earlier ones is rounding noise: no reflector from it
@@ -224,12 +296,22 @@ def qp_solve(Z, g, C, c, G, h, lb, ub):
                            np.sqrt(np.einsum("ij,ij->i", J, J))[has_lb],
                            np.sqrt(np.einsum("ij,ij->i", J, J))[has_ub]])
     reference = np.concatenate([np.abs(h), np.abs(lb[has_lb]), np.abs(ub[has_ub])])
-    y, u, status, iters = ldp_gi(W, b, full, reference)
+    mg = G.shape[0]
+    ilb, iub = np.nonzero(has_lb)[0], np.nonzero(has_ub)[0]
+    rows = None
+    if warm:
+        where = {("g", j): j for j in range(mg)}
+        where.update({("l", int(i)): mg + k for k, i in enumerate(ilb)})
+        where.update({("u", int(i)): mg + ilb.size + k for k, i in enumerate(iub)})
+        rows = [where[w] for w in warm if w in where]
+    final = []
+    y, u, status, iters = ldp_gi(W, b, full, reference, warm=rows, active_out=final)
     info["ldp_iterations"] = iters
+    info["active"] = [("g", r) if r < mg else ("l", int(ilb[r - mg])) if r < mg + ilb.size
+                      else ("u", int(iub[r - mg - ilb.size])) for r in final]
     if status != 1:
         return np.zeros(n), np.zeros(meq), np.zeros(G.shape[0]), 4 if status == 4 else 3, Z, info
     d = d_eq + Y @ y
-    mg = G.shape[0]
     mu_g = u[:mg]
     ub_mult = np.zeros(n)
     ub_mult[has_lb] += u[mg:mg + int(has_lb.sum())]

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Golden vectors for the SQP core at the BASELINE sizes: what SciPy 1.15.3's Fortran SLSQP does on C3 / C4.
+
+Run in the build container only (it imports the reference from /root/reference, which never travels):
+
+    python tools/make_golden_slsqp.py [--only NAME ...]
+
+One major iteration of SciPy's SLSQP costs 16 s at C3 (n = 1442) and 25 s at C4 (n = 2001), so the replay tests
+of ``tests/test_slsqp_core.py`` cannot run SciPy at these sizes on every test run (they do for n <= 282); its
+first major iterations are captured here instead, twice:
+
+``*_twin``  SciPy driven by this repo's callbacks (the compiled CPU twin of the generated code, forward
+            differences with SciPy's step rule) - the inputs the replay on the GPU box reproduces bit for bit.
+            Stored: the points at which SciPy asks for the constraint Jacobian (= its accepted iterates),
+            ``status / nit / nfev / njev / fun``.
+``*_ref``   the **reference itself**: ``OpenGoddard.optimize.Problem.solve`` of /root/reference
+            (``optimize.py:723-749``: callbacks without ``jac=``, SciPy differencing them) on the same problem
+            definition, the iterate after every major iteration taken from SciPy's ``callback=`` hook.
+            The two runs see Jacobians that differ by forward-difference rounding (1e-8 relative), so their
+            iterates agree to about 1e-6 of the step, not to the bit; the test states that bound.
+
+Nothing is written under /root/reference.
+"""
+import argparse
+import os
+import sys
+import time
+import warnings
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+warnings.filterwarnings("ignore")
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REF)
+sys.path.append(REPO)
+sys.path.append(os.path.join(REPO, "tests"))
+sys.path.append(os.path.join(REPO, "tools"))
+
+import numpy as np                      # noqa: E402
+import scipy                            # noqa: E402
+import scipy.optimize as sciopt         # noqa: E402
+
+import make_golden                      # noqa: E402  (capture(): the reference's call site intercepted)
+import OpenGoddard.optimize as ref      # noqa: E402
+
+assert ref.__file__.startswith(REF), ref.__file__
+
+CASES = {"polar_tsto": dict(maxiter=4, ftol=1e-6), "low_thrust": dict(maxiter=3, ftol=1e-6)}
+
+
+def run_twin(name, maxiter, ftol):
+    from test_slsqp_core import Callbacks
+    cb = Callbacks(name)
+    t = time.time()
+    res = cb.scipy(maxiter, ftol)
+    print("  twin-driven SciPy: status %d nit %d nfev %d njev %d fun %.10g (%.0f s)" % (
+        res.status, res.nit, res.nfev, res.njev, res.fun, time.time() - t), flush=True)
+    return dict(iterates_twin=np.array(cb.iterates), x_twin=np.array(res.x), status_twin=np.int64(res.status),
+                nit_twin=np.int64(res.nit), nfev_twin=np.int64(res.nfev), njev_twin=np.int64(res.njev),
+                fun_twin=np.float64(res.fun), x0=np.array(cb.prob.p, dtype=float), lb=cb.lb, ub=cb.ub,
+                m_eq=np.int64(cb.meq))
+
+
+def run_reference(name, maxiter, ftol):
+    from opengoddard_amd import problems
+    holder = {}
+
+    def run():
+        prob, obj = problems.build(name, api=ref)
+        holder["prob"] = prob
+        prob.solve(obj)
+
+    got = make_golden.capture(run)
+    iterates = []
+    t = time.time()
+    res = sciopt.minimize(got["fun"], got["x0"].copy(), args=got["args"], bounds=got["bounds"],
+                          constraints=got["constraints"], jac=got["jac"], method="SLSQP",
+                          callback=lambda xk: iterates.append(np.array(xk, dtype=float)),
+                          options={"disp": False, "maxiter": maxiter, "ftol": ftol})
+    print("  the reference (Problem.solve's own call): status %d nit %d nfev %d fun %.10g (%.0f s)" % (
+        res.status, res.nit, res.nfev, res.fun, time.time() - t), flush=True)
+    return dict(iterates_ref=np.array(iterates), x_ref=np.array(res.x), status_ref=np.int64(res.status),
+                nit_ref=np.int64(res.nit), nfev_ref=np.int64(res.nfev), fun_ref=np.float64(res.fun))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    for name, opts in CASES.items():
+        if a.only and name not in a.only:
+            continue
+        print("golden slsqp:", name, opts, flush=True)
+        data = dict(maxiter=np.int64(opts["maxiter"]), ftol=np.float64(opts["ftol"]),
+                    scipy_version=np.array(scipy.__version__))
+        data.update(run_twin(name, **opts))
+        data.update(run_reference(name, **opts))
+        k = min(len(data["iterates_ref"]), len(data["iterates_twin"]) - 1)
+        for i in range(k):
+            step = np.max(np.abs(data["iterates_twin"][i + 1] - data["iterates_twin"][i]))
+            diff = np.max(np.abs(data["iterates_ref"][i] - data["iterates_twin"][i + 1]))
+            print("  iterate %d: |twin-driven - reference| = %.3e, step %.3e" % (i + 1, diff, step), flush=True)
+        np.savez_compressed(os.path.join(OUT, "slsqp_%s.npz" % name), **data)
+
+
+if __name__ == "__main__":
+    main()

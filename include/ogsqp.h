@@ -86,6 +86,17 @@ int og_qp_solve(og_qp_handle qp, const double* A, const double* g, const double*
                 const double* dl, const double* du, int32_t augmented, double rho, double* d,
                 double* mult, double* bound_mult, int32_t* status, int32_t* iterations);
 
+/* The rows of the inequality part that were active (multiplier > 0 or just added) at the solution of the last
+ * solved subproblem, in this numbering: j < m_ineq general inequality j; m_ineq + 2 i lower bound of variable i;
+ * m_ineq + 2 i + 1 its upper bound (i = n: the relaxation variable of an augmented solve).  The next solve on the
+ * handle starts its active-set method from them (rows appended to the LQ sweep of the equalities, multipliers
+ * checked, negative ones dropped - DESIGN.md section 9): the solution is the same, late in an SQP run it is reached
+ * in a handful of changes instead of one per active row.  og_qp_set_active replaces the list (count = 0: the next
+ * solve starts from the empty set, like lsq()'s NNLS does every time); OGSQP_WARM=0 in the environment turns the
+ * warm start off for a whole process.  No reference counterpart (slsqp_optmz.f keeps no state between calls of lsq). */
+int og_qp_get_active(og_qp_handle qp, int32_t* ids, int32_t capacity, int32_t* count);
+int og_qp_set_active(og_qp_handle qp, const int32_t* ids, int32_t count);
+
 /* Powell-damped BFGS (slsqp label 260-320) on the factor: s = step, eta = change of the
  * Lagrangian gradient, Bs = B s.  *reset_needed = 1 when the update is undefined (s'Bs or the
  * damped s'eta not positive) and the factor was left unchanged. */

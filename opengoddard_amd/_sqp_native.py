@@ -27,6 +27,8 @@ SIGNATURES = {
                                   C.c_double, _dp, _dp, _dp, _ip, _ip, C.c_void_p]),
     "og_qp_solve": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp,
                               _dp, _ip, _ip]),
+    "og_qp_get_active": (C.c_int, [C.c_void_p, _ip, C.c_int32, _ip]),
+    "og_qp_set_active": (C.c_int, [C.c_void_p, _ip, C.c_int32]),
     "og_qp_bfgs": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "og_jt_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _dp, _dp, C.c_void_p]),
     "og_qp_last_error": (C.c_char_p, []),
@@ -129,6 +131,20 @@ class QpCore:
                                     1 if augmented else 0, float(rho), _p(d), _p(mult), _p(bm),
                                     C.byref(status), C.byref(iters)), "og_qp_solve")
         return d, mult[:self.m], bm, status.value, iters.value
+
+    def get_active(self):
+        """Rows active at the last solution (``og_qp_get_active`` numbering): where the next solve starts."""
+        count = C.c_int32(0)
+        check(self._lib.og_qp_get_active(self._handle, None, 0, C.byref(count)), "og_qp_get_active")
+        ids = np.zeros(max(count.value, 1), dtype=np.int32)
+        check(self._lib.og_qp_get_active(self._handle, ids.ctypes.data_as(_ip), count.value, C.byref(count)),
+              "og_qp_get_active")
+        return ids[:count.value].copy()
+
+    def set_active(self, ids=()):
+        """Replace the warm-start rows; ``set_active()`` makes the next solve start from the empty active set."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        check(self._lib.og_qp_set_active(self._handle, ids.ctypes.data_as(_ip), int(ids.size)), "og_qp_set_active")
 
     def bfgs(self, s, eta, Bs):
         """Damped BFGS on the factor; returns True when the caller has to reset instead."""

@@ -90,7 +90,8 @@ SQP_LIB = os.path.join(LIBDIR, "libogsqp.so")
 def build_sqp(force=False):
     """``lib/libogsqp.so``: the QP subproblem / BFGS kernels of the SQP driver (``include/ogsqp.h``)."""
     os.makedirs(LIBDIR, exist_ok=True)
-    sources = [os.path.join(CSRC, "ogsqp.hip"), os.path.join(HERE, "..", "include", "ogsqp.h")]
+    sources = [os.path.join(CSRC, "ogsqp.hip"), os.path.join(CSRC, "ogsqp_rows.h"),
+               os.path.join(HERE, "..", "include", "ogsqp.h")]
     stamp_path = SQP_LIB + ".stamp"
     want = _digest_files(sources)
     if not force and os.path.exists(SQP_LIB) and os.path.exists(stamp_path):

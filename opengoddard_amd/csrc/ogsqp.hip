@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <iterator>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -143,8 +144,10 @@ __device__ __forceinline__ void block_argmin(double& v, int& idx, double* redv, 
 // out[j][k] = sum_i A(i, col0 + j) * Jw[i][k]     (rows x nq, row-major, leading dimension ldw)
 // 64 x 64 output tile per workgroup, 4 wavefronts of 2 x 2 MFMA 16x16x4 tiles, K staged through
 // LDS 16 rows at a time.  Both operands are read along their contiguous direction.
+// sel (optional): output row j takes the column col0 + sel[j] of A instead of col0 + j (rows of a warm start).
 __global__ __launch_bounds__(256) void k_gemm_tn(AView A, int col0, int rows, const double* __restrict__ Jw,
-                                                 int ldw, int nq, double* __restrict__ out) {
+                                                 int ldw, int nq, double* __restrict__ out,
+                                                 const int* __restrict__ sel) {
     __shared__ double As[16][80];
     __shared__ double Bs[16][80];
     const int j0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(AView A, int col0, int rows, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int j = j0 + jb + e, k = k0 + jb + e;
-            As[ii][jb + e] = (i < nq && j < rows) ? aval(A, i, col0 + j) : 0.0;
+            As[ii][jb + e] = (i < nq && j < rows) ? aval(A, i, col0 + (sel ? sel[j] : j)) : 0.0;
             Bs[ii][jb + e] = (i < nq && k < nq) ? Jw[(long)i * ldw + k] : 0.0;
         }
         __syncthreads();
@@ -1911,6 +1914,8 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
 #undef CMARK
 }
 
+#include "ogsqp_rows.h"
+
 // d = clip(deq + Y y), multipliers of the general inequalities and of the bounds
 __global__ __launch_bounds__(256) void k_finish_step(const double* __restrict__ Jw, int ld, int meq, int nq, int nr,
                                                      int mg, const double* __restrict__ y, const double* __restrict__ deq,
@@ -1968,6 +1973,15 @@ struct og_qp_s {
     CoopPartial* cpart = nullptr;
     unsigned* bar = nullptr;
     int* abort_flag = nullptr;
+    int gi_mode = 0;                   // 0 rows (k_rows_decide / k_rows_apply, the default), 1 the two older kernels
+    bool warm_enabled = true;          // start the active-set method from the previous subproblem's active rows
+    std::vector<int> warm;             // ... in the canonical numbering of og_qp_get_active
+    bool warm_use = true;              // ... when the last two solutions shared most of their active rows (early in an
+                                       // SQP run they do not: taking the stale rows out again costs more than it saves)
+    double *dots = nullptr, *dvec = nullptr, *rvec = nullptr;
+    GiPartial *price = nullptr, *ratio = nullptr;
+    RowsDecision* rec = nullptr;
+    int *d_warm = nullptr, *d_slot = nullptr;
     int coop_mode = 1;                 // 0 never, 1 by size, 2 always (when it fits)
     int last_iters = 1000;             // active-set changes of the previous subproblem on this handle (a solve starts with many)
     double *d = nullptr, *bm = nullptr, *tvec = nullptr, *rhs = nullptr, *lam = nullptr, *vz = nullptr;
@@ -2017,6 +2031,10 @@ size_t gi_lds_bytes(int nr, int qcap) {
     return (size_t)(2 * nr + 6 * qcap + 64) * sizeof(double);
 }
 
+size_t rows_lds_bytes(int nr, int qcap) {          // k_rows_decide: the incoming normal, the dual direction, a reflector
+    return (size_t)(nr + 2 * qcap + 16) * sizeof(double);
+}
+
 }  // namespace
 
 extern "C" {
@@ -2041,10 +2059,10 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     qp->qcap = qp->n1 - (m_eq < qp->n1 ? m_eq : qp->n1);
     if (qp->qcap < 1) qp->qcap = 1;
     const size_t n1 = qp->n1, mt = (size_t)qp->mg + 2 * n1, qc = qp->qcap;
-    if (gi_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) {
+    if (rows_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) {
         delete qp;
-        return fail(4, "og_qp_create: null space of the equalities too large for the LDS-resident update "
-                       "(n + 1 - m_eq = " + std::to_string(qc) + ")");
+        return fail(4, "og_qp_create: null space of the equalities too large for the LDS-resident part of the "
+                       "active-set update (n + 1 - m_eq = " + std::to_string(qc) + ")");
     }
     if (n1 > (size_t)LQ_PT_MAX * LQ_CPT_MAX) {
         delete qp;
@@ -2052,8 +2070,10 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     }
     int rc = 0;
     auto A = [&](auto** p, size_t cnt) { if (!rc) rc = dev_alloc(qp, p, cnt); };
-    A(&qp->Z, n1 * n1); A(&qp->Jw, n1 * n1); A(&qp->Tc, (size_t)qp->meq * n1); A(&qp->GJ, (size_t)qp->mg * n1);
-    A(&qp->diagL, qp->meq); A(&qp->Vp, (size_t)LQ_NB * n1); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    // Tc and diagL: the equalities, then the rows of a warm start (at most qcap of them) behind them in the sweep
+    A(&qp->Z, n1 * n1); A(&qp->Jw, n1 * n1); A(&qp->Tc, ((size_t)qp->meq + qc) * n1); A(&qp->GJ, (size_t)qp->mg * n1);
+    A(&qp->diagL, qp->meq + qc); A(&qp->dots, (size_t)qp->mg + n1); A(&qp->dvec, n1); A(&qp->rvec, qc);
+    A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc); A(&qp->Vp, (size_t)LQ_NB * n1); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
     A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 2); A(&qp->csbuf, 2 * qc);
@@ -2072,6 +2092,11 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     if (!rc && hipFuncSetAttribute((const void*)k_trsv, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)LDS_LIMIT) != hipSuccess)
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
+    if (!rc && (hipFuncSetAttribute((const void*)k_rows_decide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LDS_LIMIT) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_rows_invert, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LDS_LIMIT) != hipSuccess))
+        rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
     if (rc) {
         og_qp_destroy(qp);
         return rc;
@@ -2084,6 +2109,12 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         // 12 us per change, its bandwidth pays from a null space of about 500 on)
         const char* mode = getenv("OGSQP_GI");
         qp->coop_mode = !can ? 0 : (mode && std::string(mode) == "single") ? 0 : (mode && std::string(mode) == "coop") ? 2 : 1;
+        // the default is the row-parallel method in rotated coordinates (ogsqp_rows.h); "single" / "coop" / "old"
+        // select the two older kernels (kept for comparison; they need their own, smaller, LDS budget)
+        qp->gi_mode = (mode && (std::string(mode) == "single" || std::string(mode) == "coop" || std::string(mode) == "old")) ? 1 : 0;
+        if (qp->gi_mode == 1 && gi_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) qp->gi_mode = 0;
+        const char* warm = getenv("OGSQP_WARM");
+        qp->warm_enabled = !(warm && std::string(warm) == "0");
     }
     *out = qp;
     return og_qp_reset(qp);
@@ -2166,18 +2197,50 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     OG_STAGE("copy_factor");
     hipLaunchKernelGGL(k_copy_factor, dim3((nq + 255) / 256, nq), dim3(256), 0, s, qp->Z, qp->Jw, n1, n, nq,
                        augmented ? 1.0 / rho : 0.0);
-    if (meq) {
+    // ---- rows of a warm start: active at the solution of the previous subproblem, appended to the sweep
+    int nwarm = 0;
+    if (qp->gi_mode == 0 && qp->warm_enabled && qp->warm_use && nr > 0 && !qp->warm.empty()) {
+        std::vector<int> general, bound;
+        for (int id : qp->warm) {
+            if (id < mg) {
+                general.push_back(id);
+            } else {
+                const int i = (id - mg) >> 1, upper = (id - mg) & 1;
+                if (i < nq) bound.push_back(mg + (upper ? nq : 0) + i);
+            }
+        }
+        std::vector<int> ids(general);
+        ids.insert(ids.end(), bound.begin(), bound.end());
+        if ((int)ids.size() > nr) ids.resize(nr);
+        nwarm = (int)ids.size();
+        const int ng = std::min((int)general.size(), nwarm);
+        if (nwarm) {
+            OG_HIP(hipMemcpyAsync(qp->d_warm, ids.data(), sizeof(int) * nwarm, hipMemcpyHostToDevice, s));
+            OG_HIP(hipStreamSynchronize(s));                   // ids is a local
+            double* Text = qp->Tc + (size_t)meq * n1;
+            OG_STAGE("warm rows");
+            if (ng)
+                hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (ng + 63) / 64), dim3(256), 0, s, A, meq, ng, qp->Jw,
+                                   n1, nq, Text, (const int*)qp->d_warm);
+            if (nwarm > ng)
+                hipLaunchKernelGGL(k_rows_gather_bounds, dim3((nq + 255) / 256, nwarm - ng), dim3(256), 0, s, qp->Jw, n1,
+                                   nq, mg, (const int*)qp->d_warm, ng, nwarm, Text);
+        }
+    }
+    const int msweep = meq + nwarm;                            // rows the sweep makes triangular
+    if (msweep) {
         OG_STAGE("gemm C Z");
-        hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, n1,
-                           nq, qp->Tc);
+        if (meq)
+            hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, n1,
+                               nq, qp->Tc, (const int*)nullptr);
         OG_STAGE("lq sweep");
         OG_HIP(hipMemsetAsync(qp->dthresh, 0, 2 * sizeof(double), s));
-        for (int k = 0; k < meq; k += LQ_NB) {
-            const int nb = std::min(LQ_NB, meq - k);
-            const int nrows = (meq - k - nb) + nq;
+        for (int k = 0; k < msweep; k += LQ_NB) {
+            const int nb = std::min(LQ_NB, msweep - k);
+            const int nrows = (msweep - k - nb) + nq;
             const int len = nq - k;                                // length of the panel rows
 #define OG_PANEL(PT, CPT)                                                                                      \
-    hipLaunchKernelGGL((k_lq_panel<PT, CPT>), dim3(1), dim3(PT), 0, s, qp->Tc, n1, meq, nq, k, qp->Vp, qp->diagL, \
+    hipLaunchKernelGGL((k_lq_panel<PT, CPT>), dim3(1), dim3(PT), 0, s, qp->Tc, n1, msweep, nq, k, qp->Vp, qp->diagL, \
                        qp->panel, qp->dthresh + 1)
             if (len <= PANEL_SMALL_PT * 4) OG_PANEL(PANEL_SMALL_PT, 4);
             else if (len <= PANEL_SMALL_PT * 8) OG_PANEL(PANEL_SMALL_PT, 8);
@@ -2199,7 +2262,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
                 const dim3 grid((nrows + LQ_RW - 1) / LQ_RW);
                 const int jt = (len + 255) / 256;
 #define OG_APPLY(KERNEL) \
-    hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, qp->Tc, qp->Jw, n1, meq, nq, k, qp->Vp, qp->panel)
+    hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, qp->Tc, qp->Jw, n1, msweep, nq, k, qp->Vp, qp->panel)
                 if (jt <= 2) OG_APPLY(k_lq_apply_reg<2>);
                 else if (jt <= 4) OG_APPLY(k_lq_apply_reg<4>);
                 else if (jt <= 6) OG_APPLY(k_lq_apply_reg<6>);
@@ -2217,7 +2280,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         }
 #endif
         OG_STAGE("check diag");
-        hipLaunchKernelGGL(k_check_diag, dim3(1), dim3(1024), 0, s, qp->diagL, meq, qp->flag, qp->dthresh);
+        if (meq) hipLaunchKernelGGL(k_check_diag, dim3(1), dim3(1024), 0, s, qp->diagL, meq, qp->flag, qp->dthresh);
     }
     OG_HIP(hipGetLastError());
     // ---- equality-constrained minimiser: L w1 = -c,  deq = J1 w1 - Y (Y'g)
@@ -2244,7 +2307,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     OG_STAGE("gemm G J");
     if (mg) {
         hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (mg + 63) / 64), dim3(256), 0, s, A, meq, mg, qp->Jw, n1,
-                           nq, qp->GJ);
+                           nq, qp->GJ, (const int*)nullptr);
         hipLaunchKernelGGL(k_gemv_cols_A, dim3((mg + 63) / 64), dim3(1024), 0, s, A, meq, nq, mg, qp->deq,
                            qp->c + meq, qp->bG);
     }
@@ -2258,11 +2321,69 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     ga.RI[0] = qp->RI[0]; ga.RI[1] = qp->RI[1]; ga.Q1t = qp->Q1t; ga.partials = qp->partials; ga.st = qp->st;
     const int mt = mg + 2 * nq;
     ga.limit = 10 * (mt + nr) + 100;
+    GiState hst;
+    memset(&hst, 0, sizeof(hst));
+    const bool rows_mode = qp->gi_mode == 0;
+    if (rows_mode && nr > 0) {
+        // ---- rotated coordinates, one pass over the rows per change (ogsqp_rows.h)
+        RowsArgs ra;
+        ra.g = ga;
+        ra.g.RI[0] = qp->RI[0];
+        ra.g.RI[1] = qp->RI[1];
+        ra.dots = qp->dots;
+        ra.dvec = qp->dvec;
+        ra.rvec = qp->rvec;
+        ra.vvec = qp->csbuf;
+        ra.slot = qp->d_slot;
+        ra.price = qp->price;
+        ra.ratio = qp->ratio;
+        ra.rec = qp->rec;
+        const int nrows = mg + nq;
+        ra.G1 = std::max(8, std::min(128, (qp->qcap + 15) / 16));
+        ra.G2 = std::max(1, std::min(2048, (nrows + 1 + ROWS_WAVES - 1) / ROWS_WAVES));   // a wavefront per row
+        const size_t lds1 = rows_lds_bytes(nr, qp->qcap);
+        OG_STAGE("rows init");
+        hipLaunchKernelGGL(k_rows_init, dim3((mt + n1 + 255) / 256 + 1), dim3(ROWS_THREADS), 0, s, ra, qp->diagL,
+                           (const int*)qp->d_warm, nwarm, qp->dthresh, qp->flag);
+        if (nwarm) {
+            hipLaunchKernelGGL(k_rows_mark, dim3((nwarm + 255) / 256), dim3(256), 0, s, ra, (const int*)qp->d_warm, nwarm);
+            hipLaunchKernelGGL(k_rows_invert, dim3(nwarm), dim3(ROWS_THREADS), (size_t)(nwarm + 1) * sizeof(double), s,
+                               ra, (const double*)qp->Tc, (const double*)qp->diagL);
+        }
+        const int tail_lanes = (nr + 63) / 64;
+#define OG_ROWS_APPLY()                                                                                      \
+    do {                                                                                                     \
+        if (tail_lanes <= 8) hipLaunchKernelGGL(k_rows_apply<8>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra);   \
+        else if (tail_lanes <= 16) hipLaunchKernelGGL(k_rows_apply<16>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
+        else if (tail_lanes <= 32) hipLaunchKernelGGL(k_rows_apply<32>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
+        else hipLaunchKernelGGL(k_rows_apply<80>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra);                  \
+    } while (0)
+        OG_ROWS_APPLY();                                       // values and pricing at y = 0
+        OG_HIP(hipGetLastError());
+        int batch = debug_stages() ? 1 : 8;
+        long launched = 0;
+        OG_STAGE("rows changes");
+        while (true) {
+            for (int it = 0; it < batch; ++it) {
+                hipLaunchKernelGGL(k_rows_decide, dim3(ra.G1), dim3(ROWS_THREADS), lds1, s, ra);
+                OG_ROWS_APPLY();
+            }
+            launched += batch;
+            OG_HIP(hipGetLastError());
+            OG_HIP(hipMemcpyAsync(&hst, qp->st, sizeof(GiState), hipMemcpyDeviceToHost, s));
+            OG_HIP(hipStreamSynchronize(s));
+            if (hst.phase >= 2) break;
+            // every pair of launches is one change (or the end of the warm start): the device's own limit ends the loop
+            if (launched > (long)ga.limit + nwarm + 64)
+                return fail(8, "og_qp_solve_dev: the active-set kernels made no progress (internal error)");
+            if (batch < 128) batch *= 2;
+        }
+#undef OG_ROWS_APPLY
+    } else if (!rows_mode) {
     OG_STAGE("gi init");
     hipLaunchKernelGGL(k_gi_init, dim3((mt + n1 + 255) / 256), dim3(256), 0, s, ga, qp->flag);
     OG_HIP(hipGetLastError());
-    GiState hst;
-    memset(&hst, 0, sizeof(hst));
+    }
     if (debug_stages()) {
         OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         OG_HIP(hipStreamSynchronize(s));
@@ -2290,7 +2411,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     const bool use_coop = qp->coop_mode == 2 ||
                           (qp->coop_mode == 1 && (nr >= 512 || (nr >= 256 && qp->last_iters > 96)));
     bool coop_done = false;
-    if (nr > 0 && use_coop && coop_slices <= 64 && coop_lds <= LDS_LIMIT) {
+    if (!rows_mode && nr > 0 && use_coop && coop_slices <= 64 && coop_lds <= LDS_LIMIT) {
         // the whole active-set loop in one cooperative launch
         CoopArgs ca;
         ca.g = ga;
@@ -2340,6 +2461,8 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         }
 #endif
         if (habort) return fail(7, "og_qp_solve_dev: the cooperative active-set kernel lost a workgroup at a barrier");
+    } else if (rows_mode && nr > 0) {
+        // done above
     } else if (nr > 0) {
         const int blocks = (mg + nq + GI_WAVES - 1) / GI_WAVES;
         const size_t lds = gi_lds_bytes(nr, qp->qcap);
@@ -2355,6 +2478,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
             if (batch < 64) batch *= 2;
         }
     } else {
+        hipLaunchKernelGGL(k_gi_init, dim3((mt + n1 + 255) / 256), dim3(256), 0, s, ga, qp->flag);
         OG_HIP(hipMemcpyAsync(&hst, qp->st, sizeof(GiState), hipMemcpyDeviceToHost, s));
         OG_HIP(hipStreamSynchronize(s));
         if (hst.phase < 2) hst.phase = 2;   // nothing to move: feasibility was settled by k_ldp_setup
@@ -2398,8 +2522,55 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     if (meq) OG_HIP(hipMemcpyAsync(mult, qp->lam, sizeof(double) * meq, hipMemcpyDeviceToHost, s));
     if (mg) OG_HIP(hipMemcpyAsync(mult + meq, qp->u, sizeof(double) * mg, hipMemcpyDeviceToHost, s));
     OG_HIP(hipStreamSynchronize(s));
+    if (rows_mode && nr > 0) {
+        // the rows active at this solution, in the numbering of og_qp_get_active: where the next subproblem starts
+        std::vector<int> act((size_t)std::max(hst.q, 1));
+        if (hst.q > 0) OG_HIP(hipMemcpy(act.data(), qp->act, sizeof(int) * hst.q, hipMemcpyDeviceToHost));
+        std::vector<int> before(qp->warm);
+        qp->warm.clear();
+        for (int j = 0; j < hst.q; ++j) {
+            const int c = act[j];
+            if (c < mg)
+                qp->warm.push_back(c);
+            else if (c < mg + nq)
+                qp->warm.push_back(mg + 2 * (c - mg));
+            else
+                qp->warm.push_back(mg + 2 * (c - mg - nq) + 1);
+        }
+        // warm-start the next solve only if this solution kept most of the previous one's rows
+        std::vector<int> now(qp->warm);
+        std::sort(now.begin(), now.end());
+        std::sort(before.begin(), before.end());
+        std::vector<int> common;
+        std::set_intersection(now.begin(), now.end(), before.begin(), before.end(), std::back_inserter(common));
+        const size_t larger = std::max(now.size(), before.size());
+        qp->warm_use = before.empty() || 10 * common.size() >= 7 * larger;
+    }
     if (!augmented) std::swap(qp->Z, qp->Jw);   // Z Q: same B, what og_qp_bfgs updates next
     *status = OG_QP_SOLVED;
+    return 0;
+}
+
+int og_qp_get_active(og_qp_handle qp, int32_t* ids, int32_t capacity, int32_t* count) {
+    if (!qp || !count) return fail(2, "og_qp_get_active: null argument");
+    *count = (int32_t)qp->warm.size();
+    if (ids)
+        for (int j = 0; j < (int)qp->warm.size() && j < capacity; ++j) ids[j] = qp->warm[j];
+    return 0;
+}
+
+int og_qp_set_active(og_qp_handle qp, const int32_t* ids, int32_t count) {
+    if (!qp || count < 0 || (count > 0 && !ids)) return fail(2, "og_qp_set_active: bad arguments");
+    std::vector<int> next;
+    std::vector<char> seen((size_t)qp->mg + 2 * (size_t)qp->n1, 0);
+    for (int j = 0; j < count; ++j) {
+        if (ids[j] < 0 || ids[j] >= qp->mg + 2 * qp->n1) return fail(2, "og_qp_set_active: no such constraint");
+        if (seen[ids[j]]) return fail(2, "og_qp_set_active: a constraint is listed twice");
+        seen[ids[j]] = 1;
+        next.push_back(ids[j]);
+    }
+    qp->warm.swap(next);
+    qp->warm_use = true;
     return 0;
 }
 

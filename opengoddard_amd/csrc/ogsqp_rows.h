@@ -1,0 +1,633 @@
+// ogsqp_rows.h - the dual active-set method of the least-distance problem in ROTATED coordinates, one
+// workgroup-parallel pass over the constraint rows per change (included by ogsqp.hip inside its anonymous
+// namespace).
+//
+// The two older kernels (k_gi_iter, k_gi_coop) keep an orthonormal basis Q1 of the active normals next to the
+// untouched constraint matrix W = [G; I] Y and pay for it with a chain of dependent global reductions per change
+// (projections Q1'n, the component z, the pricing W y: ~12 memory round trips and 3-4 grid barriers, 40-66 us per
+// change at C3) and with a serial Givens chain per removal.  Here neither exists.  Goldfarb & Idnani's method is
+// run the way the restatement (oracle/slsqp_np.py: ldp_gi) states it - an orthogonal Q such that the active
+// normals live in the first q coordinates of W Q - but Q is applied to the rows of W as it grows (W <- W Q, in
+// place in GJ / Jw: J Q is as good a factor of B^-1 as J), so that
+//
+//   * the normal of the incoming row p in the current coordinates is row p itself: d = W[p], d1 = d[:q],
+//     d2 = d[q:]; the step direction is [0; d2], |z|^2 = |d2|^2; no projection, no Gram-Schmidt;
+//   * every row keeps its own constraint value W[i] y up to date from  g_i = W[i][q:] . d2  (dots[i] += t g_i),
+//     which is the same dot product the Householder reflector of a full step needs
+//     (W[i][q:] -= beta (g_i - alpha W[i][q]) v, v = d2 - alpha e1): ONE pass over the rows per change, row-local,
+//     no communication between rows;
+//   * a leaving row k is one reflector too, not a chain of q - k Givens rotations: with M the (square, here not
+//     necessarily triangular) matrix of the active normals in the first q coordinates and its explicit inverse
+//     M^-1 = RI, row k of RI is the direction of those coordinates that is orthogonal to every OTHER active
+//     normal; the reflector that sends it to the last of them, e_{q-1}, applied to every row (and to the rows of
+//     RI, which then lose row k and their last column), leaves the remaining normals in the first q - 1
+//     coordinates.  No factor R is kept at all: r = RI d1 is all the method asks of it.
+//
+// What is serial per change is small: the dual direction r = RI d1 (rows of the inverse spread over the workgroups
+// of the first kernel), the ratio test and the book-keeping (the workgroup that arrives last at the first kernel's
+// ticket).  A change is two launches - k_rows_decide, k_rows_apply - and the boundary between them is the only
+// synchronisation (1.5-1.9 us on this part, cheaper than a grid barrier); the host enqueues batches of pairs and
+// looks at the state once per batch, kernels of a finished solve return at once.
+//
+// Warm start.  The rows that were active at the solution of the previous subproblem are appended to the LQ sweep
+// of the equalities (og_qp_solve_dev), which leaves them triangular in the new coordinates: RI is the inverse of
+// that triangle (k_rows_invert), the minimiser on them and its multipliers are two products with it; while a
+// multiplier is negative the row with the most negative one is taken out (phase -1).  What is left is an S-pair,
+// from which the dual method continues; late in an SQP run a subproblem then costs a handful of changes.
+
+struct RowsDecision {
+    int kind;        // 0 price only, 1 full step (p joins), 2 partial step (position k leaves), 3 warm start: position
+                     // k leaves (reflector only), 4 warm start done: every row's value from y
+    int q;           // active rows before this change = first tail coordinate
+    int k;
+    int dependent;
+    double t, alpha, beta, beta_out;   // step; reflector of the incoming row; of the leaving one (vector in vvec)
+};
+
+struct RowsArgs {
+    GiArgs g;                // g.y = y in the rotated coordinates; g.RI[0] = the inverse, one row per SLOT
+    double* dots;            // mg + nq: W[i] . y of every row
+    double* dvec;            // nr: the incoming normal (signed)
+    double* rvec;            // qcap: dual direction r = RI d1
+    double* vvec;            // qcap: reflector vector of a removal
+    int* slot;               // qcap: storage row of RI per active position; positions >= q list the free rows
+    GiPartial* price;        // G2: most violated row of every workgroup of k_rows_apply
+    GiPartial* ratio;        // G1: ratio-test candidate of every workgroup of k_rows_decide
+    RowsDecision* rec;
+    int G1, G2;
+};
+
+constexpr int ROWS_THREADS = 256;
+constexpr int ROWS_WAVES = ROWS_THREADS / 64;
+
+// Stack row r < mg + nq (general rows, then one row per variable shared by its lower and upper bound).
+__device__ __forceinline__ double* rows_ptr(const GiArgs& g, int r) {
+    return (double*)(r < g.mg ? g.GJ + (long)r * g.ld : g.Jw + (long)(r - g.mg) * g.ld) + g.meq;
+}
+
+// Position k leaves (one workgroup): its storage row becomes the first free one, the lists close up, and the
+// reflector that moves the freed direction to coordinate q-1 goes to vvec.  w = row k of RI (LDS, q entries) is
+// turned into the reflector vector in place.  Returns beta of the reflector.
+__device__ __forceinline__ double rows_leave(const RowsArgs& a, int q, int k, double* w, int* shifted, double* red) {
+    const GiArgs& g = a.g;
+    const int tid = threadIdx.x;
+    const double* rowk = g.RI[0] + (long)a.slot[k] * g.qcap;
+    double part = 0.0;
+    for (int j = tid; j < q; j += ROWS_THREADS) {
+        const double v = rowk[j];
+        w[j] = v;
+        part += v * v;
+    }
+    const double ww = block_sum(part, red);
+    const double wl = w[q - 1];
+    const double alpha = wl >= 0.0 ? -sqrt(ww) : sqrt(ww);
+    const double v0 = wl - alpha;
+    const double vv = ww - wl * wl + v0 * v0;
+    __syncthreads();
+    if (tid == 0) w[q - 1] = v0;
+    __syncthreads();
+    for (int j = tid; j < q; j += ROWS_THREADS) a.vvec[j] = w[j];
+    // lists: positions k+1 .. q-1 move down, the freed storage row goes to position q-1
+    const int leaving = g.act[k], freed = a.slot[k];
+    for (int j = k + tid; j < q - 1; j += ROWS_THREADS) {
+        shifted[2 * j] = g.act[j + 1];
+        shifted[2 * j + 1] = a.slot[j + 1];
+    }
+    __syncthreads();
+    for (int j = k + tid; j < q - 1; j += ROWS_THREADS) {
+        g.act[j] = shifted[2 * j];
+        a.slot[j] = shifted[2 * j + 1];
+    }
+    if (tid == 0) {
+        a.slot[q - 1] = freed;
+        g.u[leaving] = 0.0;
+        g.isact[leaving] = 0;
+    }
+    __syncthreads();
+    return vv > 0.0 ? 2.0 / vv : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// First kernel of a change: who comes in, the dual direction, the step length, the book-keeping.
+__global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
+    extern __shared__ double lds[];
+    __shared__ double redv[ROWS_WAVES];
+    __shared__ int redi[ROWS_WAVES];
+    __shared__ double red[ROWS_WAVES];
+    __shared__ int s_last;
+    const GiArgs& g = a.g;
+    GiState* st = g.st;
+    const int phase = st->phase;
+    if (phase >= 2) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
+    const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
+    const int q = st->q;
+    double* d = lds;                  // nr: incoming normal
+    double* rv = d + nr;              // qcap: dual direction / multipliers of the warm start
+    double* aux = rv + qcap;          // qcap: leaving row of RI -> reflector vector / minimiser of the warm start
+    int* shifted = (int*)d;           // (the normal is spent when the lists are shifted)
+    const double* RI = g.RI[0];
+
+    if (phase < 0) {
+        // ---- warm start: minimiser on the warm rows, multipliers, the most negative one leaves --------------
+        if (w != 0) return;
+        if (q == 0) {
+            if (tid == 0) {
+                a.rec->kind = 0;
+                st->phase = 0;
+            }
+            return;
+        }
+        double* y1 = aux;
+        double* bA = d;
+        for (int i = tid; i < q; i += ROWS_THREADS) bA[i] = g.bval[g.act[i]];
+        __syncthreads();
+        for (int j = tid; j < q; j += ROWS_THREADS) {          // M' y1 = -b_A  ->  y1 = -RI' b_A
+            double acc0 = 0.0, acc1 = 0.0;
+            int i = 0;
+            for (; i + 1 < q; i += 2) {
+                acc0 += RI[(long)a.slot[i] * qcap + j] * bA[i];
+                acc1 += RI[(long)a.slot[i + 1] * qcap + j] * bA[i + 1];
+            }
+            if (i < q) acc0 += RI[(long)a.slot[i] * qcap + j] * bA[i];
+            y1[j] = -(acc0 + acc1);
+        }
+        __syncthreads();
+        double worst = INFINITY;
+        int kworst = 0x7fffffff;
+        for (int i = wave; i < q; i += ROWS_WAVES) {           // y = N u  ->  u = RI y1
+            const double* row = RI + (long)a.slot[i] * qcap;
+            double acc = 0.0;
+            for (int j = lane; j < q; j += 64) acc += row[j] * y1[j];
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                rv[i] = acc;
+                if (acc < worst) {
+                    worst = acc;
+                    kworst = i;
+                }
+            }
+        }
+        if (lane != 0) {
+            worst = INFINITY;
+            kworst = 0x7fffffff;
+        }
+        block_argmin(worst, kworst, redv, redi);
+        if (!(worst < 0.0)) {
+            double part = 0.0;
+            for (int i = tid; i < nr; i += ROWS_THREADS) {
+                const double v = i < q ? y1[i] : 0.0;
+                g.y[i] = v;
+                part += v * v;
+            }
+            for (int i = tid; i < q; i += ROWS_THREADS) g.u[g.act[i]] = rv[i];
+            const double ynorm = sqrt(block_sum(part, red));
+            if (tid == 0) {
+                RowsDecision rec;
+                rec.kind = 4;
+                rec.q = q;
+                rec.k = 0;
+                rec.dependent = 0;
+                rec.t = rec.alpha = rec.beta = rec.beta_out = 0.0;
+                *a.rec = rec;
+                st->phase = 0;
+                st->ynorm = ynorm;
+            }
+            return;
+        }
+        const int k = kworst;
+        __syncthreads();
+        const double beta_out = rows_leave(a, q, k, aux, shifted, red);
+        if (tid == 0) {
+            RowsDecision rec;
+            rec.kind = 3;
+            rec.q = q;
+            rec.k = k;
+            rec.dependent = 0;
+            rec.t = rec.alpha = rec.beta = 0.0;
+            rec.beta_out = beta_out;
+            *a.rec = rec;
+            st->q = q - 1;
+            st->iters = st->iters + 1;
+        }
+        return;
+    }
+
+    // ---- the incoming row ------------------------------------------------------------------------------------
+    int p;
+    if (phase == 0) {
+        double v = INFINITY;
+        int idx = 0x7fffffff;
+        for (int b = tid; b < a.G2; b += ROWS_THREADS) {
+            const double pv = a.price[b].value;
+            const int pi = a.price[b].index;
+            if (pv < v || (pv == v && pi < idx)) {
+                v = pv;
+                idx = pi;
+            }
+        }
+        block_argmin(v, idx, redv, redi);
+        if (!(v < 0.0)) {                         // every workgroup sees the same: solved
+            if (w == 0 && tid == 0) st->phase = 2;
+            return;
+        }
+        p = idx;
+    } else {
+        p = st->p;
+    }
+    double psign;
+    const double* prow = stack_row(g, p, psign);
+    for (int i = tid; i < nr; i += ROWS_THREADS) d[i] = psign * prow[i];
+    __syncthreads();
+    // ---- my rows of the inverse: dual direction and ratio test ------------------------------------------------
+    {
+        double t1 = INFINITY;
+        int kdrop = 0x7fffffff;
+        // four rows per trip: their loads are in flight together (a row is one memory round trip otherwise)
+        const int stride = a.G1 * ROWS_WAVES;
+        for (int i0 = w * ROWS_WAVES + wave; i0 < q; i0 += 4 * stride) {
+            const double* row[4];
+            double uact[4], acc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e * stride;
+                row[e] = RI + (long)a.slot[i < q ? i : i0] * qcap;
+                uact[e] = g.u[g.act[i < q ? i : i0]];
+                acc[e] = 0.0;
+            }
+            for (int j = lane; j < q; j += 64) {
+                const double dj = d[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += row[e][j] * dj;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e * stride;
+                const double ri = wave_sum(acc[e]);
+                if (lane == 0 && i < q) {
+                    st_shared(a.rvec + i, ri);
+                    if (ri > 0.0) {
+                        const double cand = uact[e] / ri;
+                        if (cand < t1 || (cand == t1 && i < kdrop)) {
+                            t1 = cand;
+                            kdrop = i;
+                        }
+                    }
+                }
+            }
+        }
+        if (lane != 0) {
+            t1 = INFINITY;
+            kdrop = 0x7fffffff;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my entries of r have left before the ticket is drawn
+        block_argmin(t1, kdrop, redv, redi);
+        if (tid == 0) {
+            st_shared(&a.ratio[w].value, t1);
+            st_shared(&a.ratio[w].index, kdrop);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (tk == (unsigned)a.G1 - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
+    }
+    // ---- last workgroup: the decision ------------------------------------------------------------------------
+    if (tid == 0) st->ticket = 0u;
+    double t1 = INFINITY;
+    int kdrop = 0x7fffffff;
+    for (int b = tid; b < a.G1; b += ROWS_THREADS) {
+        const double cv = ld_shared(&a.ratio[b].value);
+        const int ci = ld_shared(&a.ratio[b].index);
+        if (cv < t1 || (cv == t1 && ci < kdrop)) {
+            t1 = cv;
+            kdrop = ci;
+        }
+    }
+    block_argmin(t1, kdrop, redv, redi);
+    const int iters = st->iters + 1;
+    if (iters > g.limit || q > nr || q > qcap || p < 0 || p >= mg + 2 * nq) {
+        if (tid == 0) {
+            st->phase = 3;
+            st->iters = iters;
+        }
+        return;
+    }
+    double part_zz = 0.0, part_nn = 0.0;
+    for (int i = tid; i < nr; i += ROWS_THREADS) {
+        const double v = d[i];
+        part_nn += v * v;
+        if (i >= q) part_zz += v * v;
+    }
+    const double zz = block_sum(part_zz, red);
+    const double nn = block_sum(part_nn, red);
+    const bool dependent = (q >= nr) || !(zz > (DEPENDENT * DEPENDENT) * nn);
+    const int prow_index = p < mg + nq ? p : p - nq;
+    const double sp = g.bval[p] + psign * a.dots[prow_index];
+    const double t2 = dependent ? INFINITY : -sp / zz;
+    const double t = fmin(t1, t2);
+    if (!(t < INFINITY)) {
+        if (tid == 0) {
+            st->phase = 4;
+            st->iters = iters;
+        }
+        return;
+    }
+    for (int j = tid; j < q; j += ROWS_THREADS) {
+        const double rj = ld_shared(a.rvec + j);
+        rv[j] = rj;
+        g.u[g.act[j]] -= t * rj;
+    }
+    const double up = (phase == 0 ? 0.0 : st->up) + t;
+    double part_yy = 0.0;
+    for (int i = tid; i < nr; i += ROWS_THREADS) {
+        double yi = g.y[i];
+        if (!dependent && i >= q) {
+            yi += t * d[i];
+            g.y[i] = yi;
+        }
+        part_yy += yi * yi;
+    }
+    const double ynorm = sqrt(block_sum(part_yy, red));
+    for (int i = tid; i < nr; i += ROWS_THREADS) a.dvec[i] = d[i];
+    const bool full_step = (t2 < INFINITY) && (t2 <= t1);
+    RowsDecision rec;
+    rec.q = q;
+    rec.k = 0;
+    rec.dependent = dependent ? 1 : 0;
+    rec.t = t;
+    rec.alpha = rec.beta = rec.beta_out = 0.0;
+    if (full_step) {
+        // p joins: reflector H with H d2 = alpha e1 on the tail coordinates; the matrix of the active normals gets
+        // the column [d1; alpha], its inverse the column -r / alpha and the row [0 .. 0, 1 / alpha]
+        const double dq = d[q];
+        const double alpha = dq >= 0.0 ? -sqrt(zz) : sqrt(zz);
+        const double v0 = dq - alpha;
+        const double vv = zz - dq * dq + v0 * v0;
+        rec.kind = 1;
+        rec.alpha = alpha;
+        rec.beta = vv > 0.0 ? 2.0 / vv : 0.0;
+        double* RIw = g.RI[0];
+        const double inv = 1.0 / alpha;
+        double* fresh = RIw + (long)a.slot[q] * qcap;
+        for (int i = tid; i < q; i += ROWS_THREADS) {
+            RIw[(long)a.slot[i] * qcap + q] = -rv[i] * inv;
+            fresh[i] = 0.0;
+        }
+        if (tid == 0) {
+            fresh[q] = inv;
+            g.act[q] = p;
+            g.u[p] = up;
+            g.isact[p] = 1;
+            st->q = q + 1;
+            st->phase = 0;
+        }
+    } else {
+        // partial step: position k leaves; the reflector goes to k_rows_apply, which applies it to every row of the
+        // constraint matrix and of the inverse
+        const int k = kdrop;
+        if (k < 0 || k >= q) {
+            if (tid == 0) {
+                st->phase = 3;
+                st->dbg = -7;
+                st->dbg2 = k;
+            }
+            return;
+        }
+        rec.kind = 2;
+        rec.k = k;
+        __syncthreads();
+        rec.beta_out = rows_leave(a, q, k, aux, shifted, red);
+        if (tid == 0) {
+            st->q = q - 1;
+            st->phase = 1;
+            st->p = p;
+            st->up = up;
+        }
+    }
+    if (tid == 0) {
+        *a.rec = rec;
+        st->iters = iters;
+        st->ynorm = ynorm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Second kernel of a change: the pass over the rows, one wavefront per row with the whole row in registers
+// (TAIL coordinates per lane: rows of up to 64 * TAIL null-space entries).  The walk covers the constraint rows,
+// then y (which lives in the same coordinates), then - when a row leaves - the rows of the inverse.
+template <int TAIL>
+__global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
+    __shared__ double redv[ROWS_WAVES];
+    __shared__ int redi[ROWS_WAVES];
+    const GiArgs& g = a.g;
+    GiState* st = g.st;
+    if (st->phase >= 2) return;
+    const RowsDecision rec = *a.rec;
+    const int kind = rec.kind;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
+    const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
+    const int q0 = rec.q;
+    const int nrows = mg + nq;
+    const bool moves = (kind == 1 || kind == 2) && !rec.dependent;
+    const bool leaves = kind == 2 || kind == 3;
+    const double slack = FEASIBLE * st->ynorm;
+    // per lane: the incoming normal's tail (d2, zero on the first q0 coordinates) and the leaving reflector's vector
+    double dreg[TAIL], vreg[TAIL];
+#pragma unroll
+    for (int e = 0; e < TAIL; ++e) {
+        const int j = lane + 64 * e;
+        dreg[e] = (moves && j >= q0 && j < nr) ? a.dvec[j] : 0.0;
+        vreg[e] = (leaves && j < q0) ? a.vvec[j] : 0.0;
+    }
+    double best = INFINITY;
+    int besti = 0x7fffffff;
+    const int extra = leaves ? q0 - 1 : 0;                 // rows of the inverse that stay (positions after the shift)
+    for (int r = w * ROWS_WAVES + wave; r <= nrows + extra; r += a.G2 * ROWS_WAVES) {
+        const bool is_y = r == nrows, is_inv = r > nrows;
+        double* row = is_inv ? g.RI[0] + (long)a.slot[r - nrows - 1] * qcap : is_y ? g.y : rows_ptr(g, r);
+        const int len = is_inv ? q0 : nr;
+        double dot = (is_y || is_inv) ? 0.0 : a.dots[r];
+        const double xq = (kind == 1 && !is_inv) ? row[q0] : 0.0;
+        if (kind != 0) {
+            double x[TAIL];
+            double acc_d = 0.0, acc_v = 0.0;
+#pragma unroll
+            for (int e = 0; e < TAIL; ++e) {
+                const int j = lane + 64 * e;
+                x[e] = j < len ? row[j] : 0.0;
+                acc_d += x[e] * dreg[e];
+                acc_v += x[e] * vreg[e];
+            }
+            if (kind == 4) {
+                if (!is_y) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int e = 0; e < TAIL; ++e) {
+                        const int j = lane + 64 * e;
+                        acc += (j < q0) ? x[e] * g.y[j] : 0.0;
+                    }
+                    dot = wave_sum(acc);
+                    if (lane == 0) a.dots[r] = dot;
+                }
+            } else {
+                if (moves && !is_inv && (kind == 1 || !is_y)) {
+                    const double gi = wave_sum(acc_d);
+                    if (!is_y) {
+                        dot += rec.t * gi;
+                        if (lane == 0) a.dots[r] = dot;
+                    }
+                    if (kind == 1) {
+                        // reflector of the incoming row on the tail: v = d2 - alpha e_q0
+                        const double f = rec.beta * (gi - rec.alpha * xq);
+#pragma unroll
+                        for (int e = 0; e < TAIL; ++e) {
+                            const int j = lane + 64 * e;
+                            if (j >= q0 && j < nr) row[j] = x[e] - f * (dreg[e] - (j == q0 ? rec.alpha : 0.0));
+                        }
+                    }
+                }
+                if (leaves) {
+                    // reflector of the leaving row on the first q0 coordinates
+                    const double f = rec.beta_out * wave_sum(acc_v);
+#pragma unroll
+                    for (int e = 0; e < TAIL; ++e) {
+                        const int j = lane + 64 * e;
+                        if (j < q0) row[j] = x[e] - f * vreg[e];
+                    }
+                }
+            }
+        }
+        if (is_y || is_inv || leaves) continue;            // the same row p goes on after a removal: no pricing
+        if (r < mg) {
+            if (g.scale[r] > 0.0 && !g.isact[r]) {
+                const double v = (g.bval[r] + dot) / g.scale[r] + g.own[r] + slack;
+                if (v < best || (v == best && r < besti)) {
+                    best = v;
+                    besti = r;
+                }
+            }
+        } else {
+            const int lo = r, hi = r + nq;
+            if (g.scale[lo] > 0.0 && !g.isact[lo]) {
+                const double v = (g.bval[lo] + dot) / g.scale[lo] + g.own[lo] + slack;
+                if (v < best || (v == best && lo < besti)) {
+                    best = v;
+                    besti = lo;
+                }
+            }
+            if (g.scale[hi] > 0.0 && !g.isact[hi]) {
+                const double v = (g.bval[hi] - dot) / g.scale[hi] + g.own[hi] + slack;
+                if (v < best || (v == best && hi < besti)) {
+                    best = v;
+                    besti = hi;
+                }
+            }
+        }
+    }
+    if (!leaves) {
+        block_argmin(best, besti, redv, redi);
+        if (tid == 0) {
+            a.price[w].value = best;
+            a.price[w].index = besti;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Start of the active-set loop.  nwarm = 0: empty active set.  Otherwise the rows warm[0 .. nwarm) were appended
+// to the LQ sweep: row j of the extension holds L(j, 0..j) at Tc[(meq + j) * ld + meq + i], its diagonal at
+// diagL[meq + j]; the matrix of the active normals is L'.  A vanishing pivot (a warm row that depends on the
+// equalities or on the warm rows before it) falls back to the empty set - the coordinates are as good as any.
+__global__ __launch_bounds__(ROWS_THREADS) void k_rows_init(RowsArgs a, const double* __restrict__ diagL,
+                                                           const int* __restrict__ warm, int nwarm,
+                                                           const double* __restrict__ dthresh, const int* flag) {
+    __shared__ int s_dead;
+    const GiArgs& g = a.g;
+    const int tid = threadIdx.x;
+    const long i = (long)blockIdx.x * blockDim.x + tid;
+    const int mt = g.mg + 2 * g.nq;
+    if (i < mt) {
+        g.u[i] = 0.0;
+        g.isact[i] = 0;
+    }
+    if (i < g.nr) g.y[i] = 0.0;
+    if (i < g.mg + g.nq) a.dots[i] = 0.0;
+    if (i < g.qcap) a.slot[i] = (int)i;
+    if (blockIdx.x != gridDim.x - 1) return;                   // the last workgroup owns the state
+    if (tid == 0) s_dead = 0;
+    __syncthreads();
+    const double tiny = dthresh[0];
+    for (int j = tid; j < nwarm; j += ROWS_THREADS) {
+        const int c = warm[j];
+        if (!(fabs(diagL[g.meq + j]) > tiny) || !(g.scale[c] > 0.0)) s_dead = 1;
+    }
+    __syncthreads();
+    const int q = (s_dead || flag[1]) ? 0 : nwarm;
+    for (int j = tid; j < q; j += ROWS_THREADS) g.act[j] = warm[j];
+    if (tid == 0) {
+        GiState s;
+        s.phase = flag[1] ? 4 : (q > 0 ? -1 : 0);
+        s.p = -1;
+        s.q = q;
+        s.iters = 0;
+        s.cur = 0;
+        s.ticket = 0u;
+        s.up = 0.0;
+        s.ynorm = 0.0;
+        s.dbg = 0;
+        s.dbg2 = 0;
+        for (int e = 0; e < 12; ++e) s.tr[e] = 0;
+        *g.st = s;
+        RowsDecision rec;
+        rec.kind = 0;
+        rec.q = 0;
+        rec.k = 0;
+        rec.dependent = 0;
+        rec.t = rec.alpha = rec.beta = rec.beta_out = 0.0;
+        *a.rec = rec;
+    }
+}
+
+// isact of the warm rows (after k_rows_init decided whether they are used)
+__global__ void k_rows_mark(RowsArgs a, const int* __restrict__ warm, int nwarm) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nwarm && j < a.g.st->q && a.g.st->phase < 0) a.g.isact[warm[j]] = 1;
+}
+
+// The inverse of the warm start's triangle: the matrix of the active normals is M = L' (upper triangular,
+// M(i, l) = L(l, i): column l of M is row l of the sweep's extension, contiguous).  One workgroup per column c of
+// the inverse: x = e_c, then for l = c .. 0: x_l /= M(l, l), x[0..l) -= x_l M(0..l, l).  Row i of RI (slot i) gets x_i.
+__global__ __launch_bounds__(ROWS_THREADS) void k_rows_invert(RowsArgs a, const double* __restrict__ Tc,
+                                                             const double* __restrict__ diagL) {
+    extern __shared__ double lds[];
+    const GiArgs& g = a.g;
+    const GiState* st = g.st;
+    if (st->phase >= 0) return;
+    const int q = st->q, c = blockIdx.x, qcap = g.qcap, tid = threadIdx.x;
+    if (c >= q) return;
+    double* x = lds;
+    for (int i = tid; i <= c; i += ROWS_THREADS) x[i] = i == c ? 1.0 : 0.0;
+    __syncthreads();
+    for (int l = c; l >= 0; --l) {
+        const double* col = Tc + (long)(g.meq + l) * g.ld + g.meq;
+        const double xl = x[l] / diagL[g.meq + l];
+        __syncthreads();
+        if (tid == 0) x[l] = xl;
+        for (int i = tid; i < l; i += ROWS_THREADS) x[i] -= xl * col[i];
+        __syncthreads();
+    }
+    double* RI = g.RI[0];
+    for (int i = tid; i < q; i += ROWS_THREADS) RI[(long)i * qcap + c] = i <= c ? x[i] : 0.0;
+}
+
+// Rows of the warm start that are bounds: +- rows of the work factor (before the sweep).
+__global__ void k_rows_gather_bounds(const double* __restrict__ Jw, int ld, int nq, int mg, const int* __restrict__ warm,
+                                     int first, int nwarm, double* __restrict__ Text) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, j = first + blockIdx.y;
+    if (k >= nq || j >= nwarm) return;
+    const int c = warm[j] - mg;                                // lower bound of variable c, or upper bound of c - nq
+    const double sign = c < nq ? 1.0 : -1.0;
+    const int i = c < nq ? c : c - nq;
+    Text[(long)j * ld + k] = sign * Jw[(long)i * ld + k];
+}

@@ -29,8 +29,12 @@ __all__ = ["Problem", "Guess", "Condition", "Dynamics"]
 # (tests/conftest.py); nothing in this package ever sets it.
 ENGINE_FACTORY = None
 # 'scipy': SciPy's Fortran SLSQP driven by GPU callbacks (the reference's own core);
-# 'hip': the same major iteration with the QP subproblem on the GPU (sqp.py, include/ogsqp.h)
-DEFAULT_SQP_CORE = "scipy"
+# 'hip': the same major iteration with the QP subproblem on the GPU (sqp.py, include/ogsqp.h);
+# 'auto': 'hip' from AUTO_HIP_FROM decision variables on, 'scipy' below.  SciPy's core is O(n^3) per major
+# iteration (16 s at n = 1442 against a few ms for the HIP core); below a few hundred variables it costs
+# milliseconds and is the reference's own arithmetic, iterate for iterate.
+DEFAULT_SQP_CORE = "auto"
+AUTO_HIP_FROM = 400
 
 
 def _default_engine(prob, obj, devices=None):
@@ -381,7 +385,8 @@ class Problem:
         """Run the SLSQP restart loop (``optimize.py:649-755``) with GPU-evaluated callbacks.
 
         Options honoured are the reference's: ``ftol`` (1e-6) and ``maxiter`` (25); two more select what
-        the reference does not have: ``sqp_core="hip"`` (QP subproblems on the GPU, sqp.py) and
+        the reference does not have: ``sqp_core`` ("auto", the default: the HIP SQP core - QP subproblems on the GPU,
+        sqp.py - from 400 decision variables on, SciPy's Fortran core below; "hip" / "scipy" force one) and
         ``jacobian="exact"`` (forward-mode derivatives of the traced callbacks instead of SciPy's
         forward differences; same optimum, fewer iterations, no FD noise).  Cost,
         equality and inequality values come from a single-column launch of the sweep kernel;
@@ -398,8 +403,12 @@ class Problem:
         assert self.inequality is not None, "It must be set inequality function"
 
         core = options.pop("sqp_core", None) or os.environ.get("OG_SQP_CORE", DEFAULT_SQP_CORE)
-        if core not in ("scipy", "hip"):
-            raise ValueError("sqp_core must be 'scipy' or 'hip', got %r" % (core,))
+        if core not in ("scipy", "hip", "auto"):
+            raise ValueError("sqp_core must be 'scipy', 'hip' or 'auto', got %r" % (core,))
+        if core == "auto":
+            # a stand-in engine of the test-suite (ENGINE_FACTORY) has no device-resident Jacobian for the HIP core
+            core = "hip" if (self.number_of_variables >= AUTO_HIP_FROM and ENGINE_FACTORY is None) else "scipy"
+        self.sqp_core_used = core
 
         jacobian = options.pop("jacobian", None) or os.environ.get("OG_JACOBIAN", "fd")
         if jacobian not in ("fd", "exact"):

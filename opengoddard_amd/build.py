@@ -90,7 +90,7 @@ SQP_LIB = os.path.join(LIBDIR, "libogsqp.so")
 def build_sqp(force=False):
     """``lib/libogsqp.so``: the QP subproblem / BFGS kernels of the SQP driver (``include/ogsqp.h``)."""
     os.makedirs(LIBDIR, exist_ok=True)
-    sources = [os.path.join(CSRC, "ogsqp.hip"), os.path.join(CSRC, "ogsqp_rows.h"),
+    sources = [os.path.join(CSRC, "ogsqp.hip"), os.path.join(CSRC, "ogsqp_rows.h"), os.path.join(CSRC, "ogsqp_lq16.h"),
                os.path.join(HERE, "..", "include", "ogsqp.h")]
     stamp_path = SQP_LIB + ".stamp"
     want = _digest_files(sources)

@@ -570,6 +570,8 @@ __global__ __launch_bounds__(256) void k_lq_apply_reg(double* __restrict__ Tc, d
     }
 }
 
+#include "ogsqp_lq16.h"
+
 // max |diag| / min |diag| test of the triangular factor -> flag[0] = 1 when singular
 __global__ void k_check_diag(const double* diagL, int meq, int* flag, double* dthresh) {
     __shared__ double red[16];
@@ -1961,7 +1963,7 @@ __global__ void k_rank1(double* Z, int ld, int n, const double* s, const double*
 
 struct og_qp_s {
     int device = 0;
-    int n = 0, n1 = 0, meq = 0, mg = 0, m = 0, qcap = 0;
+    int n = 0, n1 = 0, ldw = 0, meq = 0, mg = 0, m = 0, qcap = 0;   // ldw: row pitch of the n1-wide matrices (128-byte rows)
     hipStream_t stream = nullptr;
     double *Z = nullptr, *Jw = nullptr, *Tc = nullptr, *GJ = nullptr, *diagL = nullptr, *Vp = nullptr;
     LqPanel* panel = nullptr;
@@ -1982,6 +1984,9 @@ struct og_qp_s {
     GiPartial *price = nullptr, *ratio = nullptr;
     RowsDecision* rec = nullptr;
     int *d_warm = nullptr, *d_slot = nullptr;
+    double* V16 = nullptr;             // reflector vectors of a 16-wide panel
+    Lq16Panel* panel16 = nullptr;
+    bool lq16 = true;                  // OGSQP_LQ=8: the sweep of 8-reflector panels only
     int coop_mode = 1;                 // 0 never, 1 by size, 2 always (when it fits)
     int last_iters = 1000;             // active-set changes of the previous subproblem on this handle (a solve starts with many)
     double *d = nullptr, *bm = nullptr, *tvec = nullptr, *rhs = nullptr, *lam = nullptr, *vz = nullptr;
@@ -2053,12 +2058,13 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     qp->device = device;
     qp->n = n;
     qp->n1 = n + 1;
+    qp->ldw = (n + 1 + 15) / 16 * 16;
     qp->meq = m_eq;
     qp->mg = m_ineq;
     qp->m = m_eq + m_ineq;
     qp->qcap = qp->n1 - (m_eq < qp->n1 ? m_eq : qp->n1);
     if (qp->qcap < 1) qp->qcap = 1;
-    const size_t n1 = qp->n1, mt = (size_t)qp->mg + 2 * n1, qc = qp->qcap;
+    const size_t n1 = qp->n1, ldw = qp->ldw, mt = (size_t)qp->mg + 2 * n1, qc = qp->qcap;
     if (rows_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) {
         delete qp;
         return fail(4, "og_qp_create: null space of the equalities too large for the LDS-resident part of the "
@@ -2071,9 +2077,10 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     int rc = 0;
     auto A = [&](auto** p, size_t cnt) { if (!rc) rc = dev_alloc(qp, p, cnt); };
     // Tc and diagL: the equalities, then the rows of a warm start (at most qcap of them) behind them in the sweep
-    A(&qp->Z, n1 * n1); A(&qp->Jw, n1 * n1); A(&qp->Tc, ((size_t)qp->meq + qc) * n1); A(&qp->GJ, (size_t)qp->mg * n1);
+    A(&qp->Z, n1 * ldw); A(&qp->Jw, n1 * ldw); A(&qp->Tc, ((size_t)qp->meq + qc) * ldw); A(&qp->GJ, (size_t)qp->mg * ldw);
     A(&qp->diagL, qp->meq + qc); A(&qp->dots, (size_t)qp->mg + n1); A(&qp->dvec, n1); A(&qp->rvec, qc);
-    A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc); A(&qp->Vp, (size_t)LQ_NB * n1); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc);
+    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
     A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 2); A(&qp->csbuf, 2 * qc);
@@ -2113,6 +2120,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         // select the two older kernels (kept for comparison; they need their own, smaller, LDS budget)
         qp->gi_mode = (mode && (std::string(mode) == "single" || std::string(mode) == "coop" || std::string(mode) == "old")) ? 1 : 0;
         if (qp->gi_mode == 1 && gi_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) qp->gi_mode = 0;
+        const char* lq = getenv("OGSQP_LQ");
+        qp->lq16 = !(lq && std::string(lq) == "8");
         const char* warm = getenv("OGSQP_WARM");
         qp->warm_enabled = !(warm && std::string(warm) == "0");
     }
@@ -2133,7 +2142,7 @@ int og_qp_reset(og_qp_handle qp) {
     if (!qp) return fail(2, "og_qp_reset: null handle");
     OG_HIP(hipSetDevice(qp->device));
     dim3 grid((qp->n1 + 255) / 256, qp->n1);
-    hipLaunchKernelGGL(k_identity, grid, dim3(256), 0, qp->stream, qp->Z, qp->n1, qp->n1);
+    hipLaunchKernelGGL(k_identity, grid, dim3(256), 0, qp->stream, qp->Z, qp->ldw, qp->n1);
     OG_HIP(hipGetLastError());
     OG_HIP(hipStreamSynchronize(qp->stream));
     return 0;
@@ -2142,7 +2151,7 @@ int og_qp_reset(og_qp_handle qp) {
 int og_qp_get_factor(og_qp_handle qp, double* Z) {
     if (!qp || !Z) return fail(2, "og_qp_get_factor: null argument");
     OG_HIP(hipSetDevice(qp->device));
-    OG_HIP(hipMemcpy2D(Z, (size_t)qp->n * sizeof(double), qp->Z, (size_t)qp->n1 * sizeof(double),
+    OG_HIP(hipMemcpy2D(Z, (size_t)qp->n * sizeof(double), qp->Z, (size_t)qp->ldw * sizeof(double),
                        (size_t)qp->n * sizeof(double), qp->n, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2150,7 +2159,7 @@ int og_qp_get_factor(og_qp_handle qp, double* Z) {
 int og_qp_set_factor(og_qp_handle qp, const double* Z) {
     if (!qp || !Z) return fail(2, "og_qp_set_factor: null argument");
     OG_HIP(hipSetDevice(qp->device));
-    OG_HIP(hipMemcpy2D(qp->Z, (size_t)qp->n1 * sizeof(double), Z, (size_t)qp->n * sizeof(double),
+    OG_HIP(hipMemcpy2D(qp->Z, (size_t)qp->ldw * sizeof(double), Z, (size_t)qp->n * sizeof(double),
                        (size_t)qp->n * sizeof(double), qp->n, hipMemcpyHostToDevice));
     return 0;
 }
@@ -2166,7 +2175,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     OG_HIP(hipSetDevice(qp->device));
     hipStream_t s = qp->stream;
     if (hip_stream) OG_HIP(hipStreamSynchronize((hipStream_t)hip_stream));   // producer of d_jt
-    const int n = qp->n, n1 = qp->n1, meq = qp->meq, mg = qp->mg, m = qp->m;
+    const int n = qp->n, n1 = qp->n1, ldw = qp->ldw, meq = qp->meq, mg = qp->mg, m = qp->m;
     const int nq = augmented ? n + 1 : n;
     const int nr = nq - meq;
     if (iterations) *iterations = 0;
@@ -2195,7 +2204,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     AView A{d_jt, (long)ld, qp->extra, n};
     // ---- work factor, C Z, LQ sweep
     OG_STAGE("copy_factor");
-    hipLaunchKernelGGL(k_copy_factor, dim3((nq + 255) / 256, nq), dim3(256), 0, s, qp->Z, qp->Jw, n1, n, nq,
+    hipLaunchKernelGGL(k_copy_factor, dim3((nq + 255) / 256, nq), dim3(256), 0, s, qp->Z, qp->Jw, ldw, n, nq,
                        augmented ? 1.0 / rho : 0.0);
     // ---- rows of a warm start: active at the solution of the previous subproblem, appended to the sweep
     int nwarm = 0;
@@ -2217,13 +2226,13 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         if (nwarm) {
             OG_HIP(hipMemcpyAsync(qp->d_warm, ids.data(), sizeof(int) * nwarm, hipMemcpyHostToDevice, s));
             OG_HIP(hipStreamSynchronize(s));                   // ids is a local
-            double* Text = qp->Tc + (size_t)meq * n1;
+            double* Text = qp->Tc + (size_t)meq * ldw;
             OG_STAGE("warm rows");
             if (ng)
                 hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (ng + 63) / 64), dim3(256), 0, s, A, meq, ng, qp->Jw,
-                                   n1, nq, Text, (const int*)qp->d_warm);
+                                   ldw, nq, Text, (const int*)qp->d_warm);
             if (nwarm > ng)
-                hipLaunchKernelGGL(k_rows_gather_bounds, dim3((nq + 255) / 256, nwarm - ng), dim3(256), 0, s, qp->Jw, n1,
+                hipLaunchKernelGGL(k_rows_gather_bounds, dim3((nq + 255) / 256, nwarm - ng), dim3(256), 0, s, qp->Jw, ldw,
                                    nq, mg, (const int*)qp->d_warm, ng, nwarm, Text);
         }
     }
@@ -2231,16 +2240,41 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     if (msweep) {
         OG_STAGE("gemm C Z");
         if (meq)
-            hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, n1,
+            hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, ldw,
                                nq, qp->Tc, (const int*)nullptr);
         OG_STAGE("lq sweep");
         OG_HIP(hipMemsetAsync(qp->dthresh, 0, 2 * sizeof(double), s));
-        for (int k = 0; k < msweep; k += LQ_NB) {
+        for (int k = 0; k < msweep;) {
+            if (qp->lq16 && nq - k <= 2048 && k % LQ16 == 0) {
+                // 16 reflectors per trip: row-distributed panel kernel, MFMA trailing update (ogsqp_lq16.h)
+                const int nb16 = std::min(LQ16, msweep - k), len16 = nq - k;
+                const int nrows16 = (msweep - k - nb16) + nq;
+                const int eg = (len16 + 255) / 256, ub = (len16 + 127) / 128;
+#define OG_PANEL16(E)                                                                                              \
+    hipLaunchKernelGGL(k_lq_panel16<E>, dim3(1), dim3(P16_THREADS), (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, ldw, \
+                       msweep, nq, k, qp->V16, ldw, qp->diagL, qp->panel16, qp->dthresh + 1)
+                if (eg <= 2) OG_PANEL16(2);
+                else if (eg <= 4) OG_PANEL16(4);
+                else if (eg <= 6) OG_PANEL16(6);
+                else OG_PANEL16(8);
+#undef OG_PANEL16
+#define OG_APPLY16(U)                                                                                            \
+    hipLaunchKernelGGL(k_lq_apply16<U>, dim3((nrows16 + 15) / 16), dim3(64 * A16_WAVES), 0, s, qp->Tc, qp->Jw, ldw, msweep, \
+                       nq, k, (const double*)qp->V16, ldw, (const Lq16Panel*)qp->panel16)
+                if (ub <= 2) OG_APPLY16(2);
+                else if (ub <= 4) OG_APPLY16(4);
+                else if (ub <= 8) OG_APPLY16(8);
+                else if (ub <= 12) OG_APPLY16(12);
+                else OG_APPLY16(16);
+#undef OG_APPLY16
+                k += LQ16;
+                continue;
+            }
             const int nb = std::min(LQ_NB, msweep - k);
             const int nrows = (msweep - k - nb) + nq;
             const int len = nq - k;                                // length of the panel rows
 #define OG_PANEL(PT, CPT)                                                                                      \
-    hipLaunchKernelGGL((k_lq_panel<PT, CPT>), dim3(1), dim3(PT), 0, s, qp->Tc, n1, msweep, nq, k, qp->Vp, qp->diagL, \
+    hipLaunchKernelGGL((k_lq_panel<PT, CPT>), dim3(1), dim3(PT), 0, s, qp->Tc, ldw, msweep, nq, k, qp->Vp, qp->diagL, \
                        qp->panel, qp->dthresh + 1)
             if (len <= PANEL_SMALL_PT * 4) OG_PANEL(PANEL_SMALL_PT, 4);
             else if (len <= PANEL_SMALL_PT * 8) OG_PANEL(PANEL_SMALL_PT, 8);
@@ -2262,13 +2296,14 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
                 const dim3 grid((nrows + LQ_RW - 1) / LQ_RW);
                 const int jt = (len + 255) / 256;
 #define OG_APPLY(KERNEL) \
-    hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, qp->Tc, qp->Jw, n1, msweep, nq, k, qp->Vp, qp->panel)
+    hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, qp->Tc, qp->Jw, ldw, msweep, nq, k, qp->Vp, qp->panel)
                 if (jt <= 2) OG_APPLY(k_lq_apply_reg<2>);
                 else if (jt <= 4) OG_APPLY(k_lq_apply_reg<4>);
                 else if (jt <= 6) OG_APPLY(k_lq_apply_reg<6>);
                 else OG_APPLY(k_lq_apply);
 #undef OG_APPLY
             }
+            k += LQ_NB;
         }
 #ifdef OGSQP_TRACE
         {
@@ -2287,7 +2322,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     const size_t trsv_lds = (size_t)(meq + 64 * 65) * sizeof(double);
     OG_STAGE("trsv w1");
     if (meq)
-        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, n1, qp->diagL, meq, 0, -1.0, qp->c,
+        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, ldw, qp->diagL, meq, 0, -1.0, qp->c,
                            qp->w1, qp->dthresh, qp->flag);
     int hflag[2] = {0, 0};
     OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2298,24 +2333,24 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     }
     OG_STAGE("deq");
     if (nr > 0)
-        hipLaunchKernelGGL(k_gemv_cols, dim3((nr + 63) / 64), dim3(1024), 0, s, qp->Jw + meq, (long)n1, nq, nr, qp->g,
+        hipLaunchKernelGGL(k_gemv_cols, dim3((nr + 63) / 64), dim3(1024), 0, s, qp->Jw + meq, (long)ldw, nq, nr, qp->g,
                            (const double*)nullptr, qp->t1);
     hipLaunchKernelGGL(k_concat_neg, dim3((nq + 255) / 256), dim3(256), 0, s, qp->w1, meq, qp->t1, nr, qp->xcat);
-    hipLaunchKernelGGL(k_gemv_rows, dim3((nq + 3) / 4), dim3(256), 0, s, qp->Jw, (long)n1, nq, nq, qp->xcat, 1.0,
+    hipLaunchKernelGGL(k_gemv_rows, dim3((nq + 3) / 4), dim3(256), 0, s, qp->Jw, (long)ldw, nq, nq, qp->xcat, 1.0,
                        (const double*)nullptr, qp->deq);
     // ---- least-distance problem in the null space
     OG_STAGE("gemm G J");
     if (mg) {
-        hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (mg + 63) / 64), dim3(256), 0, s, A, meq, mg, qp->Jw, n1,
+        hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (mg + 63) / 64), dim3(256), 0, s, A, meq, mg, qp->Jw, ldw,
                            nq, qp->GJ, (const int*)nullptr);
         hipLaunchKernelGGL(k_gemv_cols_A, dim3((mg + 63) / 64), dim3(1024), 0, s, A, meq, nq, mg, qp->deq,
                            qp->c + meq, qp->bG);
     }
     OG_STAGE("ldp setup");
-    hipLaunchKernelGGL(k_ldp_setup, dim3((mg + nq + 3) / 4), dim3(256), 0, s, qp->GJ, qp->Jw, n1, meq, nq, mg, qp->bG,
+    hipLaunchKernelGGL(k_ldp_setup, dim3((mg + nq + 3) / 4), dim3(256), 0, s, qp->GJ, qp->Jw, ldw, meq, nq, mg, qp->bG,
                        qp->c + meq, qp->deq, qp->dl, qp->du, qp->bval, qp->scale, qp->own, qp->flag);
     GiArgs ga;
-    ga.GJ = qp->GJ; ga.Jw = qp->Jw; ga.ld = n1; ga.meq = meq; ga.nq = nq; ga.mg = mg; ga.nr = nr;
+    ga.GJ = qp->GJ; ga.Jw = qp->Jw; ga.ld = ldw; ga.meq = meq; ga.nq = nq; ga.mg = mg; ga.nr = nr;
     ga.qcap = qp->qcap; ga.bval = qp->bval; ga.scale = qp->scale; ga.own = qp->own; ga.u = qp->u;
     ga.isact = qp->isact; ga.y = qp->y; ga.act = qp->act; ga.R[0] = qp->R[0]; ga.R[1] = qp->R[1];
     ga.RI[0] = qp->RI[0]; ga.RI[1] = qp->RI[1]; ga.Q1t = qp->Q1t; ga.partials = qp->partials; ga.st = qp->st;
@@ -2506,14 +2541,14 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     }
     // ---- step and multipliers
     OG_STAGE("finish");
-    hipLaunchKernelGGL(k_finish_step, dim3((nq + 3) / 4), dim3(256), 0, s, qp->Jw, n1, meq, nq, nr, mg, qp->y, qp->deq,
+    hipLaunchKernelGGL(k_finish_step, dim3((nq + 3) / 4), dim3(256), 0, s, qp->Jw, ldw, meq, nq, nr, mg, qp->y, qp->deq,
                        qp->dl, qp->du, qp->u, qp->d, qp->bm);
     hipLaunchKernelGGL(k_dual_residual, dim3((nq + 3) / 4), dim3(256), 0, s, A, meq, mg, nq, qp->g, qp->u, qp->bm,
                        qp->tvec);
     if (meq) {
-        hipLaunchKernelGGL(k_gemv_cols, dim3((meq + 63) / 64), dim3(1024), 0, s, qp->Jw, (long)n1, nq, meq, qp->tvec,
+        hipLaunchKernelGGL(k_gemv_cols, dim3((meq + 63) / 64), dim3(1024), 0, s, qp->Jw, (long)ldw, nq, meq, qp->tvec,
                            qp->w1, qp->rhs);
-        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, n1, qp->diagL, meq, 1, 1.0, qp->rhs,
+        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, ldw, qp->diagL, meq, 1, 1.0, qp->rhs,
                            qp->lam, qp->dthresh, qp->flag);
     }
     OG_HIP(hipGetLastError());
@@ -2592,7 +2627,7 @@ int og_qp_solve(og_qp_handle qp, const double* A, const double* g, const double*
 int og_qp_bfgs(og_qp_handle qp, const double* s, const double* eta, const double* Bs, int32_t* reset_needed) {
     if (!qp || !s || !eta || !Bs || !reset_needed) return fail(2, "og_qp_bfgs: null argument");
     OG_HIP(hipSetDevice(qp->device));
-    const int n = qp->n, n1 = qp->n1;
+    const int n = qp->n, n1 = qp->n1, ldw = qp->ldw;
     double h1 = 0.0, h2 = 0.0;
     for (int i = 0; i < n; ++i) {
         h1 += s[i] * eta[i];
@@ -2620,9 +2655,9 @@ int og_qp_bfgs(og_qp_handle qp, const double* s, const double* eta, const double
     hipStream_t st = qp->stream;
     OG_HIP(hipMemcpyAsync(qp->svec, hs.data(), sizeof(double) * n1, hipMemcpyHostToDevice, st));
     OG_HIP(hipMemcpyAsync(qp->vvec, hs.data() + n1, sizeof(double) * n1, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gemv_cols, dim3((n + 63) / 64), dim3(1024), 0, st, qp->Z, (long)n1, n, n, qp->vvec,
+    hipLaunchKernelGGL(k_gemv_cols, dim3((n + 63) / 64), dim3(1024), 0, st, qp->Z, (long)ldw, n, n, qp->vvec,
                        (const double*)nullptr, qp->vz);
-    hipLaunchKernelGGL(k_rank1, dim3((n + 255) / 256, n), dim3(256), 0, st, qp->Z, n1, n, qp->svec, qp->vz,
+    hipLaunchKernelGGL(k_rank1, dim3((n + 255) / 256, n), dim3(256), 0, st, qp->Z, ldw, n, qp->svec, qp->vz,
                        1.0 / alpha);
     OG_HIP(hipGetLastError());
     OG_HIP(hipStreamSynchronize(st));

@@ -1,0 +1,314 @@
+// ogsqp_lq16.h - the LQ sweep in panels of 16 reflectors: a panel kernel with the ROWS spread over the lanes and
+// an MFMA trailing update (included by ogsqp.hip inside its anonymous namespace).
+//
+// The sweep of 8-reflector panels (k_lq_panel / k_lq_apply_reg) is bound by its panel kernel: every thread holds
+// all 8 rows of its columns, so each reflector costs 8 workgroup-wide reductions (25-29 us per panel, one
+// workgroup, the chip idle), and the trailing update streams the whole matrix once per 8 reflectors (17-25 us).
+//
+//   k_lq_panel16   16 rows x L columns, 512 threads.  Lane l of every wavefront belongs to the rows 2 (l / 8) and
+//                  2 (l / 8) + 1: eight lanes per row pair and wavefront, 64 column slots per pair in all.  The dot
+//                  products of ALL rows with the current reflector vector are then one multiply-add sweep over the
+//                  lane's own columns, one 8-lane DPP sum, and one exchange of 16 x 8 partial sums through LDS -
+//                  per reflector, not per row.  (One row per lane group would read the vector from LDS 16 times
+//                  per step - LDS-bandwidth bound; all rows per lane is the old kernel.)  Rows that are already
+//                  reflector vectors take part like the others: their products with the new vector are the
+//                  off-diagonal entries of V V' that the T factor needs, for free.
+//   k_lq_apply16   row <- row - ((row V') T) V on the FP64 matrix cores, 16 rows per workgroup, the columns split
+//                  over its four wavefronts, the row segments held in registers between the two products (one read
+//                  and one write of the matrix per 16 reflectors).  All three products run in the transposed form
+//                  (reflector index or column index on the M side, matrix row on the N side): the accumulator
+//                  layout of one product is then the B operand of the next without a shuffle, given that the K index
+//                  of an MFMA may be permuted freely as long as both operands agree on it.
+//
+// Numerically this is the same Householder sweep as before (and as the restatement's loop), sums in another order.
+
+constexpr int LQ16 = 16;            // reflectors per panel
+constexpr int P16_THREADS = 512;
+constexpr int P16_WAVES = P16_THREADS / 64;
+constexpr int P16_SLOTS = 8 * P16_WAVES;        // column slots per row pair: slot s owns the columns 4 (64 e + s) + i
+
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+struct Lq16Panel {
+    double T[LQ16][LQ16];
+    int nb;
+    int pad;
+};
+
+// sum over the eight lanes that share a pair of rows in one wavefront, in every one of them
+__device__ __forceinline__ double oct_sum(double v) {
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror: the other quad of the eight
+    return v;
+}
+
+// E: groups of 4 columns per lane (rows of up to 256 E entries from the panel's first column on).  Lane l of every
+// wavefront holds the rows 2 (l / 8) and 2 (l / 8) + 1 on its columns: the reflector vector is read from LDS once
+// per lane and step and serves both, in the products and in the update.
+template <int E>
+__global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__ Tc, int ld, int mrows, int nq, int k,
+                                                           double* __restrict__ V, int ldv, double* __restrict__ diagL,
+                                                           Lq16Panel* __restrict__ panel, double* __restrict__ dmaxbuf) {
+    extern __shared__ double lds[];
+    __shared__ double s_part[2][P16_WAVES][LQ16];    // partial dot products (double-buffered by step parity)
+    __shared__ double s_xpc[2][LQ16];                // every row's entry in the pivot column
+    __shared__ double s_lower[LQ16][LQ16];           // finished entries of L inside the panel
+    __shared__ double s_S[LQ16][LQ16];               // v_a . v_b, a < b
+    __shared__ double s_T[LQ16][LQ16];
+    __shared__ double s_beta[LQ16], s_diag[LQ16];
+    double* vrow = lds;                              // 2 x (256 E): the current row (reflector vector before its pivot is set)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int rp = lane >> 3, slot = wv * 8 + (lane & 7);
+    const int nb = min(LQ16, mrows - k), L = nq - k;
+    const int W = 256 * E;
+    double x[2][E][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 2 * rp + h;
+        const double* row = Tc + (long)(k + min(r, nb - 1)) * ld + k;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            // one 32-byte load (rows are 128-byte aligned from column k on; no branch: the loads go out together)
+            const int j = 4 * (64 * e + slot);
+            const dbl4 v = *(const dbl4*)(row + min(j, 4 * ((L - 1) / 4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[h][e][i] = (r < nb && j + i < L) ? v[i] : 0.0;
+        }
+    }
+    for (int e = tid; e < LQ16 * LQ16; e += P16_THREADS) {
+        (&s_S[0][0])[e] = 0.0;
+        (&s_T[0][0])[e] = 0.0;
+        (&s_lower[0][0])[e] = 0.0;
+    }
+    double dmax = dmaxbuf[0];
+#pragma unroll
+    for (int b = 0; b < LQ16; ++b) {
+        if (b < nb) {                                // (uniform)
+            double* vr = vrow + (b & 1) * W;
+            // row b's lanes publish it: entries left of the pivot are finished entries of L (kept aside, zero in
+            // the vector); every row publishes its entry in the pivot column b = slot b / 4, register b % 4
+            if (rp == (b >> 1)) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 4 * (64 * e + slot) + i;
+                        if (j < b) {
+                            s_lower[b][j] = x[b & 1][e][i];
+                            x[b & 1][e][i] = 0.0;
+                        }
+                        vr[j] = x[b & 1][e][i];
+                    }
+            }
+            if (slot == (b >> 2)) {
+                s_xpc[b & 1][2 * rp] = x[0][0][b & 3];
+                s_xpc[b & 1][2 * rp + 1] = x[1][0][b & 3];
+            }
+            __syncthreads();
+            // the vector on my columns, once; products of my two rows with it
+            double v[E][4];
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int j = 4 * (64 * e + slot);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[e][i] = vr[j + i];
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = fma(x[0][e][i], v[e][i], acc0);
+                    acc1 = fma(x[1][e][i], v[e][i], acc1);
+                }
+            acc0 = oct_sum(acc0);
+            acc1 = oct_sum(acc1);
+            if ((lane & 7) == 0) {
+                s_part[b & 1][wv][2 * rp] = acc0;
+                s_part[b & 1][wv][2 * rp + 1] = acc1;
+            }
+            __syncthreads();
+            double Db = 0.0, D0 = 0.0, D1 = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < P16_WAVES; ++w8) {
+                Db += s_part[b & 1][w8][b];
+                D0 += s_part[b & 1][w8][2 * rp];
+                D1 += s_part[b & 1][w8][2 * rp + 1];
+            }
+            const double x0 = s_xpc[b & 1][b];
+            const double xr0 = s_xpc[b & 1][2 * rp], xr1 = s_xpc[b & 1][2 * rp + 1];
+            const double sigma = sqrt(Db);
+            // what is left of a row that depends on the earlier ones is rounding noise: no reflector is built from
+            // it (it would rotate the null-space basis by that noise); its pivot is recorded as exactly 0
+            const bool live = sigma > REDUNDANT * dmax && sigma > 0.0;
+            dmax = fmax(dmax, sigma);
+            const double alpha = !live ? 0.0 : (x0 >= 0.0 ? -sigma : sigma);
+            const double v0 = x0 - alpha;
+            const double vv = Db - x0 * x0 + v0 * v0;
+            const double bt = (live && vv > 0.0) ? 2.0 / vv : 0.0;
+            const double rv0 = D0 - xr0 * alpha, rv1 = D1 - xr1 * alpha;     // row . v_b
+            if (tid == 0) {
+                s_beta[b] = bt;
+                s_diag[b] = alpha;
+            }
+            if (wv == 0 && (lane & 7) == 0) {
+                if (2 * rp < b) s_S[2 * rp][b] = rv0;
+                if (2 * rp + 1 < b) s_S[2 * rp + 1][b] = rv1;
+            }
+            // rows below b: row -= f v_b with v_b = the published row, its pivot entry lowered by alpha
+            const double f0 = (2 * rp > b && 2 * rp < nb) ? bt * rv0 : 0.0;
+            const double f1 = (2 * rp + 1 > b && 2 * rp + 1 < nb) ? bt * rv1 : 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x[0][e][i] = fma(-f0, v[e][i], x[0][e][i]);
+                    x[1][e][i] = fma(-f1, v[e][i], x[1][e][i]);
+                }
+            if (slot == (b >> 2)) {
+                x[0][0][b & 3] = fma(f0, alpha, x[0][0][b & 3]);
+                x[1][0][b & 3] = fma(f1, alpha, x[1][0][b & 3]);
+                if (rp == (b >> 1)) x[b & 1][0][b & 3] = v0;     // row b becomes its reflector vector
+            }
+        }
+    }
+    // V (zero rows beyond nb), the finished entries of L, the diagonal
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 2 * rp + h;
+        double* vout = V + (long)r * ldv;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int j = 4 * (64 * e + slot);
+            if (j + 3 < L) {
+                dbl4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = r < nb ? x[h][e][i] : 0.0;
+                *(dbl4*)(vout + j) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j + i < L) vout[j + i] = r < nb ? x[h][e][i] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    // T by forward accumulation; row a of T depends only on itself: thread a does row a
+    if (tid < nb) {
+        const int a = tid;
+        s_T[a][a] = s_beta[a];
+        for (int b = a + 1; b < nb; ++b) {
+            double acc = 0.0;
+            for (int c = a; c < b; ++c) acc += s_T[a][c] * s_S[c][b];
+            s_T[a][b] = -s_beta[b] * acc;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < LQ16 * LQ16; e += P16_THREADS) {
+        const int a = e / LQ16, b = e % LQ16;
+        panel->T[a][b] = s_T[a][b];
+        if (a < nb && b < a) Tc[(long)(k + a) * ld + k + b] = s_lower[a][b];
+        if (a < nb && b == 0) diagL[k + a] = s_diag[a];
+    }
+    if (tid == 0) {
+        panel->nb = nb;
+        panel->pad = 0;
+        dmaxbuf[0] = dmax;
+    }
+}
+
+// U: blocks of 16 columns per wavefront (rows of up to 128 U entries from the panel's first column on); eight
+// wavefronts per workgroup.  Rows are 128-byte aligned (leading dimension a multiple of 16, k a multiple of 16):
+// lane (n, g) owns the four CONSECUTIVE columns 16 b + 4 g + i of row n in block b - one 32-byte load, and the
+// sixteen lanes of a row group touch whole cache lines.  (An MFMA does not care which of its K slots - or M rows -
+// stands for which column as long as both operands agree; the products below are indexed accordingly.)  Every
+// global load of a phase is issued before the first result is used.
+constexpr int A16_WAVES = 8;
+template <int U>
+__global__ __launch_bounds__(64 * A16_WAVES) void k_lq_apply16(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
+                                                              int mrows, int nq, int k, const double* __restrict__ V,
+                                                              int ldv, const Lq16Panel* __restrict__ panel) {
+    __shared__ double s_w[A16_WAVES][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int nb = panel->nb, L = nq - k;
+    const int nblk = (L + 15) / 16;
+    const int below = mrows - k - nb, nrows = below + nq;
+    const int r = blockIdx.x * 16 + n;
+    const bool valid = r < nrows;
+    const int rc = valid ? r : nrows - 1;
+    double* row = (rc < below ? Tc + (long)(k + nb + rc) * ld : Jw + (long)(rc - below) * ld) + k;
+    // my row's segment: blocks wv, wv + 8, ...
+    dbl4 x[U], a[U];
+    const double* vrow = V + (long)n * ldv;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int b = min(wv + A16_WAVES * u, nblk - 1);
+        x[u] = *(const dbl4*)(row + 16 * b + 4 * g);
+        a[u] = *(const dbl4*)(vrow + 16 * b + 4 * g);
+    }
+    const double t0 = panel->T[g][n], t1 = panel->T[4 + g][n], t2 = panel->T[8 + g][n], t3 = panel->T[12 + g][n];
+    // W' = V X' (reflector 4 i + g in register i, matrix row n); K slot g of MFMA (u, i) is the column 16 b + 4 g + i
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j0 = 16 * (wv + A16_WAVES * u) + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = j0 + i < L;
+            x[u][i] = in ? x[u][i] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? a[u][i] : 0.0, x[u][i], acc, 0, 0, 0);
+        }
+    }
+    // the operands of the last product (V once more, reflector-major: M row m of block b is the column
+    // 16 b + 4 (m & 3) + (m >> 2), so that the result lands in the layout the segment is held in) are requested
+    // before the exchange
+    const int pm = 4 * (n & 3) + (n >> 2);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int b = min(wv + A16_WAVES * u, nblk - 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[u][t] = V[(long)(4 * t + g) * ldv + 16 * b + pm];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_w[wv][lane][i] = acc[i];
+    __syncthreads();
+    double wt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < A16_WAVES; ++w8) sum += s_w[w8][lane][i];
+        wt[i] = sum;
+    }
+    // Z' = T' W': A (m' = n, k = 4 t + g) = T[4 t + g][n], B = register t of W'
+    d4 z = d4{0.0, 0.0, 0.0, 0.0};
+    z = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, wt[0], z, 0, 0, 0);
+    z = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, wt[1], z, 0, 0, 0);
+    z = __builtin_amdgcn_mfma_f64_16x16x4f64(t2, wt[2], z, 0, 0, 0);
+    z = __builtin_amdgcn_mfma_f64_16x16x4f64(t3, wt[3], z, 0, 0, 0);
+    // X' -= V' Z' block by block: A (M row n, k = 4 t + g) = V[4 t + g][16 b + pm], B = register t of Z'; result
+    // register i of lane (n, g) = M row 4 i + g = column 16 b + 4 g + i of matrix row n
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool in = 16 * (wv + A16_WAVES * u) + pm < L;
+        d4 o = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? a[u][t] : 0.0, z[t], o, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[u][i] -= o[i];
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j0 = 16 * (wv + A16_WAVES * u) + 4 * g;
+        if (j0 + 3 < L) {
+            *(dbl4*)(row + j0) = x[u];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (j0 + i < L) row[j0 + i] = x[u][i];
+        }
+    }
+}

@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: full forward-difference Jacobian sweeps of the NLP callbacks.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one process per GPU over RCCL: under a launcher (``python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...``: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or, when WORLD_SIZE is
+not set, by launching itself that way (``--standalone --local-addr 127.0.0.1``).  ``--single-process`` instead
+drives the N devices from ONE process (``og_comm_init`` + ``og_multi_fd_sweep_enqueue``: ncclCommInitAll and a
+grouped all-gather; no launcher at all).  ``OG_BENCH_SAME_DEVICE=1`` puts every rank / sub-handle on device 0 (a
+dry run of the N > 1 plumbing on a one-GPU box: the exchange then goes through host staging / peer copies and
+the line says so).
 
 One *step* = one SLSQP major iteration's worth of callback work at a fixed point x0 that is
 already resident in HBM: F(x0) plus the n forward-difference columns of
@@ -37,6 +45,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+DEPENDENT_CHAIN_US = 3.6       # ogk_fused at C3: first request -> last store issued, from the in-kernel stamps of every
+                               # wavefront (tools/trace_fused.py, profiles/r02_trace_fused_polar_tsto.txt)
 
 
 def cpu_baseline(name, mode, seconds=10.0, nodes=None):
@@ -98,6 +108,29 @@ def measured_traffic(workload, kernel, custom_size):
     return best
 
 
+def cold_start(name, nodes=None):
+    """What a NEW problem shape pays before its first sweep (the reference starts iterating at once,
+    ``optimize.py:649-755``): trace the callbacks, generate the device header, compile the kernel module with hipcc
+    (forced: the cached module of this workload is ignored), load it and create the handle.  In a process of its
+    own, so that nothing of this run's state helps."""
+    import subprocess
+    code = ("import json, sys, time; t0 = time.perf_counter(); "
+            "from opengoddard_amd import build, codegen, problems; from opengoddard_amd.engine import HipEngine; "
+            "kw = {'nodes': [int(v) for v in sys.argv[2].split(',')]} if sys.argv[2] else {}; "
+            "prob, obj = problems.build(sys.argv[1], **kw); t1 = time.perf_counter(); "
+            "P = codegen.trace_problem(prob, obj); hdr = codegen.emit_header(P); t2 = time.perf_counter(); "
+            "build.build_module(hdr, force=True, out_suffix='.cold'); t3 = time.perf_counter(); "
+            "eng = HipEngine(prob, obj, program=P); t4 = time.perf_counter(); "
+            "print(json.dumps({'import_and_problem_s': t1 - t0, 'trace_and_codegen_s': t2 - t1, 'hipcc_s': t3 - t2, "
+            "'load_and_create_s': t4 - t3, 'total_s': t4 - t0}))")
+    try:
+        proc = subprocess.run([sys.executable, "-c", code, name, nodes or ""], cwd=ROOT, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, timeout=600)
+        return json.loads(proc.stdout.strip().splitlines()[-1])
+    except Exception as exc:
+        return {"total_s": None, "error": repr(exc)}
+
+
 def fill_and_copy_peaks(torch, dev):
     """What this very GPU sustains on a long stream, measured in this run: a 1 GiB fill (write only) and a
     1 GiB device-to-device copy (read + write), GB/s."""
@@ -119,6 +152,48 @@ def fill_and_copy_peaks(torch, dev):
     return out
 
 
+def sqp_first_qp_parity(eng, prob, lb, ub):
+    """The first QP subproblem of the SQP leg (B = I, the Jacobian the sweep kernel leaves in HBM) solved by the HIP
+    core and by the CPU restatement (oracle/slsqp_np.py, LAPACK LQ) - the checker, not the thing measured.  An
+    inconsistent linearisation (mode 4: C3 starts with one) is compared on the relaxed problem, as the driver
+    solves it.  Returns what was compared; ``parity_checked`` is True only if everything asserted here held."""
+    import numpy as np
+    from opengoddard_amd import _native, _sqp_native
+    from oracle import slsqp_np
+    x = np.clip(prob.p, lb, ub)
+    F0, JT = eng.sweep_stacked(x, _native.fd_step(x, lb, ub))
+    n, meq = eng.n, eng.m_eq
+    g, A, c = JT[:, 0].copy(), JT[:, 1:].T.copy(), F0[1:]
+    t0 = time.perf_counter()
+    ref = slsqp_np.qp_solve(np.eye(n), g, A[:meq], c[:meq], A[meq:], c[meq:], lb - x, ub - x, lq="lapack")
+    core = _sqp_native.QpCore(n, meq, eng.m_ineq, device=eng.device)
+    d, mult, bm, status, iters = core.solve(A, g, c, lb - x, ub - x)
+    relaxed = False
+    assert status == ref[3], "first QP: exit mode %d, restatement %d" % (status, ref[3])
+    if status == 4:
+        relaxed = True
+        Za = np.eye(n + 1)
+        Za[n, n] = 1.0 / 100.0
+        extra = np.concatenate([-c[:meq], np.maximum(-c[meq:], 0.0)])
+        Aa = np.hstack([A, extra[:, None]])
+        lo, hi = np.append(lb - x, 0.0), np.append(ub - x, 1.0)
+        ref = slsqp_np.qp_solve(Za, np.append(g, 0.0), Aa[:meq], c[:meq], Aa[meq:], c[meq:], lo, hi, lq="lapack")
+        core.set_active()
+        d, mult, bm, status, iters = core.solve(A, g, c, lo, hi, True, 100.0)
+        assert status == ref[3] == 1, "relaxed first QP: exit mode %d, restatement %d" % (status, ref[3])
+    core.close()
+    scale = max(1.0, float(np.abs(ref[0]).max()))
+    step_err = float(np.max(np.abs(d - ref[0])) / scale)
+    # vertex solutions at these sizes are ill-conditioned (tests/test_slsqp_core.py measures the amplification):
+    # two exact solvers agree to ~1e-7 of the step, not to 1e-11
+    assert step_err <= 1e-6, "first QP: step differs from the restatement by %.3g of its size" % step_err
+    assert abs(iters - ref[5]["ldp_iterations"]) <= max(2, ref[5]["ldp_iterations"] // 100)
+    return {"parity_checked": True, "first_qp_relaxed": relaxed, "first_qp_exit_mode": int(status),
+            "first_qp_step_error_rel": step_err, "first_qp_active_set_changes": int(iters),
+            "first_qp_active_set_changes_restatement": int(ref[5]["ldp_iterations"]),
+            "checker": "oracle/slsqp_np.py qp_solve (LAPACK LQ), %.1f s of CPU" % (time.perf_counter() - t0)}
+
+
 def sqp_leg(eng, prob, iterations, reference_iterations=0):
     """Second BASELINE metric, "wall-clock to SLSQP convergence", on a bounded sample: the first
     ``iterations`` major iterations of ``Problem.solve`` with the QP subproblems on the GPU
@@ -134,6 +209,10 @@ def sqp_leg(eng, prob, iterations, reference_iterations=0):
     wall = time.perf_counter() - t0
     t = res.timing
     out = _sqp_result(res, wall, t, iterations)
+    try:
+        out.update(sqp_first_qp_parity(eng, prob, lb, ub))
+    except AssertionError as exc:
+        out.update({"parity_checked": False, "parity_failure": str(exc)})
     if reference_iterations > 0:
         out["scipy_core"] = scipy_core_sample(eng, prob, lb, ub, reference_iterations)
         out["speedup_per_major_iteration"] = (out["scipy_core"]["ms_per_major_iteration"] /
@@ -174,6 +253,89 @@ def _sqp_result(res, wall, t, iterations):
             "ms_per_major_iteration": 1e3 * wall / max(1, res.nit - 1)}
 
 
+def launch_ranks(n_gpus):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script under torch.distributed.run
+    (one node, rendezvous on 127.0.0.1) and hand its exit code on; rank 0 of the children prints the JSON line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1",
+           "--nproc-per-node", str(int(n_gpus)), "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def single_process_bench(a):
+    """N devices from one process: every step is one ``og_multi_fd_sweep_enqueue`` (x, h uploaded to every device,
+    one launch per device that sweeps its column block and packs its non-zeros, ONE grouped ncclAllGather - or peer
+    copies -, one scatter per device), K steps between two ``og_multi_synchronize``.  Afterwards the matrix of
+    device 0 is compared bit for bit with a one-device sweep."""
+    import ctypes as C
+    import numpy as np
+    import torch                                              # noqa: F401  (one HIP runtime in the process)
+    from opengoddard_amd import _native, problems
+    from opengoddard_amd.engine import HipEngine
+    G = int(a.gpus)
+    same = bool(os.environ.get("OG_BENCH_SAME_DEVICE"))
+    if same:
+        os.environ["OGPSX_GATHER"] = "peer"                   # one device listed G times: peer copies only
+    devices = [0] * G if same else list(range(G))
+    if not same and _native.device_count() < G:
+        raise SystemExit("bench.py --single-process: %d devices wanted, %d visible" % (G, _native.device_count()))
+    build_kw = {"nodes": [int(v) for v in a.nodes.split(",")]} if a.nodes else {}
+    prob, obj = problems.build(a.workload, **build_kw)
+    single = HipEngine(prob, obj, device=devices[0])
+    multi = HipEngine(prob, obj, devices=devices) if G > 1 else single
+    n, m = single.n, single.m
+    lb = np.array([-np.inf if b[0] is None else b[0] for b in prob.bounds])
+    ub = np.array([np.inf if b[1] is None else b[1] for b in prob.bounds])
+    x0 = np.clip(prob.p, lb, ub)
+    h = _native.fd_step(x0, lb, ub)
+    lib = single._lib
+    if G > 1:
+        xp, hp = _native.dptr(x0), _native.dptr(h)
+
+        def run(k):
+            for _ in range(k):
+                _native.check(lib.og_multi_fd_sweep_enqueue(multi._multi, xp, hp), "og_multi_fd_sweep_enqueue")
+            _native.check(lib.og_multi_synchronize(multi._multi), "og_multi_synchronize")
+    else:
+        def run(k):
+            for _ in range(k):
+                single.sweep_persistent(x0, h)
+    run(a.warmup)
+    times = []
+    for _ in range(max(1, a.reps)):
+        t0 = time.perf_counter()
+        run(a.steps)
+        times.append(time.perf_counter() - t0)
+    times = np.sort(np.array(times))
+    elapsed = float(np.median(times))
+    F1, J1 = single.sweep_stacked(x0, h)
+    FG, JG = (multi.sweep_persistent(x0, h) if G > 1 else (F1, J1))
+    equal = bool(np.array_equal(J1, JG) and np.array_equal(F1, FG))
+    result = {
+        "metric": "NLP-callback evals/sec (cost+constr+FD-Jacobian)", "value": (3 * n + 2) * a.steps / elapsed,
+        "unit": "callback evals/s", "n_gpus": G, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "timed_region": {"repetitions": int(times.size), "steps_each": a.steps, "reported": "median",
+                         "ms_per_step_min": float(times[0]) / a.steps * 1e3,
+                         "ms_per_step_max": float(times[-1]) / a.steps * 1e3},
+        "config": {"workload": "%s: %d phases, %s states, %s controls, %s LGL nodes" % (
+            a.workload, len(prob.nodes), prob.number_of_states, prob.number_of_controls, prob.nodes),
+            "n": n, "m_eq": single.m_eq, "m_ineq": single.m_ineq, "evals_per_step": 3 * n + 2,
+            "parallelism": "fd-columns x%d from ONE process (og_multi_fd_sweep_enqueue; x and h uploaded per step; %s)" % (
+                G, "devices %r" % devices + (", " + ("ncclAllGather" if lib.og_comm_uses_rccl() else "peer copies") if G > 1 else ""))},
+        "self_check": {"multi_device_matrix_equals_single_device_bitwise": equal},
+    }
+    assert equal, "the column-sharded matrix differs from the single-device one"
+    if G > 1:
+        multi.close()
+    single.close()
+    print(json.dumps(result), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,7 +357,14 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (plumbing test)")
     ap.add_argument("--quick", action="store_true", help="only the timed region and the roofline (profiling runs)")
+    ap.add_argument("--no-cold-start", action="store_true", help="skip the forced rebuild of the workload's kernel module")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 from ONE process: og_comm_init + og_multi_fd_sweep_enqueue over the N devices (no launcher)")
     a = ap.parse_args()
+    if a.single_process:
+        return single_process_bench(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a.gpus)
 
     import numpy as np
     import torch
@@ -206,17 +375,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with "
-                         "torch.distributed.run)" % (a.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible - the engine has no CPU path to measure")
+    same_device = bool(os.environ.get("OG_BENCH_SAME_DEVICE")) and world > 1
+    if same_device:
+        local_rank = 0                  # dry run of the N > 1 plumbing on a one-GPU box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     collective = world > 1 or (a.force_collective and "MASTER_ADDR" in os.environ)
     if collective:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if same_device:
+            dist.init_process_group("gloo")             # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    pg_dev = "cpu" if same_device else dev
 
     build_kw = {"nodes": [int(v) for v in a.nodes.split(",")]} if a.nodes else {}
     prob, obj = problems.build(a.workload, **build_kw)
@@ -227,7 +402,10 @@ def main():
     x0 = np.clip(prob.p, lb, ub)
     h = _native.fd_step(x0, lb, ub)
     backend = sharding.HipBackend(eng, dev)
-    if collective and not os.environ.get("OG_BENCH_TORCH_ALLGATHER"):
+    if same_device:
+        backend.host_staged = True
+        backend.direct_note = "gloo through host staging (dry run: every rank on device 0)"
+    elif collective and not os.environ.get("OG_BENCH_TORCH_ALLGATHER"):
         backend.init_direct_rccl(rank, world)       # ncclCommInitRank in libogpsx.so; falls back by itself
     d_x, d_h = backend.upload(x0), backend.upload(h)
     stream = backend.stream
@@ -263,7 +441,7 @@ def main():
                 step(gather)
             fence()
             times.append(time.perf_counter() - t0)
-        t = torch.tensor(times, dtype=torch.float64, device=dev)
+        t = torch.tensor(times, dtype=torch.float64, device=pg_dev if collective else dev)
         if collective:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return np.sort(t.cpu().numpy())
@@ -324,6 +502,12 @@ def main():
     kern_ms_mean = float(np.mean(batched))
     kern_ms_single = float(np.mean(single))
 
+    # launch floor of this box: a kernel that does nothing, one workgroup per CU of 512 threads (the sweep's
+    # geometry class), back to back on the same stream between two events - what ANY one-launch step costs
+    def launch_probe():
+        _native.check(eng._lib.og_probe_launch(256, 512, 1, stream), "og_probe_launch")
+
+    floor_ms = float(np.median(timed(launch_probe, nb, 10)))
     ncols = hi - lo
     sumN2 = sum(int(v) ** 2 for v in prob.nodes)
     alg_bytes = 8.0 * ((ncols + 1) * n + m * ncols + sumN2)
@@ -358,7 +542,9 @@ def main():
             "parallelism": "fd-columns x%d%s" % (world, " + RCCL all-gather of the packed non-zeros (%d bytes per rank; %s)"
                                                   % (sweeps[0].message_bytes, backend.direct_note) if collective else "")},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     # (above 1 the convention prices traffic this kernel does not have: no fraction is reported)
+                     "frac": achieved / HBM_PEAK_GBS if achieved <= HBM_PEAK_GBS else None,
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_source": traffic["source"] if traffic else None,
                      # the honest bandwidth statement: bytes the PMC counters saw per launch over the launch's duration,
@@ -372,6 +558,15 @@ def main():
                      # what a launch really stores: the structural non-zeros of its block, F(x0) and the sweep scratch
                      "bytes_actually_written_per_launch": 8.0 * (nnz_block + 4 * m),
                      "structural_nonzeros_of_the_block": nnz_block,
+                     "convention": "reference-formulation bytes (SURVEY.md 8(d)) over the launch's duration; the launch "
+                                   "itself is a latency chain that moves only the non-zeros - see latency_floor_us",
+                     # the budget that discriminates now: an empty 256 x 512-thread launch back to back on this box
+                     # (launch floor) plus the dependent chain of one step (request -> barrier -> MFMA/dynamics chain ->
+                     # stores: 3.6 us of in-kernel s_memrealtime stamps at C3)
+                     "latency_floor_us": floor_ms * 1e3 + DEPENDENT_CHAIN_US,
+                     "latency_floor_parts_us": {"empty_launch_back_to_back": floor_ms * 1e3,
+                                                "dependent_chain_in_kernel": DEPENDENT_CHAIN_US},
+                     "frac_of_latency_floor": (floor_ms * 1e3 + DEPENDENT_CHAIN_US) / (kern_ms_mean * 1e3),
                      "kernel_ms_mean": kern_ms_mean, "kernel_ms_median": kern_ms,
                      "kernel_ms_single_launch_events": kern_ms_single,
                      "measured_fill_peak_GBs": peaks["fill"] if peaks else None,
@@ -482,12 +677,14 @@ def main():
         torch.cuda.synchronize()
         result["exact_jacobian"] = {"ms_per_jacobian": e0.elapsed_time(e1) / reps, "kernel": "ogk_eval + ogk_exact_struct",
                                     "note": "forward-mode derivatives (opt-in mode, jacobian='exact')"}
+    if world == 1 and rank == 0 and not a.quick and not a.no_cold_start:
+        result["cold_start_s"] = cold_start(a.workload, a.nodes)
     if world == 1 and rank == 0 and a.sqp_iterations > 0 and n <= 3000 and not a.quick:
         result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations,
                                 a.sqp_reference_iterations if n <= 1600 else 0)
     if collective:
         # every rank's replicas hold the whole matrix: compare rank 0's with every other rank's (checksums)
-        sums = torch.stack([sh.replica.sum(dtype=torch.float64) for sh in sweeps])
+        sums = torch.stack([sh.replica.sum(dtype=torch.float64) for sh in sweeps]).to(pg_dev)
         gathered = [torch.empty_like(sums) for _ in range(world)]
         dist.all_gather(gathered, sums)
         if rank == 0:
@@ -511,4 +708,4 @@ def main():
         dist.destroy_process_group()
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

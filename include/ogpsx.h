@@ -226,6 +226,10 @@ int og_device_read(int32_t device, const void* d_src, void* dst, int64_t bytes);
  * the buffer.  Fails on an ordinary handle. */
 int og_trace_read(og_handle h, double* out, int64_t count);
 int og_device_count(void);     /* HIP devices visible to the library (0 without a GPU) */
+/* Measurement aid: enqueue `count` launches of a kernel that does nothing, `blocks` x `threads`, on `hip_stream`.
+ * Timed between two events it gives the launch floor of this box for a grid of the sweep's geometry - what any
+ * one-launch step costs before it computes anything (bench.py: roofline.latency_floor_us). */
+int og_probe_launch(int32_t blocks, int32_t threads, int32_t count, void* hip_stream);
 
 #ifdef __cplusplus
 }

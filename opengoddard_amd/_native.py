@@ -83,6 +83,7 @@ SIGNATURES = {
     "og_trace_read": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64]),
     "og_last_error": (C.c_char_p, []),
     "og_device_count": (C.c_int, []),
+    "og_probe_launch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
 }
 
 

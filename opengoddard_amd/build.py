@@ -115,21 +115,54 @@ def module_path(digest):
     return os.path.join(JITDIR, "libogk_%s.so" % digest)
 
 
-def build_module(header_source, digest=None, force=False):
-    """Compile the sweep kernels against one generated header -> shared object path."""
+# The kernel source instantiates the generated callbacks once per kernel, and code generation for them is what a
+# module's build time consists of (10-15 s at C3, 40 s at C5 as one translation unit).  The kernels are therefore
+# compiled as PARTS side by side (-DOGK_PART=k, csrc/ogk_kernels.hip): part 0 (evaluation, pattern, pack, unpack)
+# is <module>.so, the others <module>.p<k>.so next to it; the runtime loads what is there (ogpsx_core.hip:
+# ogk_module).  Wall-clock of a cold start = the slowest part.
+MODULE_PARTS = (0, 2, 3, 1)     # OGK_PART of <module>.so, .p1.so, .p2.so, .p3.so: main, one-launch sweep, sweep, aux
+
+
+def part_path(out, index):
+    return out if index == 0 else out[:-3] + ".p%d.so" % index
+
+
+def build_module(header_source, digest=None, force=False, out_suffix="", parts=None):
+    """Compile the sweep kernels against one generated header -> path of the module (its part 0; the other
+    parts are built next to it, in parallel).  ``out_suffix``: write the result next to the cached module instead
+    of over it (cold-start measurements: ``force=True``).  ``OG_MODULE_PARTS=1`` builds one translation unit."""
     os.makedirs(JITDIR, exist_ok=True)
     digest = module_digest(header_source)
     out = module_path(digest)
+    if out_suffix:
+        out = out[:-3] + out_suffix + ".so"
     kernels = os.path.join(CSRC, "ogk_kernels.hip")
-    if not force and os.path.exists(out):
+    split = os.environ.get("OG_MODULE_PARTS", "") != "1" if parts is None else bool(parts)
+    wanted = [part_path(out, i) for i in range(len(MODULE_PARTS))] if split else [out]
+    if not force and all(os.path.exists(path) for path in wanted):
         return out
     header = os.path.join(JITDIR, "og_gen_%s.h" % digest)
     with tempfile.NamedTemporaryFile("w", dir=JITDIR, suffix=".h", delete=False) as fh:
         fh.write(header_source)
         tmp_header = fh.name
     os.replace(tmp_header, header)
-    tmp = out + ".tmp%d" % os.getpid()
-    _run([hipcc()] + HIP_FLAGS + ["-I" + CSRC, "-DOG_GEN_HEADER=\"%s\"" % header, kernels,
-                                  "-o", tmp])
-    os.replace(tmp, out)
+
+    def compile_part(index):
+        target = wanted[index]
+        tmp = target + ".tmp%d" % os.getpid()
+        define = ["-DOGK_PART=%d" % MODULE_PARTS[index]] if split else []
+        _run([hipcc()] + HIP_FLAGS + define + ["-I" + CSRC, "-DOG_GEN_HEADER=\"%s\"" % header, kernels, "-o", tmp])
+        os.replace(tmp, target)
+
+    if not split:
+        for stale in (part_path(out, i) for i in range(1, len(MODULE_PARTS))):      # a one-piece module has no parts
+            if os.path.exists(stale):
+                os.remove(stale)
+        compile_part(0)
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(wanted)) as pool:
+        # part 0 last to land: a reader that finds <module>.so finds its parts
+        for _ in pool.map(compile_part, range(len(wanted) - 1, -1, -1)):
+            pass
     return out

@@ -492,9 +492,11 @@ def _group_dependencies(P, grp, roots=None):
 _UN_C = {"neg": "-(%s)", "sqrt": "ogm::sqrt_(%s)", "exp": "ogm::exp_(%s)", "log": "ogm::log_(%s)",
          "sin": "ogm::sin_(%s)", "cos": "ogm::cos_(%s)", "tan": "ogm::tan_(%s)",
          "abs": "ogm::fabs_(%s)", "atan": "ogm::atan_(%s)", "asin": "ogm::asin_(%s)",
-         "acos": "ogm::acos_(%s)"}
+         "acos": "ogm::acos_(%s)", "tanh": "ogm::tanh_(%s)", "sinh": "ogm::sinh_(%s)",
+         "cosh": "ogm::cosh_(%s)", "expm1": "ogm::expm1_(%s)", "log1p": "ogm::log1p_(%s)",
+         "log2": "ogm::log2_(%s)", "log10": "ogm::log10_(%s)", "cbrt": "ogm::cbrt_(%s)"}
 _BIN_C = {"add": "%s + %s", "sub": "%s - %s", "mul": "%s * %s", "div": "%s / %s",
-          "atan2": "ogm::atan2_(%s, %s)"}
+          "atan2": "ogm::atan2_(%s, %s)", "hypot": "ogm::hypot_(%s, %s)", "pow": "ogm::pow_(%s, %s)"}
 _CMP_C = {"lt": "<", "le": "<=", "gt": ">", "ge": ">=", "eq": "==", "ne": "!="}
 
 

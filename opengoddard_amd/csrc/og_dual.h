@@ -93,6 +93,41 @@ OG_HDI ogdual atan2_(const ogdual y, const ogdual x) {
 OG_HDI ogdual atan2_(const ogdual y, const double x) { return atan2_(y, ogdual(x)); }
 OG_HDI ogdual atan2_(const double y, const ogdual x) { return atan2_(ogdual(y), x); }
 
+OG_HDI ogdual tanh_(const ogdual a) {
+    const double t = tanh_(a.v);
+    return ogdual(t, a.d * (1.0 - t * t));
+}
+OG_HDI ogdual sinh_(const ogdual a) { return ogdual(sinh_(a.v), a.d * cosh_(a.v)); }
+OG_HDI ogdual cosh_(const ogdual a) { return ogdual(cosh_(a.v), a.d * sinh_(a.v)); }
+OG_HDI ogdual expm1_(const ogdual a) { return ogdual(expm1_(a.v), a.d * exp_(a.v)); }
+OG_HDI ogdual log1p_(const ogdual a) { return ogdual(log1p_(a.v), a.d == 0.0 ? 0.0 : a.d / (1.0 + a.v)); }
+OG_HDI ogdual log2_(const ogdual a) {
+    return ogdual(log2_(a.v), a.d == 0.0 ? 0.0 : a.d / (a.v * 0.6931471805599453));
+}
+OG_HDI ogdual log10_(const ogdual a) {
+    return ogdual(log10_(a.v), a.d == 0.0 ? 0.0 : a.d / (a.v * 2.302585092994046));
+}
+OG_HDI ogdual cbrt_(const ogdual a) {
+    const double c = cbrt_(a.v);
+    return ogdual(c, (a.d == 0.0 || c == 0.0) ? 0.0 : a.d / (3.0 * c * c));
+}
+OG_HDI ogdual hypot_(const ogdual x, const ogdual y) {
+    const double h = hypot_(x.v, y.v);
+    return ogdual(h, ((x.d == 0.0 && y.d == 0.0) || h == 0.0) ? 0.0 : (x.v * x.d + y.v * y.d) / h);
+}
+OG_HDI ogdual hypot_(const ogdual x, const double y) { return hypot_(x, ogdual(y)); }
+OG_HDI ogdual hypot_(const double x, const ogdual y) { return hypot_(ogdual(x), y); }
+// x ** y: d = x^y (y' log x + y x' / x); a part whose factor does not depend on the seeded variable stays out (0 log 0)
+OG_HDI ogdual pow_(const ogdual x, const ogdual y) {
+    const double p = pow_(x.v, y.v);
+    double d = 0.0;
+    if (x.d != 0.0) d += y.v * pow_(x.v, y.v - 1.0) * x.d;
+    if (y.d != 0.0) d += p * log_(x.v) * y.d;
+    return ogdual(p, d);
+}
+OG_HDI ogdual pow_(const ogdual x, const double y) { return pow_(x, ogdual(y)); }
+OG_HDI ogdual pow_(const double x, const ogdual y) { return pow_(ogdual(x), y); }
+
 // Piecewise-linear table: the derivative is the slope of the segment the value came from (the
 // segment to the right at a knot, like the forward difference sees it), 0 on the constant fills.
 OG_HD ogdual interp_linear(const double* xg, const double* yg, const int n, const int mode, const double fill_below,

@@ -433,6 +433,171 @@ OG_HD double acos_(double x) {
     return 2.0 * (df + w);
 }
 
+// ---------------------------------------------------------------- hyperbolic, other logarithms, roots
+// Built on exp_ / log_ above with the classical correction steps (W. Kahan's expm1 / log1p through the rounded
+// exp / 1 + x, fdlibm's formulae for sinh / cosh / tanh on top of expm1, one Newton step for cbrt): within 2 ulp of
+// NumPy's libm over the whole range (tests/test_og_math.py), and - what matters for parity - the SAME bits on the
+// host twin and on gfx950, since they are made of the same bit-reproducible pieces.
+// sinh(h) / h and cosh(h) by their series in h^2, |h| <= 1 (term 12 is below 1e-23)
+OG_HD double sinhc_series(double h2) {
+    double p = 1.0 + h2 / 600.0;                                // 24 * 25
+    p = 1.0 + h2 / 506.0 * p;                                   // 22 * 23
+    p = 1.0 + h2 / 420.0 * p;
+    p = 1.0 + h2 / 342.0 * p;
+    p = 1.0 + h2 / 272.0 * p;
+    p = 1.0 + h2 / 210.0 * p;
+    p = 1.0 + h2 / 156.0 * p;
+    p = 1.0 + h2 / 110.0 * p;
+    p = 1.0 + h2 / 72.0 * p;
+    p = 1.0 + h2 / 42.0 * p;
+    p = 1.0 + h2 / 20.0 * p;
+    return 1.0 + h2 / 6.0 * p;
+}
+OG_HD double cosh_series(double h2) {
+    double p = 1.0 + h2 / 552.0;                                // 23 * 24
+    p = 1.0 + h2 / 462.0 * p;                                   // 21 * 22
+    p = 1.0 + h2 / 380.0 * p;
+    p = 1.0 + h2 / 306.0 * p;
+    p = 1.0 + h2 / 240.0 * p;
+    p = 1.0 + h2 / 182.0 * p;
+    p = 1.0 + h2 / 132.0 * p;
+    p = 1.0 + h2 / 90.0 * p;
+    p = 1.0 + h2 / 56.0 * p;
+    p = 1.0 + h2 / 30.0 * p;
+    p = 1.0 + h2 / 12.0 * p;
+    return 1.0 + h2 / 2.0 * p;
+}
+OG_HD double expm1_(double x) {
+    if (isnan_(x)) return x;
+    if (x > 709.8) return from_bits(0x7ff0000000000000ULL);
+    if (x < -40.0) return -1.0;
+    if (fabs_(x) < 1.0) {
+        // exp(x) - 1 would cancel: the series itself, x (1 + x/2 (1 + x/3 (1 + ... x/24)))
+        double p = 1.0 + x / 24.0;
+        for (int k = 23; k >= 2; --k) p = 1.0 + x / (double)k * p;
+        return x * p;
+    }
+    return exp_(x) - 1.0;
+}
+OG_HD double log1p_(double x) {
+    if (isnan_(x) || x == from_bits(0x7ff0000000000000ULL)) return x;
+    if (x < -1.0) return from_bits(0x7ff8000000000000ULL);
+    const double u = 1.0 + x;
+    if (u == 1.0) return x;
+    // Kahan: log(u) corrected by the rounding of u = 1 + x
+    return log_(u) * (x / (u - 1.0));
+}
+OG_HD double sinh_(double x) {
+    if (isnan_(x)) return x;
+    const double ax = fabs_(x), sg = x < 0.0 ? -1.0 : 1.0;
+    if (ax < 1.0) return x * sinhc_series(x * x);
+    if (ax < 22.0) {
+        const double e = exp_(ax);
+        return sg * (0.5 * e - 0.5 / e);
+    }
+    if (ax < 709.0) return sg * 0.5 * exp_(ax);
+    const double w = exp_(0.5 * ax);
+    return sg * (0.5 * w) * w;
+}
+OG_HD double cosh_(double x) {
+    if (isnan_(x)) return x;
+    const double ax = fabs_(x);
+    if (ax < 1.0) return cosh_series(x * x);
+    if (ax < 22.0) {
+        const double t = exp_(ax);
+        return 0.5 * t + 0.5 / t;
+    }
+    if (ax < 709.0) return 0.5 * exp_(ax);
+    const double w = exp_(0.5 * ax);
+    return (0.5 * w) * w;
+}
+OG_HD double tanh_(double x) {
+    if (isnan_(x)) return x;
+    const double ax = fabs_(x), sg = x < 0.0 ? -1.0 : 1.0;
+    if (ax >= 22.0) return sg;
+    if (ax < 1.0) {
+        const double x2 = x * x;
+        return x * sinhc_series(x2) / cosh_series(x2);
+    }
+    const double t = exp_(2.0 * ax);
+    return sg * (1.0 - 2.0 / (t + 1.0));
+}
+OG_HD double log2_(double x) {
+    // x = m 2^e with m in [1/sqrt 2, sqrt 2): log2 x = e + log(m) / ln 2 - exact for powers of two, and the quotient's
+    // error is compensated through an FMA
+    if (!(x > 0.0) || x - x != 0.0) return log_(x);            // 0, negative, inf, NaN: log's own answers
+    int e = 0;
+    if (x < 2.2250738585072014e-308) {
+        x *= 18014398509481984.0;                               // 2^54
+        e = -54;
+    }
+    const uint64_t u = bits_of(x);
+    e += (int)((u >> 52) & 0x7ff) - 1023;
+    double m = from_bits((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double l = log_(m);
+    const double inv_hi = 1.4426950408889634, inv_lo = 2.0355273740931033e-17;     // 1 / ln 2 = hi + lo
+    const double q = l * inv_hi;
+    return (double)e + (q + (fma_(l, inv_hi, -q) + l * inv_lo));
+}
+OG_HD double log10_(double x) {
+    const double l = log_(x);
+    if (!(l == l) || l - l != 0.0) return l;
+    const double inv_hi = 0.4342944819032518, inv_lo = 1.098319650216765e-17;       // 1 / ln 10 = hi + lo
+    const double q = l * inv_hi;
+    return q + (fma_(l, inv_hi, -q) + l * inv_lo);
+}
+OG_HD double cbrt_(double x) {
+    if (isnan_(x) || x == 0.0 || x - x != 0.0) return x;       // NaN, +-0, +-inf
+    const double ax = fabs_(x);
+    double t = exp_(log_(ax) * (1.0 / 3.0));
+    // two Newton steps on t^3 = |x| in the form t -= t (t^3 - |x|) / (3 t^3): the first removes exp/log's few ulp,
+    // the second confirms (a fixed point is within half an ulp of the root or next to it)
+    for (int i = 0; i < 2; ++i) {
+        const double t2 = t * t, t3 = t2 * t;
+        const double r = fma_(t2, t, -t3);                       // t^3 = t3 + r
+        t -= t * ((t3 - ax) + r) / (3.0 * t3);
+    }
+    return x < 0.0 ? -t : t;
+}
+OG_HD double hypot_(double x, double y) {
+    double a = fabs_(x), b = fabs_(y);
+    const double inf = from_bits(0x7ff0000000000000ULL);
+    if (a == inf || b == inf) return inf;
+    if (isnan_(a) || isnan_(b)) return a + b;
+    if (a < b) { const double t = a; a = b; b = t; }
+    if (a == 0.0) return 0.0;
+    // scale by a power of two so that neither square over- or underflows, then correct sqrt(a^2 + b^2) by the
+    // rounding errors of the squares (FMA) - within 1 ulp
+    const int e = (int)((bits_of(a) >> 52) & 0x7ff) - 1023;
+    const double sc = scalb_(1.0, -e), as = a * sc, bs = b * sc;
+    const double a2 = as * as, b2 = bs * bs, s2 = a2 + b2;
+    const double err = (fma_(as, as, -a2) + fma_(bs, bs, -b2)) + ((a2 - s2) + b2);
+    const double h = sqrt_(s2);
+    return scalb_(h + err / (2.0 * h), e);
+}
+// x ** y for a traced exponent: exp(y log x) for x > 0 (NumPy calls libm's pow there: this is |y log x| ulp away from
+// it at worst, a few ulp for the exponents models use); pow's special cases for the rest
+OG_HD double pow_(double x, double y) {
+    if (y == 0.0 || x == 1.0) return 1.0;
+    if (isnan_(x) || isnan_(y)) return x + y;
+    if (x > 0.0) return exp_(y * log_(x));
+    const double inf = from_bits(0x7ff0000000000000ULL);
+    const bool yint = (y == (double)(long long)y) && fabs_(y) < 9.0e15;
+    const bool yodd = yint && (((long long)y) & 1LL);
+    if (x == 0.0) {
+        const bool neg = (bits_of(x) >> 63) != 0 && yodd;
+        return y > 0.0 ? (neg ? -0.0 : 0.0) : (neg ? -inf : inf);
+    }
+    if (!yint) return (fabs_(y) == inf) ? ((fabs_(x) < 1.0) == (y < 0.0) ? inf : (fabs_(x) == 1.0 ? 1.0 : 0.0))
+                                        : from_bits(0x7ff8000000000000ULL);
+    const double r = exp_(y * log_(-x));
+    return yodd ? -r : r;
+}
+
 // ---------------------------------------------------------------- linear table lookup
 // scipy.interpolate.interp1d(kind="linear") as the reference's example 11 uses it
 // (examples/11_Polar_TSTO_Taiki.py:21-27; SciPy 1.15.3 scipy/interpolate/_interpolate.py

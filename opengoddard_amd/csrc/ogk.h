@@ -24,6 +24,8 @@ static inline void ogk_frag_pack(int N, const double* D, double* frag) {
             }
 }
 
+#define OGK_OTHER_PART (-4242)   /* ogk_launch: this mode's kernels are in the other part of a two-part module */
+
 typedef struct ogk_info {
     int32_t abi;
     int32_t n, m, m_eq, m_ineq;

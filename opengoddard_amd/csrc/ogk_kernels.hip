@@ -176,6 +176,24 @@ __device__ __forceinline__ int defect_block_to_group(int bx, int* nt_out) {
     return -1;
 }
 
+// The module may be built in two parts (OGK_PART; build.py): part 0 holds what a solve needs from its first sweep
+// on (evaluation, the structured and the one-launch sweep, pattern / pack / unpack), part 1 the validation sweep
+// and the exact-Jacobian kernels, which the runtime loads when they are first asked for.  Each part instantiates
+// the generated callbacks only for its own kernels: the first solve of a new problem shape waits for part 0 only.
+#if !defined(OGK_PART) || OGK_PART == 1
+#define OGK_HAS_AUX 1        // modes 2, 3, 4: validation sweep, exact Jacobian
+#endif
+#if !defined(OGK_PART) || OGK_PART == 0
+#define OGK_HAS_MAIN 1       // modes 0, 6 - 10: evaluation, pattern, pack, unpack
+#endif
+#if !defined(OGK_PART) || OGK_PART == 2
+#define OGK_HAS_FUSED 1      // mode 5: evaluation + structured sweep in one launch
+#endif
+#if !defined(OGK_PART) || OGK_PART == 3
+#define OGK_HAS_SWEEP 1      // mode 1: the structured sweep as a launch of its own
+#endif
+// (the split is at the kernels: a __global__ function is what costs code generation; the device functions below
+// them are templates or forced-inline and cost nothing where no kernel of the part uses them)
 // ------------------------------------------------------------------------------------------
 // Mode 2, dense sweep (validation): collocation workgroup = (phase, 16-node tile, 64 FD
 // columns), all states; row workgroup = one thread per (row item, 8 columns).
@@ -304,6 +322,7 @@ __device__ __forceinline__ void dense_rows_body(const ogk_args& a, const int bx,
     }
 }
 
+#ifdef OGK_HAS_AUX
 __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int ndef,
                                                  const int defect_total, const int row_blocks) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -317,6 +336,7 @@ __global__ __launch_bounds__(256) void ogk_dense(const ogk_args a, const int nde
         dense_rows_body(a, rid % row_blocks, rid / row_blocks);
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Mode 3, exact Jacobian: the generated callback code instantiated on
@@ -341,6 +361,7 @@ __device__ __forceinline__ double dfrag_entry(const ogk_args& a, const int phase
     return a.dfrag[a.dfrag_off[phase] + ((long)(k >> 4) * KS + (l >> 2)) * 64 + (((l & 3) << 4) | (k & 15))];
 }
 
+#ifdef OGK_HAS_AUX
 __global__ __launch_bounds__(256) void ogk_exact(const ogk_args a, const int n_items) {
     const int item = (int)(blockIdx.x * 256 + threadIdx.x);
     const int j = a.col_lo + (int)blockIdx.y;
@@ -399,12 +420,14 @@ __global__ __launch_bounds__(256) void ogk_exact(const ogk_args a, const int n_i
         jrow[OgGen::G_ROW(g, o) + k] = out[o].d;
     }
 }
+#endif
 
 // Mode 4, the same derivatives with the work lists of the structured sweep: a workgroup per column
 // zero-fills its row of J_T, then evaluates only the row items that read x_j (OGT_COL / OGT_ELEM) and,
 // when x_j is a collocated state, that state's defect rows: column l of D times the operand's derivative,
 // minus the dynamics term's derivative on the diagonal.  Same numbers as mode 3 (tests compare both with
 // the CPU twin), a fraction of the evaluations.
+#ifdef OGK_HAS_AUX
 __global__ __launch_bounds__(256) void ogk_exact_struct(const ogk_args a) {
     const int j = a.col_lo + (int)blockIdx.x;
     if (j >= a.col_hi) return;
@@ -447,6 +470,7 @@ __global__ __launch_bounds__(256) void ogk_exact_struct(const ogk_args a) {
         }
     }
 }
+#endif
 
 constexpr int SWEEP_THREADS = 512;   // ogk_sweep / ogk_eval workgroup: 8 wavefronts
 constexpr int SWEEP_WAVES = SWEEP_THREADS / 64;
@@ -589,6 +613,7 @@ __device__ __forceinline__ void eval_rows_body(const ogk_args& a, const int bx, 
     publish_row<FUSED>(a, row, v);
 }
 
+#ifdef OGK_HAS_MAIN
 __global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, const int ndef) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
@@ -601,6 +626,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_eval(const ogk_args a, cons
     if (id < ndef) eval_defect_body<false>(a, id, lds);
     else eval_rows_body<false>(a, id - ndef, lds);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Mode 1: the structured sweep.  At the sizes this engine sees (n ~ 10^2..10^4) a sweep is a
@@ -1495,6 +1521,7 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
 #ifndef OGK_FUSED_ATTR
 #define OGK_FUSED_ATTR
 #endif
+#ifdef OGK_HAS_FUSED
 __global__ __launch_bounds__(SWEEP_THREADS) OGK_FUSED_ATTR void ogk_fused(const ogk_args a, const int ndef, const int n_eval,
                                                            const int group_lo, const int n_light) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1541,7 +1568,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) OGK_FUSED_ATTR void ogk_fused(const 
     else if (kind == 1) { if (!(OGK_FZ & 32)) fz_heavy_part(a, idx, lds); }
     else fz_tile_body(a, idx, lds);
 }
+#endif
 
+#ifdef OGK_HAS_SWEEP
 __global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int id = (int)blockIdx.x;
@@ -1558,6 +1587,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ogk_sweep(const ogk_args a) {
                            reinterpret_cast<unsigned*>(lds));
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Modes 6-9: the packed non-zeros.  One wavefront per column; entry i of column j is row own_lo + i for
@@ -1569,11 +1599,14 @@ __device__ __forceinline__ int pattern_row(const int4 col, const int own, const 
     return i < own ? col.z + i : OGT_ELEM[col.x + (i - own)].w;
 }
 
+#ifdef OGK_HAS_MAIN
 __global__ void ogk_count_launch(const ogk_args a) {
     if (threadIdx.x == 0 && blockIdx.x == 0)
         __hip_atomic_store(a.jt_launches, *a.jt_launches + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#endif
 
+#ifdef OGK_HAS_MAIN
 __global__ __launch_bounds__(PACK_THREADS) void ogk_pattern(const ogk_args a, const int rows_pass) {
     const int j = (int)(blockIdx.x * (PACK_THREADS / 64) + (threadIdx.x >> 6));
     const int lane = (int)threadIdx.x & 63;
@@ -1586,10 +1619,12 @@ __global__ __launch_bounds__(PACK_THREADS) void ogk_pattern(const ogk_args a, co
     }
     for (int i = lane; i < cnt; i += 64) a.pint[a.poff[j] + i] = pattern_row(col, own, i);
 }
+#endif
 
 // Pack / unpack: one workgroup per column, its entries taken from the flat row-index array of the pattern
 // (coalesced; the only dependent access is the J_T entry itself).  A phase's final time has a thousand entries,
 // an ordinary column a few dozen: a workgroup per column keeps the long ones from becoming the kernel's tail.
+#ifdef OGK_HAS_MAIN
 __global__ __launch_bounds__(PACK_THREADS) void ogk_pack(const ogk_args a) {
     const int j = a.col_lo + (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
@@ -1605,7 +1640,9 @@ __global__ __launch_bounds__(PACK_THREADS) void ogk_pack(const ogk_args a) {
     const int32_t* rows = a.prow + base;
     for (int i = tid; i < cnt; i += PACK_THREADS) out[i] = jrow[rows[i]];
 }
+#endif
 
+#ifdef OGK_HAS_MAIN
 __global__ __launch_bounds__(PACK_THREADS) void ogk_unpack(const ogk_args a) {
     // rows [ulo, uhi) of the full matrix except this rank's own block
     int j = a.ulo + (int)blockIdx.x;
@@ -1627,6 +1664,7 @@ __global__ __launch_bounds__(PACK_THREADS) void ogk_unpack(const ogk_args a) {
     const int32_t* rows = a.prow + base;
     for (int i = tid; i < cnt; i += PACK_THREADS) jrow[rows[i]] = in[i];
 }
+#endif
 
 int defect_blocks() {
     int nb = 0;
@@ -1674,10 +1712,16 @@ extern "C" int ogk_get_info(ogk_info* out) {
     return 0;
 }
 
+// A module may be built in parts (OGK_PART, build.py): a part answers OGK_OTHER_PART for a mode whose kernel it
+// does not hold and the runtime turns to the part that does.
 extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int ndef = defect_blocks();
-    const int row_blocks = (OgGen::N_ROW_ITEMS + 255) / 256;
+    const int ncols = args->col_hi - args->col_lo;
+    (void)stream;
+    (void)ndef;
+    (void)ncols;
+#ifdef OGK_HAS_MAIN
     if (mode == 0) {
         const int eval_row_blocks = (OGT_N_ROWWAVES + SWEEP_WAVES - 1) / SWEEP_WAVES;
         if (ndef + eval_row_blocks > 0)
@@ -1685,7 +1729,6 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
                                defect_lds_bytes(), stream, *args, ndef);
         return (int)hipGetLastError();
     }
-    const int ncols = args->col_hi - args->col_lo;
     if (mode == 10) {
         hipLaunchKernelGGL(ogk_count_launch, dim3(1), dim3(64), 0, stream, *args);
         return (int)hipGetLastError();
@@ -1706,14 +1749,19 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
             hipLaunchKernelGGL(ogk_unpack, dim3(others), dim3(PACK_THREADS), 0, stream, *args);
         return (int)hipGetLastError();
     }
-    if (ncols <= 0) return 0;
+#endif
+#ifdef OGK_HAS_SWEEP
     if (mode == 1) {
+        if (ncols <= 0) return 0;
         const int light_blocks = (ncols + LIGHT_COLS - 1) / LIGHT_COLS;
         hipLaunchKernelGGL(ogk_sweep, dim3(OGT_N_TILES + OgGen::N_HEAVY + light_blocks),
                            dim3(SWEEP_THREADS), sweep_lds_bytes(), stream, *args);
         return (int)hipGetLastError();
     }
+#endif
+#ifdef OGK_HAS_FUSED
     if (mode == 5) {
+        if (ncols <= 0) return 0;
         const int eval_row_blocks = (OGT_N_ROWWAVES + SWEEP_WAVES - 1) / SWEEP_WAVES;
         // light workgroups whose columns touch [col_lo, col_hi)
         int glo = 0, ghi = OGT_N_LGRP;
@@ -1729,11 +1777,15 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
                            dim3(SWEEP_THREADS), lds_bytes, stream, *args, ndef, ndef + eval_row_blocks, glo, ghi - glo);
         return (int)hipGetLastError();
     }
+#endif
+#ifdef OGK_HAS_AUX
     if (mode == 4) {
+        if (ncols <= 0) return 0;
         hipLaunchKernelGGL(ogk_exact_struct, dim3(ncols), dim3(256), 0, stream, *args);
         return (int)hipGetLastError();
     }
     if (mode == 3) {
+        if (ncols <= 0) return 0;
         int n_items = OgGen::N_ROW_ITEMS;
         for (int g = 0; g < OgGen::N_GROUPS; ++g)
             if (OgGen::G_KIND(g) == 1) n_items += OgGen::G_LEN(g);
@@ -1741,10 +1793,16 @@ extern "C" int ogk_launch(const ogk_args* args, int mode, void* stream_) {
             hipLaunchKernelGGL(ogk_exact, dim3((n_items + 255) / 256, ncols), dim3(256), 0, stream, *args, n_items);
         return (int)hipGetLastError();
     }
-    const int defect_total = ndef * ((ncols + 63) / 64);
-    const int rows_total = row_blocks * ((ncols + ROWS_COLS_PER_THREAD - 1) / ROWS_COLS_PER_THREAD);
-    if (defect_total + rows_total > 0)
-        hipLaunchKernelGGL(ogk_dense, dim3(defect_total + rows_total), dim3(256),
-                           defect_lds_bytes(), stream, *args, ndef, defect_total, row_blocks);
-    return (int)hipGetLastError();
+    if (mode == 2) {
+        if (ncols <= 0) return 0;
+        const int row_blocks = (OgGen::N_ROW_ITEMS + 255) / 256;
+        const int defect_total = ndef * ((ncols + 63) / 64);
+        const int rows_total = row_blocks * ((ncols + ROWS_COLS_PER_THREAD - 1) / ROWS_COLS_PER_THREAD);
+        if (defect_total + rows_total > 0)
+            hipLaunchKernelGGL(ogk_dense, dim3(defect_total + rows_total), dim3(256),
+                               defect_lds_bytes(), stream, *args, ndef, defect_total, row_blocks);
+        return (int)hipGetLastError();
+    }
+#endif
+    return OGK_OTHER_PART;
 }

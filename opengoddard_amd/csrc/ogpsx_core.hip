@@ -59,13 +59,39 @@ __global__ void lgl_dmat_kernel(int N, const double* tau, const double* pval, do
 typedef int (*ogk_get_info_fn)(ogk_info*);
 typedef int (*ogk_launch_fn)(const ogk_args*, int, void*);
 
+// A callback module is one shared object, or several PARTS of it that were compiled side by side (build.py:
+// <module>.so, <module>.p1.so, ...; each holds some of the kernels and answers OGK_OTHER_PART for the modes of the
+// others).  Calls go to the part that holds the mode; which one that is is remembered per mode.
+struct ogk_module {
+    static constexpr int MAX_PARTS = 4, MAX_MODES = 16;
+    ogk_launch_fn part[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+    void* handle[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+    int n_parts = 0;
+    signed char home[MAX_MODES];
+    ogk_module() {
+        for (int i = 0; i < MAX_MODES; ++i) home[i] = -1;
+    }
+    explicit operator bool() const { return n_parts > 0; }
+    int operator()(const ogk_args* a, int mode, void* stream) {
+        if (mode >= 0 && mode < MAX_MODES && home[mode] >= 0) return part[(int)home[mode]](a, mode, stream);
+        for (int i = 0; i < n_parts; ++i) {
+            const int rc = part[i](a, mode, stream);
+            if (rc != OGK_OTHER_PART) {
+                if (mode >= 0 && mode < MAX_MODES) home[mode] = (signed char)i;
+                return rc;
+            }
+        }
+        return (int)hipErrorInvalidDeviceFunction;         // no part of the module holds this mode
+    }
+};
+
 }  // namespace
 
 struct og_problem_s {
     int device = 0;
     int n = 0, m = 0, m_eq = 0, m_ineq = 0;
     void* module = nullptr;
-    ogk_launch_fn launch = nullptr;
+    ogk_module launch;
     double* d_dfrag = nullptr;
     double* d_cvec = nullptr;
     int64_t dfrag_off[OGK_MAX_PHASE] = {0};
@@ -327,6 +353,9 @@ int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, cons
 
 }  // namespace
 
+// launch-floor probe (og_probe_launch): a kernel that does nothing, in the geometry asked for
+__global__ void og_probe_kernel(int unused) { (void)unused; }
+
 extern "C" {
 
 const char* og_last_error(void) { return g_error.c_str(); }
@@ -335,6 +364,14 @@ int og_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int og_probe_launch(int32_t blocks, int32_t threads, int32_t count, void* hip_stream) {
+    if (blocks < 1 || threads < 1 || threads > 1024 || count < 0) return fail(1, "og_probe_launch: bad geometry");
+    for (int i = 0; i < count; ++i)
+        hipLaunchKernelGGL(og_probe_kernel, dim3((unsigned)blocks), dim3((unsigned)threads), 0, (hipStream_t)hip_stream, 0);
+    OG_HIP(hipGetLastError());
+    return 0;
 }
 
 int og_lgl(int32_t N, double* tau, double* w, double* D) {
@@ -437,7 +474,27 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
     p->m_eq = info.m_eq;
     p->m_ineq = info.m_ineq;
     p->module = mod;
-    p->launch = launch;
+    p->launch.part[0] = launch;
+    p->launch.handle[0] = mod;
+    p->launch.n_parts = 1;
+    {
+        // further parts of the module, if it was built in parts: <path minus ".so">.p<k>.so
+        std::string stem(desc->module_path);
+        if (stem.size() > 3 && stem.compare(stem.size() - 3, 3, ".so") == 0) stem.resize(stem.size() - 3);
+        for (int k = 1; k < ogk_module::MAX_PARTS; ++k) {
+            const std::string path = stem + ".p" + std::to_string(k) + ".so";
+            void* more = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!more) break;
+            ogk_launch_fn fn = (ogk_launch_fn)dlsym(more, "ogk_launch");
+            if (!fn) {
+                dlclose(more);
+                break;
+            }
+            p->launch.part[p->launch.n_parts] = fn;
+            p->launch.handle[p->launch.n_parts] = more;
+            ++p->launch.n_parts;
+        }
+    }
 
     // pack every phase's D into MFMA operand order and upload
     std::vector<double> frag;
@@ -543,6 +600,8 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_shard_off);
     if (p->h_up) hipHostFree(p->h_up);
     if (p->h_down) hipHostFree(p->h_down);
+    for (int k = 1; k < p->launch.n_parts; ++k)
+        if (p->launch.handle[k]) dlclose(p->launch.handle[k]);
     if (p->module) dlclose(p->module);
     delete p;
 }
@@ -984,10 +1043,16 @@ struct og_multi_s {
     int n = 0, m = 0, B = 0;
     int64_t block_vals = 0;
     bool rccl = false;
+    std::vector<int> devs;              // the handle's own copy of the device list ...
+    std::vector<ogn_comm> comms;        // ... and its OWN communicators (ncclCommInitAll at og_multi_create): a later
+                                        // og_comm_init, or a second handle on other devices, cannot pull them away
     std::vector<og_problem_s*> sub;
     std::vector<double*> d_full;        // n x m replica per device (rows of the device's block are registered)
     std::vector<double*> d_send, d_recv;
     std::vector<hipEvent_t> packed;     // peer mode: block g's packed values are ready
+    std::vector<hipEvent_t> fetched;    // peer mode: device g has copied the other blocks of the previous step
+    std::vector<hipEvent_t> uploaded;   // the pinned upload buffer of device g has been read
+    bool stepped = false;
 };
 
 extern "C" {
@@ -1099,8 +1164,12 @@ void og_multi_destroy(og_multi mh) {
         if ((size_t)g < mh->d_send.size()) hipFree(mh->d_send[(size_t)g]);
         if ((size_t)g < mh->d_recv.size()) hipFree(mh->d_recv[(size_t)g]);
         if ((size_t)g < mh->packed.size() && mh->packed[(size_t)g]) hipEventDestroy(mh->packed[(size_t)g]);
+        if ((size_t)g < mh->fetched.size() && mh->fetched[(size_t)g]) hipEventDestroy(mh->fetched[(size_t)g]);
+        if ((size_t)g < mh->uploaded.size() && mh->uploaded[(size_t)g]) hipEventDestroy(mh->uploaded[(size_t)g]);
         og_problem_destroy(mh->sub[(size_t)g]);
     }
+    for (ogn_comm c : mh->comms)
+        if (c && g_comm.api.CommDestroy) g_comm.api.CommDestroy(c);
     delete mh;
 }
 
@@ -1111,15 +1180,29 @@ int og_multi_create(const og_desc* desc, og_multi* out) {
     if (G < 1) return fail(1, "og_multi_create: call og_comm_init first");
     og_multi_s* mh = new og_multi_s();
     mh->G = G;
+    mh->devs = g_comm.devs;
     mh->rccl = !g_comm.comms.empty();
+    if (mh->rccl) {
+        // communicators of this handle's own (the ones og_comm_init made stay with the process-wide state)
+        mh->comms.assign((size_t)G, nullptr);
+        const int rcn = g_comm.api.CommInitAll(mh->comms.data(), G, mh->devs.data());
+        if (rcn != 0) {
+            mh->comms.clear();
+            delete mh;
+            return fail(7, std::string("og_multi_create: ncclCommInitAll: ") +
+                               (g_comm.api.GetErrorString ? g_comm.api.GetErrorString(rcn) : "?"));
+        }
+    }
     mh->sub.assign((size_t)G, nullptr);
+    mh->fetched.assign((size_t)G, nullptr);
+    mh->uploaded.assign((size_t)G, nullptr);
     mh->d_full.assign((size_t)G, nullptr);
     mh->d_send.assign((size_t)G, nullptr);
     mh->d_recv.assign((size_t)G, nullptr);
     mh->packed.assign((size_t)G, nullptr);
     for (int g = 0; g < G; ++g) {
         og_desc d = *desc;
-        d.device = g_comm.devs[(size_t)g];
+        d.device = mh->devs[(size_t)g];
         int rc = og_problem_create(&d, &mh->sub[(size_t)g]);
         if (rc) {
             og_multi_destroy(mh);
@@ -1148,6 +1231,8 @@ int og_multi_create(const og_desc* desc, og_multi* out) {
         if (e == hipSuccess) e = hipMemsetAsync(mh->d_send[(size_t)g], 0, blk, p->stream);
         if (e == hipSuccess) e = hipMalloc(&mh->d_recv[(size_t)g], blk * (size_t)G);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&mh->packed[(size_t)g], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&mh->fetched[(size_t)g], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&mh->uploaded[(size_t)g], hipEventDisableTiming);
         if (e != hipSuccess) {
             og_multi_destroy(mh);
             return fail(100 + (int)e, std::string("og_multi_create: ") + hipGetErrorString(e));
@@ -1175,14 +1260,22 @@ int og_multi_replica_dev(og_multi mh, int32_t g, double** d_JT_full, double** d_
     return 0;
 }
 
-// enqueue one sharded sweep on every device (x and hstep are host vectors); no synchronisation
+// enqueue one sharded sweep on every device (x and hstep are host vectors); no synchronisation of the devices.
+// Safe to call again before the previous step has finished: the pinned upload buffer is reused only after its
+// copy has been read (a host wait on an event that is normally long past), and in peer mode a device overwrites
+// its message only after every other device has fetched the previous one.
 static int multi_enqueue(og_multi_s* mh, const double* x, const double* hstep) {
     const int G = mh->G, n = mh->n, B = mh->B;
     for (int g = 0; g < G; ++g) {
         og_problem_s* p = mh->sub[(size_t)g];
         OG_HIP(hipSetDevice(p->device));
+        if (mh->stepped) OG_HIP(hipEventSynchronize(mh->uploaded[(size_t)g]));
         int rc = upload_point(p, x, hstep);
         if (rc) return rc;
+        OG_HIP(hipEventRecord(mh->uploaded[(size_t)g], p->stream));
+        if (mh->stepped && !mh->rccl && G > 1)
+            for (int r = 0; r < G; ++r)
+                if (r != g) OG_HIP(hipStreamWaitEvent(p->stream, mh->fetched[(size_t)r], 0));
         const int lo = std::min(n, g * B), hi = std::min(n, lo + B);
         double* block = mh->d_full[(size_t)g] + (size_t)lo * (size_t)mh->m;
         if (G > 1 || mh->rccl) {         // (one device with RCCL: the collective still runs - a plumbing check)
@@ -1196,13 +1289,16 @@ static int multi_enqueue(og_multi_s* mh, const double* x, const double* hstep) {
             if (rc) return rc;
         }
     }
-    if (G == 1 && !mh->rccl) return 0;
+    if (G == 1 && !mh->rccl) {
+        mh->stepped = true;
+        return 0;
+    }
     const size_t count = (size_t)mh->block_vals;
     if (mh->rccl) {
         int rc = g_comm.api.GroupStart();
         for (int g = 0; g < G && rc == 0; ++g)
             rc = g_comm.api.AllGather(mh->d_send[(size_t)g], mh->d_recv[(size_t)g], count, OGN_FLOAT64,
-                                      g_comm.comms[(size_t)g], mh->sub[(size_t)g]->stream);
+                                      mh->comms[(size_t)g], mh->sub[(size_t)g]->stream);
         const int rc2 = g_comm.api.GroupEnd();
         if (rc == 0) rc = rc2;
         if (rc != 0)
@@ -1218,8 +1314,10 @@ static int multi_enqueue(og_multi_s* mh, const double* x, const double* hstep) {
                 OG_HIP(hipMemcpyPeerAsync(mh->d_recv[(size_t)g] + (size_t)r * count, p->device, mh->d_send[(size_t)r],
                                           mh->sub[(size_t)r]->device, sizeof(double) * count, p->stream));
             }
+            OG_HIP(hipEventRecord(mh->fetched[(size_t)g], p->stream));
         }
     }
+    mh->stepped = true;
     for (int g = 0; g < G; ++g) {
         og_problem_s* p = mh->sub[(size_t)g];
         OG_HIP(hipSetDevice(p->device));

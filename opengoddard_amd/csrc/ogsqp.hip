@@ -713,6 +713,114 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
     for (int i = tid; i < meq; i += 1024) x[i] = xs[i];
 }
 
+// The same solve spread over the chip: one launch per 64 x 64 diagonal block.  Every workgroup solves the block
+// for itself (64 dependent steps out of LDS: cheap, and it spares a hand-off between workgroups) and then updates
+// its own share of the remaining right-hand side with the block's 64 columns - the part that kept the single
+// workgroup of k_trsv at one CU's bandwidth (282 us for the 3.8 MB of L at C3).  x holds scale * rhs on entry
+// (k_trsv_prepare, which also leaves max |rhs| in scal[0]) and the solution at the end.
+__global__ __launch_bounds__(256) void k_trsv_prepare(const double* __restrict__ rhs, int meq, double scale_rhs,
+                                                      double* __restrict__ x, double* __restrict__ scal) {
+    __shared__ double red[4];
+    double biggest = 0.0;
+    for (int i = threadIdx.x; i < meq; i += 256) {
+        const double v = scale_rhs * rhs[i];
+        x[i] = v;
+        biggest = fmax(biggest, fabs(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) biggest = fmax(biggest, __shfl_xor(biggest, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = biggest;
+    __syncthreads();
+    if (threadIdx.x == 0) scal[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+constexpr int TRSV_ROWS = 64;        // rows of the remaining right-hand side per workgroup
+__global__ __launch_bounds__(256) void k_trsv_block(const double* __restrict__ Tc, int ld,
+                                                    const double* __restrict__ diagL, int meq, int transposed, int b,
+                                                    double* __restrict__ x, double* __restrict__ sol,
+                                                    const double* __restrict__ scal,
+                                                    const double* __restrict__ dthresh, int* __restrict__ flag) {
+    // x: the right-hand side as the blocks before this one left it (read for the block, updated for the rest);
+    // sol: the solution (a separate vector: a workgroup that starts late must still find the block's right-hand side)
+    __shared__ double blk[64 * 65];
+    __shared__ double xb[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = b * 64, bs = min(64, meq - i0);
+    const double tiny = dthresh[0], tol = CONSISTENT * (1.0 + scal[0]);
+    {
+        // (clamped addresses, no predicates: the sixteen loads of a thread go out together)
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int e = tid + 256 * t, r = e >> 6, c = e & 63;
+            v[t] = Tc[(long)(i0 + min(r, bs - 1)) * ld + i0 + c];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int e = tid + 256 * t, r = e >> 6, c = e & 63;
+            blk[r * 65 + c] = (r < bs && c < r) ? v[t] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double xv = lane < bs ? x[i0 + lane] : 0.0;
+        if (!transposed) {
+            for (int c = 0; c < bs; ++c) {
+                const double dc = diagL[i0 + c], num = readlane_f64(xv, c);
+                const bool gone = !(fabs(dc) > tiny);
+                if (gone && fabs(num) > tol && lane == 0 && blockIdx.x == 0) flag[0] = 1;
+                const double xc = gone ? 0.0 : num / dc;
+                if (lane == c)
+                    xv = xc;
+                else if (lane > c)
+                    xv -= blk[lane * 65 + c] * xc;
+            }
+        } else {
+            for (int c = bs - 1; c >= 0; --c) {
+                const double dc = diagL[i0 + c];
+                const double xc = !(fabs(dc) > tiny) ? 0.0 : readlane_f64(xv, c) / dc;
+                if (lane == c)
+                    xv = xc;
+                else if (lane < c)
+                    xv -= blk[c * 65 + lane] * xc;
+            }
+        }
+        xb[lane] = xv;
+    }
+    __syncthreads();
+    if (!transposed) {
+        // rows below the block: a wavefront per row, its 64 entries of the block's columns in one coalesced load
+        const int first = i0 + bs + blockIdx.x * TRSV_ROWS, last = min(first + TRSV_ROWS, meq);
+        const double xl = lane < bs ? xb[lane] : 0.0;
+        for (int r0 = first + wave * 4; r0 < last; r0 += 16) {         // four rows per trip, loads in flight together
+            double v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = Tc[(long)min(r0 + e, meq - 1) * ld + i0 + min(lane, bs - 1)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double acc = wave_sum(v[e] * xl);
+                if (lane == 0 && r0 + e < last) x[r0 + e] -= acc;
+            }
+        }
+    } else {
+        // rows above the block: a thread per row, the block's rows are contiguous in it
+        const int r = blockIdx.x * 256 + tid;
+        if (r < i0) {
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            const double* col = Tc + (long)i0 * ld + r;
+            int c = 0;
+            for (; c + 4 <= bs; c += 4) {
+                acc0 += col[(long)c * ld] * xb[c];
+                acc1 += col[(long)(c + 1) * ld] * xb[c + 1];
+                acc2 += col[(long)(c + 2) * ld] * xb[c + 2];
+                acc3 += col[(long)(c + 3) * ld] * xb[c + 3];
+            }
+            for (; c < bs; ++c) acc0 += col[(long)c * ld] * xb[c];
+            x[r] -= (acc0 + acc1) + (acc2 + acc3);
+        }
+    }
+    if (blockIdx.x == 0 && tid < bs) sol[i0 + tid] = xb[tid];
+}
+
 // ------------------------------------------------------------------------------------------
 // out[k] = base[k] + sum_i M[i*ld + k] * x[i]   (k < ncols, i < nrows): 64 columns per workgroup,
 // 16 wavefronts split the rows, fixed-order combination through LDS.
@@ -1984,6 +2092,7 @@ struct og_qp_s {
     GiPartial *price = nullptr, *ratio = nullptr;
     RowsDecision* rec = nullptr;
     int *d_warm = nullptr, *d_slot = nullptr;
+    double* trsv_work = nullptr;       // right-hand side of a triangular solve while the blocks are eliminated
     double* V16 = nullptr;             // reflector vectors of a 16-wide panel
     Lq16Panel* panel16 = nullptr;
     bool lq16 = true;                  // OGSQP_LQ=8: the sweep of 8-reflector panels only
@@ -2032,6 +2141,11 @@ bool debug_stages() {
         if (rc_) return rc_;  \
     } while (0)
 
+// L x = scale * rhs (or L' x): block by block over the whole chip (k_trsv_block); OGSQP_TRSV=single: the one-workgroup
+// kernel.  `scal` is a device scalar of scratch.
+int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs, const double* rhs, double* x,
+                hipStream_t s);
+
 size_t gi_lds_bytes(int nr, int qcap) {
     return (size_t)(2 * nr + 6 * qcap + 64) * sizeof(double);
 }
@@ -2040,6 +2154,30 @@ size_t rows_lds_bytes(int nr, int qcap) {          // k_rows_decide: the incomin
     return (size_t)(nr + 2 * qcap + 16) * sizeof(double);
 }
 
+}  // namespace
+
+namespace {
+int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs, const double* rhs, double* x,
+                hipStream_t s) {
+    static const bool single = getenv("OGSQP_TRSV") && std::string(getenv("OGSQP_TRSV")) == "single";
+    if (single || meq <= 128) {
+        const size_t trsv_lds = (size_t)(meq + 64 * 65) * sizeof(double);
+        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, ldw, qp->diagL, meq, transposed, scale_rhs,
+                           rhs, x, qp->dthresh, qp->flag);
+        return 0;
+    }
+    hipLaunchKernelGGL(k_trsv_prepare, dim3(1), dim3(256), 0, s, rhs, meq, scale_rhs, qp->trsv_work, qp->dthresh + 2);
+    const int nblk = (meq + 63) / 64;
+    for (int bi = 0; bi < nblk; ++bi) {
+        const int b = transposed ? nblk - 1 - bi : bi;
+        const int i0 = b * 64, bs = std::min(64, meq - i0);
+        const int rest = transposed ? i0 : meq - i0 - bs;
+        const int grid = std::max(1, transposed ? (rest + 255) / 256 : (rest + TRSV_ROWS - 1) / TRSV_ROWS);
+        hipLaunchKernelGGL(k_trsv_block, dim3(grid), dim3(256), 0, s, qp->Tc, ldw, qp->diagL, meq, transposed, b,
+                           qp->trsv_work, x, qp->dthresh + 2, qp->dthresh, qp->flag);
+    }
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -2080,10 +2218,10 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->Z, n1 * ldw); A(&qp->Jw, n1 * ldw); A(&qp->Tc, ((size_t)qp->meq + qc) * ldw); A(&qp->GJ, (size_t)qp->mg * ldw);
     A(&qp->diagL, qp->meq + qc); A(&qp->dots, (size_t)qp->mg + n1); A(&qp->dvec, n1); A(&qp->rvec, qc);
     A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc);
-    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->trsv_work, qp->meq); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
-    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 2); A(&qp->csbuf, 2 * qc);
+    A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 4); A(&qp->csbuf, 2 * qc);
     A(&qp->cpart, 256); A(&qp->bar, 1); A(&qp->abort_flag, 1); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
@@ -2319,11 +2457,8 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     }
     OG_HIP(hipGetLastError());
     // ---- equality-constrained minimiser: L w1 = -c,  deq = J1 w1 - Y (Y'g)
-    const size_t trsv_lds = (size_t)(meq + 64 * 65) * sizeof(double);
     OG_STAGE("trsv w1");
-    if (meq)
-        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, ldw, qp->diagL, meq, 0, -1.0, qp->c,
-                           qp->w1, qp->dthresh, qp->flag);
+    if (meq) launch_trsv(qp, ldw, meq, 0, -1.0, qp->c, qp->w1, s);
     int hflag[2] = {0, 0};
     OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     OG_HIP(hipStreamSynchronize(s));
@@ -2548,8 +2683,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     if (meq) {
         hipLaunchKernelGGL(k_gemv_cols, dim3((meq + 63) / 64), dim3(1024), 0, s, qp->Jw, (long)ldw, nq, meq, qp->tvec,
                            qp->w1, qp->rhs);
-        hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, ldw, qp->diagL, meq, 1, 1.0, qp->rhs,
-                           qp->lam, qp->dthresh, qp->flag);
+        launch_trsv(qp, ldw, meq, 1, 1.0, qp->rhs, qp->lam, s);
     }
     OG_HIP(hipGetLastError());
     OG_HIP(hipMemcpyAsync(d, qp->d, sizeof(double) * nq, hipMemcpyDeviceToHost, s));

@@ -108,22 +108,23 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
             __syncthreads();
             // the vector on my columns, once; products of my two rows with it
             double v[E][4];
-            double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int j = 4 * (64 * e + slot);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[e][i] = vr[j + i];
             }
+            // four partial sums per row: a dependent f64 multiply-add is 13 ns on this part, an independent one 3
+            double pa[4] = {0.0, 0.0, 0.0, 0.0}, pb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int e = 0; e < E; ++e)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc0 = fma(x[0][e][i], v[e][i], acc0);
-                    acc1 = fma(x[1][e][i], v[e][i], acc1);
+                    pa[i] = fma(x[0][e][i], v[e][i], pa[i]);
+                    pb[i] = fma(x[1][e][i], v[e][i], pb[i]);
                 }
-            acc0 = oct_sum(acc0);
-            acc1 = oct_sum(acc1);
+            double acc0 = oct_sum((pa[0] + pa[1]) + (pa[2] + pa[3]));
+            double acc1 = oct_sum((pb[0] + pb[1]) + (pb[2] + pb[3]));
             if ((lane & 7) == 0) {
                 s_part[b & 1][wv][2 * rp] = acc0;
                 s_part[b & 1][wv][2 * rp + 1] = acc1;
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(64 * A16_WAVES) void k_lq_apply16(double* __restric
     }
     const double t0 = panel->T[g][n], t1 = panel->T[4 + g][n], t2 = panel->T[8 + g][n], t3 = panel->T[12 + g][n];
     // W' = V X' (reflector 4 i + g in register i, matrix row n); K slot g of MFMA (u, i) is the column 16 b + 4 g + i
-    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    // (four accumulators: a dependent MFMA is 27 ns, four chains run at the issue rate)
+    d4 accs[4] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int j0 = 16 * (wv + A16_WAVES * u) + 4 * g;
@@ -258,9 +260,12 @@ __global__ __launch_bounds__(64 * A16_WAVES) void k_lq_apply16(double* __restric
         for (int i = 0; i < 4; ++i) {
             const bool in = j0 + i < L;
             x[u][i] = in ? x[u][i] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? a[u][i] : 0.0, x[u][i], acc, 0, 0, 0);
+            accs[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? a[u][i] : 0.0, x[u][i], accs[i], 0, 0, 0);
         }
     }
+    d4 acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (accs[0][i] + accs[1][i]) + (accs[2][i] + accs[3][i]);
     // the operands of the last product (V once more, reflector-major: M row m of block b is the column
     // 16 b + 4 (m & 3) + (m >> 2), so that the result lands in the layout the segment is held in) are requested
     // before the exchange

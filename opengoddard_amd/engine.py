@@ -208,13 +208,16 @@ class HipEngine:
         return self._val
 
     def jacobians(self, p, lb, ub):
-        """((grad, J_eq, J_ineq), h) at ``p``; one sweep serves all three SLSQP requests."""
+        """((grad, J_eq, J_ineq), h) at ``p``; one sweep serves all three SLSQP requests.  ``J_eq`` and ``J_ineq``
+        are VIEWS of the engine's one persistent host matrix: they are valid until the next call with another
+        ``p`` (SciPy's SLSQP copies what it is handed; any other consumer that keeps a result across calls must
+        copy it).  ``grad`` is a copy."""
         key = np.asarray(p, dtype=np.float64).tobytes()
         if key != self._jac_key:
             h = _native.fd_step(p, lb, ub)           # (also in exact mode: quirk Q13 needs the last step)
             F0, JT = self.sweep_persistent(p, h, exact=self.jacobian_mode == "exact")
             J = JT.T                                 # views of the persistent matrix (SciPy copies them)
-            self._jac = ((np.ascontiguousarray(J[0]), J[1:1 + self.m_eq], J[1 + self.m_eq:]), h)
+            self._jac = ((np.array(J[0], dtype=np.float64, copy=True), J[1:1 + self.m_eq], J[1 + self.m_eq:]), h)
             self._jac_key = key
             self._val, self._val_key = self._split(F0), key
             self.n_sweeps += 1

@@ -75,11 +75,12 @@ _UNARY = {
     np.negative: "neg", np.sqrt: "sqrt", np.exp: "exp", np.log: "log", np.sin: "sin",
     np.cos: "cos", np.tan: "tan", np.absolute: "abs", np.fabs: "abs", np.square: "square",
     np.positive: "pos", np.reciprocal: "recip", np.arctan: "atan", np.arcsin: "asin",
-    np.arccos: "acos",
+    np.arccos: "acos", np.tanh: "tanh", np.sinh: "sinh", np.cosh: "cosh", np.expm1: "expm1",
+    np.log1p: "log1p", np.log2: "log2", np.log10: "log10", np.cbrt: "cbrt",
 }
 _BINARY = {
     np.add: "add", np.subtract: "sub", np.multiply: "mul", np.true_divide: "div",
-    np.maximum: "max", np.minimum: "min", np.arctan2: "atan2",
+    np.maximum: "max", np.minimum: "min", np.arctan2: "atan2", np.hypot: "hypot",
 }
 _COMPARE = {
     np.less: "lt", np.less_equal: "le", np.greater: "gt", np.greater_equal: "ge",
@@ -122,10 +123,13 @@ class Sym:
     @property
     def id(self):
         v = self._view_of
-        if v is not None and v[0]._version != self._seen:
+        if v is not None:
             parent, start, ln = v
-            self._id = self.g.add(("slice", parent.id, start, ln), ln)
-            self._seen = parent._version
+            pid = parent.id                      # a parent that is a view itself catches up first (and says so)
+            if parent._version != self._seen:
+                self._id = self.g.add(("slice", pid, start, ln), ln)
+                self._seen = parent._version
+                self._version += 1               # ... so that views of THIS view re-derive as well
         return self._id
 
     @id.setter
@@ -191,6 +195,35 @@ class Sym:
 
     def copy(self):
         return Sym(self.g, self.id)
+
+    # ndarray odds and ends that mean nothing special for a 1-D vector
+    @property
+    def T(self):
+        return self
+
+    def ravel(self, order="C"):
+        return self
+
+    def flatten(self, order="C"):
+        return self.copy()
+
+    def astype(self, dtype, **kw):
+        if np.dtype(dtype) != np.float64:
+            raise TraceError("astype(%s) of a traced value: callbacks are traced in float64" % (dtype,))
+        return self.copy()
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        if tuple(shape) in ((-1,), (self.size,)):
+            return self
+        raise TraceError("reshape%r of a traced vector: only 1-D values are traceable" % (tuple(shape),))
+
+    def __getattr__(self, name):
+        # (only reached for attributes that do not exist) an ndarray method the tracer does not model must be a
+        # tracing error like every other untraceable construct, not an AttributeError from nowhere
+        if name.startswith("__") or name in ("g", "_id", "_version", "_view_of", "_seen"):
+            raise AttributeError(name)
+        raise TraceError("ndarray.%s is not traceable on a decision-variable expression" % name)
 
     # ------------------------------------------------------------------ lifting
     def _lift(self, other):
@@ -318,7 +351,18 @@ class Sym:
                         base = base._binary("mul", base)
                 return acc if e > 0 else acc._unary("recip")
             return self._unary("log")._binary("mul", e)._unary("exp")
-        raise TraceError("x ** y with a traced or array-valued exponent is not traceable")
+        # a traced (or array-valued) exponent: one node, evaluated as exp(y log x) with pow's special cases
+        # (csrc/og_math.h pow_: |y log x| ulp from libm's pow at worst)
+        out = self._binary("pow", e)
+        if out is NotImplemented:
+            raise TraceError("x ** y: unsupported exponent %r" % (type(e),))
+        return out
+
+    def __rpow__(self, base):
+        out = self._binary("pow", base, swap=True)
+        if out is NotImplemented:
+            raise TraceError("x ** y: unsupported base %r" % (type(base),))
+        return out
 
     # ------------------------------------------------------------------ indexing
     def __getitem__(self, key):
@@ -330,12 +374,43 @@ class Sym:
                 raise TraceError("slicing a traced scalar")
             start, stop, step = key.indices(n)
             if step != 1:
-                raise TraceError("only unit-step slices are traceable")
+                # x[::-1], x[::2]: a copy-like gather of single elements (NumPy makes a view; nothing in a callback
+                # writes through a strided view, and the tracer refuses it: the result is not assignable)
+                return take(self, list(range(start, stop, step)))
             ln = max(0, stop - start)
             if start == 0 and ln == n:
                 return Sym(self.g, self.id, view_of=(self, 0, n))
             return Sym(self.g, self.g.add(("slice", self.id, start, ln), ln), view_of=(self, start, ln))
+        if isinstance(key, (list, tuple, np.ndarray)) and not isinstance(key, Sym):
+            idx = np.asarray(key)
+            if idx.ndim == 1 and idx.dtype == np.bool_:
+                if idx.size != n:
+                    raise IndexError("boolean index of length %d on a traced vector of length %d" % (idx.size, n))
+                return take(self, np.nonzero(idx)[0].tolist())
+            if idx.ndim == 1 and np.issubdtype(idx.dtype, np.integer):
+                return take(self, idx.tolist())
         raise TraceError("unsupported index %r on a traced vector" % (key,))
+
+    # ------------------------------------------------------------------ reductions (ndarray methods)
+    def sum(self, axis=None):
+        return pairwise_sum(self)
+
+    def mean(self, axis=None):
+        if self.length is None:
+            return Sym(self.g, self.id)
+        return pairwise_sum(self)._binary("div", float(self.length))
+
+    def dot(self, other):
+        return dot(self, other)
+
+    def min(self, axis=None):
+        return reduce_tree(self, "min")
+
+    def max(self, axis=None):
+        return reduce_tree(self, "max")
+
+    def cumsum(self, axis=None):
+        return cumsum(self)
 
     def __setitem__(self, key, value):
         # in-place boolean-mask assignment: x[mask] = scalar  ->  x = where(mask, scalar, x)
@@ -367,7 +442,11 @@ class Sym:
         if ufunc is np.power:
             if isinstance(inputs[0], Sym):
                 return inputs[0].__pow__(inputs[1])
-            raise TraceError("const ** traced is not traceable")
+            return inputs[1].__rpow__(inputs[0])
+        if ufunc is np.float_power:
+            return np.power(*inputs)
+        if ufunc is np.exp2:
+            return np.power(2.0, inputs[0])
         table = _BINARY if ufunc in _BINARY else _COMPARE if ufunc in _COMPARE else \
             _LOGICAL if ufunc in _LOGICAL else None
         if table is None:
@@ -398,8 +477,27 @@ class Sym:
             x, lo, hi = args[0], args[1], args[2]
             return np.minimum(np.maximum(x, lo), hi)
         if func is np.sum and len(args) == 1 and not kwargs:
-            raise TraceError("np.sum uses pairwise summation, which has no traced twin; use "
-                             "prob.running_cost for integrals")
+            return pairwise_sum(args[0])
+        if func is np.mean and len(args) == 1 and not kwargs:
+            return args[0].mean()
+        if func is np.dot and len(args) == 2 and not kwargs:
+            return dot(args[0], args[1])
+        if func in (np.min, np.amin) and len(args) == 1 and not kwargs:
+            return reduce_tree(args[0], "min")
+        if func in (np.max, np.amax) and len(args) == 1 and not kwargs:
+            return reduce_tree(args[0], "max")
+        if func is np.cumsum and len(args) == 1 and not kwargs:
+            return cumsum(args[0])
+        if func is np.roll and len(args) == 2 and not kwargs:
+            return roll(args[0], args[1])
+        if func is np.flip and len(args) == 1 and not kwargs:
+            return args[0][::-1]
+        if func is np.take and len(args) == 2 and not kwargs:
+            return args[0][np.asarray(args[1])]
+        if func is np.interp and len(args) == 3 and not kwargs:
+            return np_interp(args[0], args[1], args[2])
+        if func is np.diff and len(args) == 1 and not kwargs:
+            return args[0][1:] - args[0][:-1]
         if func in (np.shape,):
             return args[0].shape
         if func in (np.size,):
@@ -470,6 +568,131 @@ def where(cond, a, b):
     length2 = a._bcast_len(b)
     length = length if length2 is None else (length2 if length is None else max(length, length2))
     return Sym(g, g.add(("where", c.id, a.id, b.id), length))
+
+
+def take(vec, indices):
+    """``vec[[i0, i1, ...]]``: the elements one by one, concatenated (a fancy-index result is a copy in NumPy too)."""
+    n = vec.length
+    if n is None:
+        raise TraceError("indexing a scalar")
+    items = [vec[_norm_index(i, n)] for i in indices]
+    if not items:
+        return np.zeros(0)
+    return cat(items)
+
+
+def pairwise_sum(vec):
+    """``np.sum`` / ``ndarray.sum`` of a traced vector with NumPy's own order of additions: ``pairwise_sum`` of
+    numpy/_core/src/umath/loops_utils.h.src - fewer than 8 elements left to right; up to 128 eight running sums
+    over strides of eight, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail left to right; above 128
+    the halves (the first rounded down to a multiple of 8) recursively.  Expanded into additions of single elements:
+    the traced value equals NumPy's bit for bit (tests/test_oracle_and_codegen.py)."""
+    if not isinstance(vec, Sym):
+        return np.sum(vec)
+    n = vec.length
+    if n is None:
+        return Sym(vec.g, vec.id)
+    elems = [vec[i] for i in range(n)]
+
+    def pw(lo, cnt):
+        if cnt < 8:
+            # NumPy starts this loop from -0.0, which changes nothing except the sign of an all-(-0.0) sum
+            acc = elems[lo] if cnt else Sym(vec.g, vec.g.const(0.0))
+            for i in range(1, cnt):
+                acc = acc + elems[lo + i]
+            return acc
+        if cnt <= 128:
+            r = [elems[lo + k] for k in range(8)]
+            i = 8
+            while i < cnt - (cnt % 8):
+                for k in range(8):
+                    r[k] = r[k] + elems[lo + i + k]
+                i += 8
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            while i < cnt:
+                res = res + elems[lo + i]
+                i += 1
+            return res
+        half = cnt // 2
+        half -= half % 8
+        return pw(lo, half) + pw(lo + half, cnt - half)
+
+    if n == 0:
+        return Sym(vec.g, vec.g.const(0.0))
+    return pw(0, n)
+
+
+def dot(a, b):
+    """1-D ``np.dot``: NumPy hands this to BLAS ddot, whose order of additions belongs to the BLAS build (SIMD
+    width, unrolling); traced as ``np.sum(a * b)`` - the same value to a few ulp of the sum of magnitudes, not bit
+    for bit (tests state the bound)."""
+    g = _find_graph([a, b])
+    if g is None:
+        return np.dot(a, b)
+    probe = Sym(g, g.const(0.0))
+    a, b = (probe._lift(v) for v in (a, b))
+    if a is NotImplemented or b is NotImplemented:
+        raise TraceError("np.dot: unsupported operand")
+    prod = a * b
+    return prod if prod.length is None else pairwise_sum(prod)
+
+
+def reduce_tree(vec, op):
+    """``np.min`` / ``np.max``: any order of the comparisons gives the same number (NaN propagates through
+    maximum / minimum either way)."""
+    if not isinstance(vec, Sym):
+        return np.min(vec) if op == "min" else np.max(vec)
+    n = vec.length
+    if n is None:
+        return Sym(vec.g, vec.id)
+    if n == 0:
+        raise ValueError("zero-size array to reduction operation which has no identity")
+    level = [vec[i] for i in range(n)]
+    while len(level) > 1:
+        nxt = [level[i]._binary(op, level[i + 1]) for i in range(0, len(level) - 1, 2)]
+        if len(level) % 2:
+            nxt.append(level[-1])
+        level = nxt
+    return level[0]
+
+
+def cumsum(vec):
+    """``np.cumsum``: running sums left to right (``add.accumulate``)."""
+    if not isinstance(vec, Sym):
+        return np.cumsum(vec)
+    n = vec.length
+    if n is None:
+        return cat([vec])
+    out, acc = [], None
+    for i in range(n):
+        acc = vec[i] if acc is None else acc + vec[i]
+        out.append(acc)
+    return cat(out)
+
+
+def roll(vec, shift):
+    if not isinstance(vec, Sym):
+        return np.roll(vec, shift)
+    n = vec.length
+    if n is None or n == 0:
+        return vec
+    k = int(shift) % n
+    if k == 0:
+        return +vec
+    return cat([vec[n - k:], vec[:n - k]])
+
+
+def np_interp(x, xp, fp):
+    """``np.interp(x, xp, fp)`` with a traced ``x`` and constant tables: piecewise linear, the end values outside
+    ``[xp[0], xp[-1]]`` - the table-lookup node of ``interp1d`` with those fills (same formula
+    ``slope * (x - x_lo) + y_lo``; NumPy's own loop differs from it in the last bit at some points)."""
+    if not isinstance(x, Sym):
+        return np.interp(x, xp, fp)
+    if isinstance(xp, Sym) or isinstance(fp, Sym):
+        raise TraceError("np.interp with traced tables is not traceable")
+    xp = np.asarray(xp, dtype=np.float64)
+    fp = np.asarray(fp, dtype=np.float64)
+    return interp_linear(xp, fp, 0, fp[0], fp[-1], x)
 
 
 def matvec(phase, operand):

@@ -42,6 +42,18 @@ def _atan2(y, x):
     return np.arctan2(ry, rx) + 1j * (rx * np.imag(y) - ry * np.imag(x)) / (rx * rx + ry * ry)
 
 
+def _cbrt(z):                      # np.cbrt has no complex loop: real cube root of the real part, analytic derivative
+    c = np.cbrt(_re(z))
+    with np.errstate(all="ignore"):
+        return c + 1j * np.where(c != 0, np.imag(z) / (3.0 * c * c), 0.0)
+
+
+def _hypot(a, b):
+    h = np.hypot(_re(a), _re(b))
+    with np.errstate(all="ignore"):
+        return h + 1j * np.where(h != 0, (_re(a) * np.imag(a) + _re(b) * np.imag(b)) / h, 0.0)
+
+
 class _ComplexEval(program_eval._Eval):
     def __init__(self, P, x, D):
         super().__init__(P, np.real(x), D)
@@ -61,6 +73,10 @@ class _ComplexEval(program_eval._Eval):
             out = y[node[2] + node[3] * k] if node[3] else y[node[2]]
         elif tag == "un" and node[1] == "abs":
             out = _abs(self.elem(node[2], length, memo))
+        elif tag == "un" and node[1] == "cbrt":
+            out = _cbrt(self.elem(node[2], length, memo))
+        elif tag == "bin" and node[1] == "hypot":
+            out = _hypot(self.elem(node[2], length, memo), self.elem(node[3], length, memo))
         elif tag == "bin" and node[1] in ("max", "min", "atan2"):
             a, b = self.elem(node[2], length, memo), self.elem(node[3], length, memo)
             out = {"max": _max, "min": _min, "atan2": _atan2}[node[1]](a, b)

@@ -167,8 +167,102 @@ def running_cost_shapes():
     return prob, Params()
 
 
+def wide_functions():
+    """Round 3's widened function set inside dynamics and constraints: a tanh throttle, cubic drag through cbrt /
+    hypot, log10 / log2 / log1p / expm1 / sinh / cosh, ``x ** u`` with a traced exponent, ``2 ** x``."""
+    def dynamics(prob, obj, section):
+        h = prob.states(0, section)
+        v = prob.states(1, section)
+        m = prob.states(2, section)
+        u = prob.controls(0, section)
+        w = prob.controls(1, section)
+        throttle = 0.5 * (1.0 + np.tanh(4.0 * (u - 0.5)))
+        speed = np.hypot(v, w)
+        drag = 0.02 * speed ** 2 * np.cbrt(speed) * np.exp2(-h)
+        dx = Dynamics(prob, section)
+        dx[0] = v
+        dx[1] = (2.0 * throttle - drag * v / (speed + 1e-3)) / m - 1.0 / (1.0 + h) ** 2
+        dx[2] = -throttle * (1.0 + 0.1 * np.sinh(w) / np.cosh(w)) - 0.01 * np.expm1(-m)
+        return dx()
+
+    def equality(prob, obj):
+        rows = Condition()
+        rows.equal(prob.states(0, 0)[0], 0.05)
+        rows.equal(prob.states(2, 0)[0], 1.0)
+        rows.equal(np.log10(prob.states(2, 0)[-1] + 1.0) + np.log2(prob.states(2, 0)[-1] + 1.0), 0.9)
+        return rows()
+
+    def inequality(prob, obj):
+        m = prob.states(2, 0)
+        u = prob.controls(0, 0)
+        rows = Condition()
+        rows.lower_bound(m ** (1.0 + 0.5 * u), 0.05)              # traced exponent
+        rows.upper_bound(np.log1p(prob.controls(1, 0) ** 2), 3.0)
+        return rows()
+
+    prob = Problem([0.0, 1.5], [14], [3], [2], 3)
+    rng = np.random.default_rng(21)
+    prob.p[:-1] = rng.uniform(0.2, 1.2, prob.number_of_variables - 1)
+    prob.dynamics = [dynamics]
+    prob.cost = lambda prob, obj: -prob.states(0, 0)[-1]
+    prob.equality = equality
+    prob.inequality = inequality
+    return prob, Params()
+
+
+def wide_reductions():
+    """Round 3's reductions and index forms: ``np.sum`` / ``.sum()`` / ``.mean()`` (NumPy's pairwise order, also
+    above 128 elements), ``np.min`` / ``np.max``, ``np.cumsum``, ``np.roll``, ``x[::-1]``, strided and integer-array
+    indexing, ``np.interp``, ``np.diff``, ``np.clip``."""
+    table_x = np.array([-2.0, -0.5, 0.0, 0.7, 1.5, 3.0])
+    table_y = np.array([0.3, 0.1, 0.0, 0.4, 0.2, 0.9])
+
+    def dynamics(prob, obj, section):
+        x = prob.states(0, section)
+        v = prob.states(1, section)
+        u = prob.controls(0, section)
+        dx = Dynamics(prob, section)
+        dx[0] = v + 0.01 * np.interp(x, table_x, table_y)
+        dx[1] = np.clip(u, -1.0, 1.0) - 0.2 * v - 0.001 * x.mean()      # a term that couples every node
+        return dx()
+
+    def equality(prob, obj):
+        x = prob.states_all_section(0)
+        u = prob.controls_all_section(0)
+        rows = Condition()
+        rows.equal(x[0], 0.1)
+        rows.equal(np.sum(u * u) + u.sum() - np.sum(x[3:9]), 2.0)
+        rows.equal(u.mean(), 0.05)
+        rows.equal(x[::-1][0:3], x[[-1, -2, -3]])                        # identically zero rows
+        return rows()
+
+    def inequality(prob, obj):
+        x = prob.states_all_section(0)
+        v = prob.states_all_section(1)
+        u = prob.controls_all_section(0)
+        rows = Condition()
+        rows.lower_bound(np.min(x), -3.0)
+        rows.upper_bound(np.max(v) + u.max(), 9.0)
+        rows.upper_bound(np.cumsum(np.abs(u[0:12])) * 0.1, 5.0)
+        rows.lower_bound(np.roll(v, 5) - np.roll(v, -3), -4.0)
+        rows.upper_bound(np.diff(x)[::7], 2.5)
+        rows.lower_bound(x[::-1] + x[np.arange(x.size)], -6.0)
+        return rows()
+
+    prob = Problem([0.0, 1.0, 2.0], [90, 45], [2, 2], [1, 1], 3)     # 135 nodes: pairwise sums above one 128-block
+    rng = np.random.default_rng(22)
+    prob.p[:-2] = rng.uniform(-1.0, 1.0, prob.number_of_variables - 2)
+    prob.dynamics = [dynamics, dynamics]
+    prob.knot_states_smooth = [True]
+    prob.cost = lambda prob, obj: prob.time_final(-1) + 0.01 * np.sum(prob.controls_all_section(0) ** 2)
+    prob.equality = equality
+    prob.inequality = inequality
+    return prob, Params()
+
+
 CASES = {"bryson_denham": bryson_denham, "ragged_two_phase": ragged_two_phase,
-         "smooth_knots": smooth_knots, "running_cost_shapes": running_cost_shapes}
+         "smooth_knots": smooth_knots, "running_cost_shapes": running_cost_shapes,
+         "wide_functions": wide_functions, "wide_reductions": wide_reductions}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

@@ -45,6 +45,25 @@ def test_twin_exact_jacobian_matches_complex_step(name):
         assert np.max(np.abs(JE - JC) / scale) <= 1e-13
 
 
+@pytest.mark.parametrize("case", ["wide_functions", "wide_reductions"])
+def test_twin_exact_jacobian_of_the_widened_function_set(case):
+    """Round 3's functions and reductions in exact mode: the derivative rules of og_dual.h (tanh, sinh, cosh, expm1,
+    log1p, log2, log10, cbrt, hypot, x ** y) and the expanded sums against complex-step differentiation."""
+    import test_edge_problems
+    prob, obj = test_edge_problems.CASES[case]()
+    P = codegen.trace_problem(prob, obj)
+    tw = twin.Twin(prob, obj, program=P)
+    lb, ub = np_path.bounds_arrays(prob)
+    cols = np.unique(np.r_[np.arange(0, tw.n, 3), tw.n - 1]).astype(np.int32)
+    x = _points(prob, lb, ub)[1]
+    F0, JE = tw.exact(x, cols)
+    assert np.array_equal(F0, tw.values(x))
+    JC = exact_jac.jacobian(P, prob, x, list(cols))
+    scale = np.maximum(1.0, np.abs(JC).max(axis=0))[None, :]
+    assert np.all(np.isfinite(JE))
+    assert np.max(np.abs(JE - JC) / scale) <= 1e-12
+
+
 @pytest.mark.parametrize("name", SMOOTH)
 def test_exact_jacobian_agrees_with_the_reference_fd_goldens(name, golden, lgl_golden):
     """The reference's own Jacobians (SciPy forward differences through the reference's callbacks,
@@ -129,9 +148,11 @@ def test_with_exact_jacobians_both_sqp_cores_walk_the_same_path(name, maxiter, f
     a, b = out["scipy"], out["hip"]
     assert a.status == b.status == (0 if converges else 9)
     assert np.all(np.isfinite(b.x)) and np.isfinite(b.fun)
-    if update == "single":
+    if update == "single" and not converges:
         assert (a.nit, a.nfev, a.njev) == (b.nit, b.nfev, b.njev)
     elif converges:
+        # (round 2's single-workgroup kernel reproduced SciPy's 203 iterations exactly; since the LQ sweep sums in
+        # 16-reflector panels the paths touch different roundings and an iteration boundary near ftol 1e-10 may move)
         assert abs(a.nit - b.nit) <= 10 and abs(a.nfev - b.nfev) <= 12
     else:
         # 40 iterations from an inconsistent start: the two kernels' roundings separate the paths early;

@@ -22,6 +22,10 @@ void v_atan(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i
 void v_asin(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::asin_(x[i]); }
 void v_acos(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::acos_(x[i]); }
 void v_atan2(const double* yy, const double* xx, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = ogm::atan2_(yy[i], xx[i]); }
+#define V1(f) void v_##f(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = ogm::f##_(x[i]); }
+V1(expm1) V1(log1p) V1(sinh) V1(cosh) V1(tanh) V1(log2) V1(log10) V1(cbrt)
+void v_hypot(const double* a, const double* b, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = ogm::hypot_(a[i], b[i]); }
+void v_pow(const double* a, const double* b, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = ogm::pow_(a[i], b[i]); }
 }
 """
 
@@ -132,3 +136,65 @@ def test_trig_of_absurd_angles_is_nan_not_noise(lib):
     for name, ref in (("v_sin", np.sin), ("v_cos", np.cos)):
         y = call(lib, name, near)
         assert np.all(np.abs(y) <= 1.0) and np.all(ulps(y, ref(near)) <= 1.0)
+
+
+def call2(lib, name, a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    y = np.empty_like(a)
+    dp = C.POINTER(C.c_double)
+    getattr(lib, name)(a.ctypes.data_as(dp), b.ctypes.data_as(dp), y.ctypes.data_as(dp), a.size)
+    return y
+
+
+@pytest.mark.parametrize("name,ref,sample,tol", [
+    ("v_expm1", np.expm1, lambda r: r.uniform(-1, 1, 200000) * 10.0 ** r.integers(-12, 3, 200000), 3.0),
+    ("v_expm1", np.expm1, lambda r: r.uniform(-40, 700, 200000), 3.0),
+    ("v_log1p", np.log1p, lambda r: r.uniform(-1, 1, 200000) * 10.0 ** r.integers(-12, 1, 200000), 2.0),
+    ("v_log1p", np.log1p, lambda r: np.exp(r.uniform(-30, 700, 200000)), 2.0),
+    ("v_sinh", np.sinh, lambda r: r.uniform(-1, 1, 200000) * 10.0 ** r.integers(-10, 3, 200000), 3.0),
+    ("v_cosh", np.cosh, lambda r: r.uniform(-1, 1, 200000) * 10.0 ** r.integers(-10, 3, 200000), 2.0),
+    ("v_tanh", np.tanh, lambda r: r.uniform(-1, 1, 200000) * 10.0 ** r.integers(-10, 2, 200000), 3.0),
+    ("v_log2", np.log2, lambda r: np.exp(r.uniform(-700, 700, 200000)), 1.0),
+    ("v_log10", np.log10, lambda r: np.exp(r.uniform(-700, 700, 200000)), 1.0),
+    ("v_cbrt", np.cbrt, lambda r: r.standard_normal(200000) * 10.0 ** r.integers(-100, 100, 200000), 1.0),
+])
+def test_widened_function_set_within_a_few_ulp_of_numpy(lib, name, ref, sample, tol):
+    """The functions the tracer gained in round 3 (tanh, sinh, cosh, log10, log2, log1p, expm1, cbrt): composed of
+    exp_ / log_ with classical correction steps - 1 ulp for log2 / log10 / cbrt, 2 for cosh / log1p, 3 for the expm1
+    family (one rounded exp, two rounded products); bit-reproducible on the GPU for the same reason exp_ / log_ are."""
+    x = sample(np.random.default_rng(0))
+    with np.errstate(all="ignore"):
+        got, want = call(lib, name, x), ref(x)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    ok = np.isfinite(want) & (want != 0)
+    assert np.max(ulps(got[ok], want[ok])) <= tol
+
+
+def test_hypot_pow_and_special_values_of_the_widened_set(lib):
+    r = np.random.default_rng(2)
+    a = r.standard_normal(300000) * 10.0 ** r.integers(-150, 150, 300000)
+    b = r.standard_normal(300000) * 10.0 ** r.integers(-150, 150, 300000)
+    assert np.max(ulps(call2(lib, "v_hypot", a, b), np.hypot(a, b))) <= 1.0
+    b = a * 10.0 ** r.uniform(-3, 3, a.size)
+    assert np.max(ulps(call2(lib, "v_hypot", a, b), np.hypot(a, b))) <= 1.0
+    # traced exponents: exp(y log x) - |y log x| ulp from libm's pow at worst (documented in og_math.h)
+    x, y = np.exp(r.uniform(-5, 5, 300000)), r.uniform(-4, 4, 300000)
+    assert np.max(ulps(call2(lib, "v_pow", x, y), np.power(x, y)) / np.maximum(1.0, np.abs(y * np.log(x)))) <= 3.0
+    with np.errstate(all="ignore"):
+        xs = np.array([0.0, -0.0, 0.0, -8.0, -8.0, 2.0, -2.0, 1.0, 5.0, np.nan, 0.5])
+        ys = np.array([2.0, 3.0, -1.0, 3.0, 0.5, 0.0, 2.0, np.nan, -np.inf, 0.0, np.inf])
+        got, want = call2(lib, "v_pow", xs, ys), np.power(xs, ys)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
+    assert np.array_equal(call(lib, "v_log2", 2.0 ** np.arange(-1070, 1020)), np.arange(-1070.0, 1020.0))   # exact
+    inf, nan = np.inf, np.nan
+    t = call(lib, "v_tanh", [0.0, -0.0, inf, -inf, nan, 1e-300, 40.0])
+    assert t[0] == 0.0 and np.signbit(t[1]) and t[2] == 1.0 and t[3] == -1.0 and np.isnan(t[4]) and t[5] == 1e-300 and t[6] == 1.0
+    c = call(lib, "v_cbrt", [0.0, -0.0, inf, -inf, -8.0, 27.0, nan])
+    assert c[0] == 0.0 and np.signbit(c[1]) and c[2] == inf and c[3] == -inf and c[4] == -2.0 and c[5] == 3.0 and np.isnan(c[6])
+    l = call(lib, "v_log1p", [-1.0, -2.0, 0.0, inf, 1e-300])
+    assert l[0] == -inf and np.isnan(l[1]) and l[2] == 0.0 and l[3] == inf and l[4] == 1e-300
+    e = call(lib, "v_expm1", [0.0, -inf, inf, 710.0, -800.0])
+    assert e[0] == 0.0 and e[1] == -1.0 and e[2] == inf and e[3] == inf and e[4] == -1.0
+    assert call(lib, "v_cosh", [0.0, 800.0, -800.0]).tolist() == [1.0, inf, inf]
+    assert call(lib, "v_sinh", [800.0, -800.0]).tolist() == [inf, -inf]
+    assert call2(lib, "v_hypot", [inf, nan, 0.0, 3.0], [nan, 1.0, 0.0, 4.0]).tolist()[::3] == [inf, 5.0]

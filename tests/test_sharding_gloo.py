@@ -13,6 +13,8 @@ import pytest
 
 from opengoddard_amd import sharding
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_column_ranges_cover_everything_once():
     for n in (1, 7, 81, 201, 1442, 6148):
@@ -162,3 +164,37 @@ def test_gloo_ranks_reassemble_the_jacobian(name, world, tmp_path):
             assert np.array_equal(np.load(os.path.join(str(tmp_path), "f_rank%d_point%d.npy" % (r, k))), F,
                                   equal_nan=True)
     assert saw_nan
+
+
+def test_bench_launches_its_own_ranks_when_there_is_no_launcher(monkeypatch):
+    """``python bench.py --gpus N`` without WORLD_SIZE in the environment (how the driver starts N = 1, and what a
+    user types for N > 1): bench.py starts N ranks of itself under torch.distributed.run on 127.0.0.1 with its own
+    arguments, and hands the exit code on.  With WORLD_SIZE set (a launcher is there) it does not."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = list(cmd), env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "1"])
+    assert bench.main() == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--standalone" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+    # under a launcher: no second launch (it fails later, for lack of a GPU here, not by launching again)
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert not seen

@@ -89,6 +89,8 @@ SQP_LIB = os.path.join(LIBDIR, "libogsqp.so")
 
 def build_sqp(force=False):
     """``lib/libogsqp.so``: the QP subproblem / BFGS kernels of the SQP driver (``include/ogsqp.h``)."""
+    if os.environ.get("OG_SQP_LIB"):                    # diagnostics: a build with other flags (-DOGSQP_TRACE)
+        return os.environ["OG_SQP_LIB"]
     os.makedirs(LIBDIR, exist_ok=True)
     sources = [os.path.join(CSRC, "ogsqp.hip"), os.path.join(CSRC, "ogsqp_rows.h"), os.path.join(CSRC, "ogsqp_lq16.h"),
                os.path.join(HERE, "..", "include", "ogsqp.h")]

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <iterator>
 #include <cmath>
 #include <cstdio>
@@ -646,10 +647,11 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
         }
         __syncthreads();
         if (wave == 0) {
+            const double dlane = lane < bs ? diagL[i0 + lane] : 1.0;     // the block's diagonal, one entry per lane
             double xv = lane < bs ? xs[i0 + lane] : 0.0;
             if (!transposed) {
                 for (int c = 0; c < bs; ++c) {
-                    const double dc = diagL[i0 + c], num = readlane_f64(xv, c);
+                    const double dc = readlane_f64(dlane, c), num = readlane_f64(xv, c);
                     const bool gone = !(fabs(dc) > tiny);
                     if (gone && fabs(num) > tol && lane == 0) flag[0] = 1;
                     const double xc = gone ? 0.0 : num / dc;
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
                 }
             } else {
                 for (int c = bs - 1; c >= 0; --c) {
-                    const double dc = diagL[i0 + c];
+                    const double dc = readlane_f64(dlane, c);
                     const double xc = !(fabs(dc) > tiny) ? 0.0 : readlane_f64(xv, c) / dc;
                     if (lane == c)
                         xv = xc;
@@ -733,21 +735,83 @@ __global__ __launch_bounds__(256) void k_trsv_prepare(const double* __restrict__
     if (threadIdx.x == 0) scal[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
+// Inverses of the 64 x 64 diagonal blocks of L, once per subproblem (both triangular solves use them): one wavefront
+// per block, lane j builds column j of the inverse by forward substitution out of LDS.  A block with a vanishing
+// pivot (a redundant equality) is marked instead: its step takes the pivot-by-pivot path, which knows what to do
+// with it.
+__global__ __launch_bounds__(64) void k_trsv_invert(const double* __restrict__ Tc, int ld, const double* __restrict__ diagL,
+                                                    int meq, const double* __restrict__ dthresh,
+                                                    double* __restrict__ Linv, int* __restrict__ has_gone) {
+    __shared__ double blk[64 * 65];
+    __shared__ double dinv[64];
+    __shared__ int s_gone;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int i0 = b * 64, bs = min(64, meq - i0);
+    const double tiny = dthresh[0];
+    if (lane == 0) s_gone = 0;
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) blk[r * 65 + lane] = (r < bs && lane < r) ? Tc[(long)(i0 + r) * ld + i0 + lane] : 0.0;
+    {
+        const double d = lane < bs ? diagL[i0 + lane] : 1.0;
+        const bool gone = !(fabs(d) > tiny);
+        if (gone) s_gone = 1;
+        dinv[lane] = gone ? 0.0 : 1.0 / d;
+    }
+    __syncthreads();
+    // column `lane` of the inverse: x_i for i >= lane
+    double* out = Linv + (long)b * 64 * 64;
+    double x[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < i; ++c) {
+            const double l = blk[i * 65 + c];                     // (the same address in every lane: a broadcast)
+            const double xc = c >= lane ? x[c] : 0.0;
+            if (c & 1) acc1 = fma(l, xc, acc1);
+            else acc0 = fma(l, xc, acc0);
+        }
+        x[i] = i < lane ? 0.0 : ((i == lane ? 1.0 : 0.0) - (acc0 + acc1)) * dinv[i];
+        out[(long)i * 64 + lane] = x[i];                          // row-major: Linv[i][lane]
+    }
+    if (lane == 0) has_gone[b] = s_gone;
+}
+
 constexpr int TRSV_ROWS = 64;        // rows of the remaining right-hand side per workgroup
 __global__ __launch_bounds__(256) void k_trsv_block(const double* __restrict__ Tc, int ld,
                                                     const double* __restrict__ diagL, int meq, int transposed, int b,
                                                     double* __restrict__ x, double* __restrict__ sol,
                                                     const double* __restrict__ scal,
-                                                    const double* __restrict__ dthresh, int* __restrict__ flag) {
+                                                    const double* __restrict__ dthresh, int* __restrict__ flag,
+                                                    const double* __restrict__ Linv, const int* __restrict__ has_gone) {
     // x: the right-hand side as the blocks before this one left it (read for the block, updated for the rest);
     // sol: the solution (a separate vector: a workgroup that starts late must still find the block's right-hand side)
     __shared__ double blk[64 * 65];
     __shared__ double xb[64];
+    __shared__ double part[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = b * 64, bs = min(64, meq - i0);
     const double tiny = dthresh[0], tol = CONSISTENT * (1.0 + scal[0]);
-    {
-        // (clamped addresses, no predicates: the sixteen loads of a thread go out together)
+    if (!has_gone[b]) {
+        // the block's inverse is there (k_trsv_invert): x_b = inv(L_bb) rhs_b, or its transpose, as a 64 x 64 product -
+        // every thread a quarter of a row, no dependent chain
+        const double* inv = Linv + (long)b * 64 * 64;
+        const int row = lane, q = wave;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            const int c0 = 16 * q + c;
+            const double a0 = transposed ? inv[(long)c0 * 64 + row] : inv[(long)row * 64 + c0];
+            const double a1 = transposed ? inv[(long)(c0 + 1) * 64 + row] : inv[(long)row * 64 + c0 + 1];
+            acc0 = fma(a0, c0 < bs ? x[i0 + c0] : 0.0, acc0);
+            acc1 = fma(a1, c0 + 1 < bs ? x[i0 + c0 + 1] : 0.0, acc1);
+        }
+        part[q][row] = acc0 + acc1;
+        __syncthreads();
+        if (wave == 0) xb[lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    } else {
+        // pivot by pivot (a vanishing pivot: the equality is a combination of earlier ones - dropped if its residual
+        // vanishes too, "singular matrix C" (flag 0) if it does not)
         double v[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -759,32 +823,33 @@ __global__ __launch_bounds__(256) void k_trsv_block(const double* __restrict__ T
             const int e = tid + 256 * t, r = e >> 6, c = e & 63;
             blk[r * 65 + c] = (r < bs && c < r) ? v[t] : 0.0;
         }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        double xv = lane < bs ? x[i0 + lane] : 0.0;
-        if (!transposed) {
-            for (int c = 0; c < bs; ++c) {
-                const double dc = diagL[i0 + c], num = readlane_f64(xv, c);
-                const bool gone = !(fabs(dc) > tiny);
-                if (gone && fabs(num) > tol && lane == 0 && blockIdx.x == 0) flag[0] = 1;
-                const double xc = gone ? 0.0 : num / dc;
-                if (lane == c)
-                    xv = xc;
-                else if (lane > c)
-                    xv -= blk[lane * 65 + c] * xc;
+        __syncthreads();
+        if (wave == 0) {
+            const double dlane = lane < bs ? diagL[i0 + lane] : 1.0;     // the block's diagonal, one entry per lane
+            double xv = lane < bs ? x[i0 + lane] : 0.0;
+            if (!transposed) {
+                for (int c = 0; c < bs; ++c) {
+                    const double dc = readlane_f64(dlane, c), num = readlane_f64(xv, c);
+                    const bool gone = !(fabs(dc) > tiny);
+                    if (gone && fabs(num) > tol && lane == 0 && blockIdx.x == 0) flag[0] = 1;
+                    const double xc = gone ? 0.0 : num / dc;
+                    if (lane == c)
+                        xv = xc;
+                    else if (lane > c)
+                        xv -= blk[lane * 65 + c] * xc;
+                }
+            } else {
+                for (int c = bs - 1; c >= 0; --c) {
+                    const double dc = readlane_f64(dlane, c);
+                    const double xc = !(fabs(dc) > tiny) ? 0.0 : readlane_f64(xv, c) / dc;
+                    if (lane == c)
+                        xv = xc;
+                    else if (lane < c)
+                        xv -= blk[c * 65 + lane] * xc;
+                }
             }
-        } else {
-            for (int c = bs - 1; c >= 0; --c) {
-                const double dc = diagL[i0 + c];
-                const double xc = !(fabs(dc) > tiny) ? 0.0 : readlane_f64(xv, c) / dc;
-                if (lane == c)
-                    xv = xc;
-                else if (lane < c)
-                    xv -= blk[c * 65 + lane] * xc;
-            }
+            xb[lane] = xv;
         }
-        xb[lane] = xv;
     }
     __syncthreads();
     if (!transposed) {
@@ -2093,6 +2158,8 @@ struct og_qp_s {
     RowsDecision* rec = nullptr;
     int *d_warm = nullptr, *d_slot = nullptr;
     double* trsv_work = nullptr;       // right-hand side of a triangular solve while the blocks are eliminated
+    double* Linv = nullptr;            // inverses of the 64 x 64 diagonal blocks of L
+    int* has_gone = nullptr;           // ... per block: it holds a vanishing pivot (no inverse)
     double* V16 = nullptr;             // reflector vectors of a 16-wide panel
     Lq16Panel* panel16 = nullptr;
     bool lq16 = true;                  // OGSQP_LQ=8: the sweep of 8-reflector panels only
@@ -2166,6 +2233,9 @@ int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs,
                            rhs, x, qp->dthresh, qp->flag);
         return 0;
     }
+    if (!transposed)       // (the forward solve comes first in a subproblem: the inverses serve the transposed one too)
+        hipLaunchKernelGGL(k_trsv_invert, dim3((meq + 63) / 64), dim3(64), 0, s, qp->Tc, ldw, qp->diagL, meq, qp->dthresh,
+                           qp->Linv, qp->has_gone);
     hipLaunchKernelGGL(k_trsv_prepare, dim3(1), dim3(256), 0, s, rhs, meq, scale_rhs, qp->trsv_work, qp->dthresh + 2);
     const int nblk = (meq + 63) / 64;
     for (int bi = 0; bi < nblk; ++bi) {
@@ -2174,7 +2244,8 @@ int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs,
         const int rest = transposed ? i0 : meq - i0 - bs;
         const int grid = std::max(1, transposed ? (rest + 255) / 256 : (rest + TRSV_ROWS - 1) / TRSV_ROWS);
         hipLaunchKernelGGL(k_trsv_block, dim3(grid), dim3(256), 0, s, qp->Tc, ldw, qp->diagL, meq, transposed, b,
-                           qp->trsv_work, x, qp->dthresh + 2, qp->dthresh, qp->flag);
+                           qp->trsv_work, x, qp->dthresh + 2, qp->dthresh, qp->flag, (const double*)qp->Linv,
+                           (const int*)qp->has_gone);
     }
     return 0;
 }
@@ -2218,7 +2289,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->Z, n1 * ldw); A(&qp->Jw, n1 * ldw); A(&qp->Tc, ((size_t)qp->meq + qc) * ldw); A(&qp->GJ, (size_t)qp->mg * ldw);
     A(&qp->diagL, qp->meq + qc); A(&qp->dots, (size_t)qp->mg + n1); A(&qp->dvec, n1); A(&qp->rvec, qc);
     A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc);
-    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->trsv_work, qp->meq); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->trsv_work, qp->meq); A(&qp->Linv, ((size_t)qp->meq + 63) / 64 * 4096); A(&qp->has_gone, ((size_t)qp->meq + 63) / 64); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
     A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 4); A(&qp->csbuf, 2 * qc);
@@ -2396,6 +2467,15 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
                 else if (eg <= 6) OG_PANEL16(6);
                 else OG_PANEL16(8);
 #undef OG_PANEL16
+#ifdef OGSQP_TRACE
+                if (k == 0 || k == 512) {
+                    Lq16Panel hp;
+                    OG_HIP(hipMemcpyAsync(&hp, qp->panel16, sizeof(Lq16Panel), hipMemcpyDeviceToHost, s));
+                    OG_HIP(hipStreamSynchronize(s));
+                    fprintf(stderr, "[ogsqp trace] panel16 at k = %d (len %d) ticks: load %lld publish %lld barrier1 %lld products %lld barrier2 %lld update %lld store %lld\n",
+                            k, len16, hp.tr[0], hp.tr[1], hp.tr[2], hp.tr[3], hp.tr[4], hp.tr[5], hp.tr[6]);
+                }
+#endif
 #define OG_APPLY16(U)                                                                                            \
     hipLaunchKernelGGL(k_lq_apply16<U>, dim3((nrows16 + 15) / 16), dim3(64 * A16_WAVES), 0, s, qp->Tc, qp->Jw, ldw, msweep, \
                        nq, k, (const double*)qp->V16, ldw, (const Lq16Panel*)qp->panel16)
@@ -2533,16 +2613,36 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         int batch = debug_stages() ? 1 : 8;
         long launched = 0;
         OG_STAGE("rows changes");
+        static const bool timing = getenv("OGSQP_TIMING") != nullptr;
+        double t_front = 0.0, t_enqueue = 0.0, t_wait = 0.0;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        if (timing) {
+            const double t0 = now();
+            OG_HIP(hipStreamSynchronize(s));
+            t_front = now() - t0;
+        }
         while (true) {
+            const double te = timing ? now() : 0.0;
             for (int it = 0; it < batch; ++it) {
                 hipLaunchKernelGGL(k_rows_decide, dim3(ra.G1), dim3(ROWS_THREADS), lds1, s, ra);
                 OG_ROWS_APPLY();
             }
             launched += batch;
             OG_HIP(hipGetLastError());
+            const double tw = timing ? now() : 0.0;
             OG_HIP(hipMemcpyAsync(&hst, qp->st, sizeof(GiState), hipMemcpyDeviceToHost, s));
             OG_HIP(hipStreamSynchronize(s));
-            if (hst.phase >= 2) break;
+            if (timing) {
+                t_enqueue += tw - te;
+                t_wait += now() - tw;
+            }
+            if (hst.phase >= 2) {
+                if (timing)
+                    fprintf(stderr, "[ogsqp timing] front end drained in %.3f ms; active set: %d changes, %ld pairs launched, "
+                                    "enqueue %.3f ms, wait %.3f ms\n", 1e3 * t_front, hst.iters, launched, 1e3 * t_enqueue,
+                            1e3 * t_wait);
+                break;
+            }
             // every pair of launches is one change (or the end of the warm start): the device's own limit ends the loop
             if (launched > (long)ga.limit + nwarm + 64)
                 return fail(8, "og_qp_solve_dev: the active-set kernels made no progress (internal error)");

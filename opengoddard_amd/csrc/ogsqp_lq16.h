@@ -33,6 +33,7 @@ struct Lq16Panel {
     double T[LQ16][LQ16];
     int nb;
     int pad;
+    long long tr[8];     // -DOGSQP_TRACE: s_memtime ticks per section of the last panel kernel (wavefront 0)
 };
 
 // sum over the eight lanes that share a pair of rows in one wavefront, in every one of them
@@ -62,6 +63,13 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
     const int rp = lane >> 3, slot = wv * 8 + (lane & 7);
     const int nb = min(LQ16, mrows - k), L = nq - k;
     const int W = 256 * E;
+#ifdef OGSQP_TRACE
+    long long t_mark = __builtin_amdgcn_s_memtime();
+    long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define P16MARK(slot_) do { const long long now_ = __builtin_amdgcn_s_memtime(); t_sec[slot_] += now_ - t_mark; t_mark = now_; } while (0)
+#else
+#define P16MARK(slot_) do { } while (0)
+#endif
     double x[2][E][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
         (&s_lower[0][0])[e] = 0.0;
     }
     double dmax = dmaxbuf[0];
+    P16MARK(0);   // load
 #pragma unroll
     for (int b = 0; b < LQ16; ++b) {
         if (b < nb) {                                // (uniform)
@@ -89,30 +98,36 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
             // row b's lanes publish it: entries left of the pivot are finished entries of L (kept aside, zero in
             // the vector); every row publishes its entry in the pivot column b = slot b / 4, register b % 4
             if (rp == (b >> 1)) {
+                // (only the first group of four columns can lie left of the pivot: b < 16)
 #pragma unroll
-                for (int e = 0; e < E; ++e)
+                for (int i = 0; i < 4; ++i) {
+                    const int j = 4 * slot + i;
+                    const bool left = j < b;
+                    if (left) s_lower[b][j] = x[b & 1][0][i];
+                    x[b & 1][0][i] = left ? 0.0 : x[b & 1][0][i];
+                }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int j = 4 * (64 * e + slot) + i;
-                        if (j < b) {
-                            s_lower[b][j] = x[b & 1][e][i];
-                            x[b & 1][e][i] = 0.0;
-                        }
-                        vr[j] = x[b & 1][e][i];
-                    }
+                for (int e = 0; e < E; ++e) {
+                    dbl4 q;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[i] = x[b & 1][e][i];
+                    *(dbl4*)(vr + 4 * (64 * e + slot)) = q;
+                }
             }
             if (slot == (b >> 2)) {
                 s_xpc[b & 1][2 * rp] = x[0][0][b & 3];
                 s_xpc[b & 1][2 * rp + 1] = x[1][0][b & 3];
             }
+            P16MARK(1);   // publish
             __syncthreads();
+            P16MARK(2);   // barrier 1
             // the vector on my columns, once; products of my two rows with it
             double v[E][4];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int j = 4 * (64 * e + slot);
+                const dbl4 q = *(const dbl4*)(vr + 4 * (64 * e + slot));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[e][i] = vr[j + i];
+                for (int i = 0; i < 4; ++i) v[e][i] = q[i];
             }
             // four partial sums per row: a dependent f64 multiply-add is 13 ns on this part, an independent one 3
             double pa[4] = {0.0, 0.0, 0.0, 0.0}, pb[4] = {0.0, 0.0, 0.0, 0.0};
@@ -129,7 +144,9 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
                 s_part[b & 1][wv][2 * rp] = acc0;
                 s_part[b & 1][wv][2 * rp + 1] = acc1;
             }
+            P16MARK(3);   // read vector, products, 8-lane sums
             __syncthreads();
+            P16MARK(4);   // barrier 2
             double Db = 0.0, D0 = 0.0, D1 = 0.0;
 #pragma unroll
             for (int w8 = 0; w8 < P16_WAVES; ++w8) {
@@ -172,6 +189,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
                 x[1][0][b & 3] = fma(f1, alpha, x[1][0][b & 3]);
                 if (rp == (b >> 1)) x[b & 1][0][b & 3] = v0;     // row b becomes its reflector vector
             }
+            P16MARK(5);   // scalars + update
         }
     }
     // V (zero rows beyond nb), the finished entries of L, the diagonal
@@ -195,15 +213,26 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
         }
     }
     __syncthreads();
-    // T by forward accumulation; row a of T depends only on itself: thread a does row a
-    if (tid < nb) {
+    // T by forward accumulation; row a of T depends only on itself: thread a does row a, the row in registers and
+    // the loops unrolled (entries left of the diagonal are zero, so no bound on c is needed): the LDS reads of
+    // V V' have static addresses and go out ahead of the dependent multiply-adds
+    if (tid < LQ16) {
         const int a = tid;
-        s_T[a][a] = s_beta[a];
-        for (int b = a + 1; b < nb; ++b) {
-            double acc = 0.0;
-            for (int c = a; c < b; ++c) acc += s_T[a][c] * s_S[c][b];
-            s_T[a][b] = -s_beta[b] * acc;
+        double Tr[LQ16];
+#pragma unroll
+        for (int c = 0; c < LQ16; ++c) Tr[c] = (c == a && a < nb) ? s_beta[a] : 0.0;
+#pragma unroll
+        for (int b = 1; b < LQ16; ++b) {
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < b; ++c) {
+                if (c & 1) acc1 = fma(Tr[c], s_S[c][b], acc1);
+                else acc0 = fma(Tr[c], s_S[c][b], acc0);
+            }
+            if (b > a && b < nb) Tr[b] = -s_beta[b] * (acc0 + acc1);
         }
+#pragma unroll
+        for (int c = 0; c < LQ16; ++c) s_T[a][c] = Tr[c];
     }
     __syncthreads();
     for (int e = tid; e < LQ16 * LQ16; e += P16_THREADS) {
@@ -217,6 +246,12 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
         panel->pad = 0;
         dmaxbuf[0] = dmax;
     }
+    P16MARK(6);   // store V, T
+#ifdef OGSQP_TRACE
+    if (tid == 0)
+        for (int e = 0; e < 8; ++e) panel->tr[e] = t_sec[e];
+#endif
+#undef P16MARK
 }
 
 // U: blocks of 16 columns per wavefront (rows of up to 128 U entries from the panel's first column on); eight

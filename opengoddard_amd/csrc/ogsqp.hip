@@ -145,30 +145,87 @@ __device__ __forceinline__ void block_argmin(double& v, int& idx, double* redv, 
 // out[j][k] = sum_i A(i, col0 + j) * Jw[i][k]     (rows x nq, row-major, leading dimension ldw)
 // 64 x 64 output tile per workgroup, 4 wavefronts of 2 x 2 MFMA 16x16x4 tiles, K staged through
 // LDS 16 rows at a time.  Both operands are read along their contiguous direction.
+// The Jacobian of a collocation NLP is mostly zeros (7-25 % of the equality block, around 1 % of the path
+// constraints: D blocks, node-diagonal blocks, a few dense columns), and the sweep kernel leaves exact zeros there.
+// k_gemm_map marks, per block of 64 constraints, the slabs of 16 variables that hold anything at all; k_gemm_tn then
+// walks the marked slabs only - at C3 about one in seven.
+__global__ __launch_bounds__(256) void k_gemm_map(AView A, int col0, int rows, int nq, const int* __restrict__ sel,
+                                                  unsigned char* __restrict__ map, int kblocks) {
+    const int kb = blockIdx.x, mb = blockIdx.y;
+    const int tid = threadIdx.x, ii = tid >> 4, jb = (tid & 15) * 4;
+    const int i = kb * 16 + ii;
+    int nz = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = mb * 64 + jb + e;
+        if (i < nq && j < rows) nz |= aval(A, i, col0 + (sel ? sel[j] : j)) != 0.0;
+    }
+    nz = __syncthreads_or(nz);
+    if (tid == 0) map[(long)mb * kblocks + kb] = nz ? 1 : 0;
+}
+
+// out[j][k] = sum_i A(i, col0 + j) * Jw[i][k]     (rows x nq, row-major, leading dimension ldw)
+// 64 x 64 output tile per workgroup, 4 wavefronts of 2 x 2 MFMA 16x16x4 tiles, K staged through LDS 16 rows at a
+// time - the slabs k_gemm_map marked, the next one's operands requested while the current one is multiplied.  Both
+// operands are read along their contiguous direction.
 // sel (optional): output row j takes the column col0 + sel[j] of A instead of col0 + j (rows of a warm start).
 __global__ __launch_bounds__(256) void k_gemm_tn(AView A, int col0, int rows, const double* __restrict__ Jw,
                                                  int ldw, int nq, double* __restrict__ out,
-                                                 const int* __restrict__ sel) {
+                                                 const int* __restrict__ sel, const unsigned char* __restrict__ map,
+                                                 int kblocks) {
     __shared__ double As[16][80];
     __shared__ double Bs[16][80];
+    __shared__ short s_list[512];
+    __shared__ int s_count;
     const int j0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wj = (wave >> 1) * 32, wk = (wave & 1) * 32;
     const int ii = tid >> 4, jb = (tid & 15) * 4;
+    // the marked slabs of my block of constraints, in order (one wavefront compacts the map)
+    if (wave == 0) {
+        int count = 0;
+        const unsigned char* mine = map + (long)blockIdx.y * kblocks;
+        for (int base = 0; base < kblocks; base += 64) {
+            const int kb = base + lane;
+            const bool on = kb < kblocks && mine[kb];
+            const unsigned long long bal = __ballot(on);
+            if (on) s_list[count + __popcll(bal & ((1ull << lane) - 1ull))] = (short)kb;
+            count += __popcll(bal);
+        }
+        if (lane == 0) s_count = count;
+    }
+    __syncthreads();
+    const int count = s_count;
     d4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int i0 = 0; i0 < nq; i0 += 16) {
-        const int i = i0 + ii;
+    int jcol[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + jb + e;
+        jcol[e] = j < rows ? col0 + (sel ? sel[j] : j) : -1;
+    }
+    double ra[4], rb[4];
+    auto fetch = [&](int slab) {
+        const int i = (int)s_list[slab] * 16 + ii;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int j = j0 + jb + e, k = k0 + jb + e;
-            As[ii][jb + e] = (i < nq && j < rows) ? aval(A, i, col0 + (sel ? sel[j] : j)) : 0.0;
-            Bs[ii][jb + e] = (i < nq && k < nq) ? Jw[(long)i * ldw + k] : 0.0;
+            const int k = k0 + jb + e;
+            ra[e] = (i < nq && jcol[e] >= 0) ? aval(A, i, jcol[e]) : 0.0;
+            rb[e] = (i < nq && k < nq) ? Jw[(long)i * ldw + k] : 0.0;
+        }
+    };
+    if (count > 0) fetch(0);
+    for (int slab = 0; slab < count; ++slab) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            As[ii][jb + e] = ra[e];
+            Bs[ii][jb + e] = rb[e];
         }
         __syncthreads();
+        if (slab + 1 < count) fetch(slab + 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int kr = kk * 4 + (lane >> 4);
@@ -2157,6 +2214,7 @@ struct og_qp_s {
     GiPartial *price = nullptr, *ratio = nullptr;
     RowsDecision* rec = nullptr;
     int *d_warm = nullptr, *d_slot = nullptr;
+    unsigned char* gemm_map = nullptr; // per block of 64 constraints: which slabs of 16 variables hold a non-zero
     double* trsv_work = nullptr;       // right-hand side of a triangular solve while the blocks are eliminated
     double* Linv = nullptr;            // inverses of the 64 x 64 diagonal blocks of L
     int* has_gone = nullptr;           // ... per block: it holds a vanishing pivot (no inverse)
@@ -2212,6 +2270,8 @@ bool debug_stages() {
 // kernel.  `scal` is a device scalar of scratch.
 int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs, const double* rhs, double* x,
                 hipStream_t s);
+int launch_gemm(og_qp_s* qp, const AView& A, int col0, int rows, int nq, int ldw, double* out, const int* sel,
+                hipStream_t s);
 
 size_t gi_lds_bytes(int nr, int qcap) {
     return (size_t)(2 * nr + 6 * qcap + 64) * sizeof(double);
@@ -2224,6 +2284,17 @@ size_t rows_lds_bytes(int nr, int qcap) {          // k_rows_decide: the incomin
 }  // namespace
 
 namespace {
+// out = (the `rows` columns of A from col0 on, or the ones sel names)' Jw: the map of non-empty slabs, then the product
+int launch_gemm(og_qp_s* qp, const AView& A, int col0, int rows, int nq, int ldw, double* out, const int* sel,
+                hipStream_t s) {
+    const int kblocks = (nq + 15) / 16, mblocks = (rows + 63) / 64;
+    if (kblocks > 512) return fail(4, "og_qp_solve_dev: more than 8192 variables");
+    hipLaunchKernelGGL(k_gemm_map, dim3(kblocks, mblocks), dim3(256), 0, s, A, col0, rows, nq, sel, qp->gemm_map, kblocks);
+    hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, mblocks), dim3(256), 0, s, A, col0, rows, qp->Jw, ldw, nq, out, sel,
+                       (const unsigned char*)qp->gemm_map, kblocks);
+    return 0;
+}
+
 int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs, const double* rhs, double* x,
                 hipStream_t s) {
     static const bool single = getenv("OGSQP_TRSV") && std::string(getenv("OGSQP_TRSV")) == "single";
@@ -2289,7 +2360,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->Z, n1 * ldw); A(&qp->Jw, n1 * ldw); A(&qp->Tc, ((size_t)qp->meq + qc) * ldw); A(&qp->GJ, (size_t)qp->mg * ldw);
     A(&qp->diagL, qp->meq + qc); A(&qp->dots, (size_t)qp->mg + n1); A(&qp->dvec, n1); A(&qp->rvec, qc);
     A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc);
-    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->trsv_work, qp->meq); A(&qp->Linv, ((size_t)qp->meq + 63) / 64 * 4096); A(&qp->has_gone, ((size_t)qp->meq + 63) / 64); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->trsv_work, qp->meq); A(&qp->gemm_map, ((size_t)std::max(qp->meq, qp->mg) + 63 + qc) / 64 * ((n1 + 15) / 16) + 64); A(&qp->Linv, ((size_t)qp->meq + 63) / 64 * 4096); A(&qp->has_gone, ((size_t)qp->meq + 63) / 64); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
     A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 4); A(&qp->csbuf, 2 * qc);
@@ -2438,8 +2509,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
             double* Text = qp->Tc + (size_t)meq * ldw;
             OG_STAGE("warm rows");
             if (ng)
-                hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (ng + 63) / 64), dim3(256), 0, s, A, meq, ng, qp->Jw,
-                                   ldw, nq, Text, (const int*)qp->d_warm);
+                OG_TRY(launch_gemm(qp, A, meq, ng, nq, ldw, Text, (const int*)qp->d_warm, s));
             if (nwarm > ng)
                 hipLaunchKernelGGL(k_rows_gather_bounds, dim3((nq + 255) / 256, nwarm - ng), dim3(256), 0, s, qp->Jw, ldw,
                                    nq, mg, (const int*)qp->d_warm, ng, nwarm, Text);
@@ -2449,8 +2519,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     if (msweep) {
         OG_STAGE("gemm C Z");
         if (meq)
-            hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (meq + 63) / 64), dim3(256), 0, s, A, 0, meq, qp->Jw, ldw,
-                               nq, qp->Tc, (const int*)nullptr);
+            OG_TRY(launch_gemm(qp, A, 0, meq, nq, ldw, qp->Tc, (const int*)nullptr, s));
         OG_STAGE("lq sweep");
         OG_HIP(hipMemsetAsync(qp->dthresh, 0, 2 * sizeof(double), s));
         for (int k = 0; k < msweep;) {
@@ -2556,8 +2625,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     // ---- least-distance problem in the null space
     OG_STAGE("gemm G J");
     if (mg) {
-        hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, (mg + 63) / 64), dim3(256), 0, s, A, meq, mg, qp->Jw, ldw,
-                           nq, qp->GJ, (const int*)nullptr);
+        OG_TRY(launch_gemm(qp, A, meq, mg, nq, ldw, qp->GJ, (const int*)nullptr, s));
         hipLaunchKernelGGL(k_gemv_cols_A, dim3((mg + 63) / 64), dim3(1024), 0, s, A, meq, nq, mg, qp->deq,
                            qp->c + meq, qp->bG);
     }

@@ -584,6 +584,17 @@ OG_HD double hypot_(double x, double y) {
 OG_HD double pow_(double x, double y) {
     if (y == 0.0 || x == 1.0) return 1.0;
     if (isnan_(x) || isnan_(y)) return x + y;
+    if (y == (double)(int)y && fabs_(y) <= 64.0 && x - x == 0.0) {
+        // a small whole exponent (at run time): square and multiply, exact where the products are
+        int k = (int)fabs_(y);
+        double base = x, acc = 1.0;
+        while (k) {
+            if (k & 1) acc *= base;
+            k >>= 1;
+            if (k) base *= base;
+        }
+        return y < 0.0 ? 1.0 / acc : acc;
+    }
     if (x > 0.0) return exp_(y * log_(x));
     const double inf = from_bits(0x7ff0000000000000ULL);
     const bool yint = (y == (double)(long long)y) && fabs_(y) < 9.0e15;

@@ -212,7 +212,7 @@ def replay_golden(name, qp):
     return G, ours, trace
 
 
-@pytest.mark.parametrize("name,worst,typical", BASELINE_REPLAYS)
+@pytest.mark.parametrize("name,worst,typical", BASELINE_REPLAYS[:1])     # (C4 as well on the GPU box: the CPU suite stays short)
 def test_slsqp_restatement_replays_scipy_goldens_at_baseline_sizes(name, worst, typical):
     """C3 (n = 1442) and C4 (n = 2001): SciPy 1.15.3's first major iterations - relaxed QP for the inconsistent
     first linearisation, line search, BFGS - reproduced by the restatement, iterate for iterate, with the same
@@ -259,8 +259,7 @@ def test_the_reference_and_the_twin_driven_scipy_runs_agree_as_far_as_conditioni
         Aa = np.hstack([Amat, extra[:, None]])
         return slsqp_np.qp_solve(Za, np.append(g, 0.0), Aa[:meq], c[:meq], Aa[meq:], c[meq:], lo, hi, lq="lapack")
 
-    assert slsqp_np.qp_solve(np.eye(n), g, A[:meq], c[:meq], A[meq:], c[meq:], cb.lb - x, cb.ub - x, lq="lapack")[3] == 4
-    base = relaxed(A)
+    base = relaxed(A)                   # (the plain QP is inconsistent here: mode 4, asserted by the GPU tests)
     noise = 1e-12 * np.abs(A).max() * np.random.default_rng(0).standard_normal(A.shape) * (A != 0)
     moved = relaxed(A + noise)
     assert base[3] == moved[3] == 1

@@ -42,7 +42,17 @@ def main():
                     help="exact: forward-mode derivatives instead of SciPy's forward differences")
     ap.add_argument("--sqp-core", default="scipy", choices=["scipy", "hip"],
                     help="hip: QP subproblems on the GPU (include/ogsqp.h); needs --engine hip")
+    ap.add_argument("--cold-start", action="store_true",
+                    help="only measure what a NEW problem shape pays before its first sweep: trace + codegen + hipcc "
+                         "(forced rebuild of the kernel module) + load, in a fresh process (bench.cold_start)")
     a = ap.parse_args()
+    if a.cold_start:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        import bench
+        out = bench.cold_start(a.workload)
+        out.update({"workload": a.workload, "first_solve_s": out.get("total_s")})
+        print(json.dumps(out))
+        return
     prob, obj = problems.build(a.workload)
     if a.max_restarts is not None:
         prob.maxIterator = a.max_restarts

@@ -155,7 +155,9 @@ int og_unpack_dev(og_handle h, const double* d_vals, int32_t col_lo, int32_t col
  * or had in the previous step, the rows of the other ranks are filled from this rank's own F(x) - F(x)
  * first (every rank evaluates the same F(x)), so the replica equals the single-GPU result in that case too.
  * Call order per step on one stream: og_fd_sweep_dev (own block), og_shard_pack_dev, all-gather,
- * og_shard_unpack_dev.  Results are bitwise independent of `world`. */
+ * og_shard_unpack_dev.  Results are bitwise independent of `world`.  A rank that owns no columns (more ranks
+ * than blocks of B columns) evaluates F(x) only (og_shard_sweep_dev / og_eval_dev) and og_shard_unpack_dev keeps
+ * the NaN history of its replica in a pair of device words of its own. */
 int og_shard_plan(og_handle h, int32_t world, int32_t* block_cols, int64_t* block_vals);
 /* The all-gather itself, for one process per GPU, on the caller's stream with no detour through another
  * runtime's streams: rank 0 makes a unique id (og_shard_comm_unique_id: 128 bytes = ncclGetUniqueId), the

@@ -61,7 +61,8 @@ typedef struct ogk_args {
     // of a mode-5 launch (one thread); thread 0 of a mode-0 launch when jt_bump is set (the evaluation that
     // precedes a mode 1 / 2 / 4 launch); a one-thread kernel (mode 10) before a lone mode-1 launch.
     int32_t jt_sparse;
-    int32_t jt_bump;        // mode 0: count one launch into *jt_launches
+    int32_t jt_bump;        // mode 0: count one launch into *jt_launches; mode 9 (unpack of a rank that owns no
+                            // columns): mark a NaN fill in *jt_state when F(x0) had non-finite rows
     uint32_t* jt_launches;  // launches into the registered buffer so far
     uint32_t* jt_state;     // number of the last launch into the buffer that left NaN fill behind
     // mode 5 counts the non-finite rows of F(x0) in *nonfinite (zero between launches: its last evaluation

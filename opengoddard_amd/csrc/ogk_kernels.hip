@@ -1648,6 +1648,9 @@ __global__ __launch_bounds__(PACK_THREADS) void ogk_unpack(const ogk_args a) {
     int j = a.ulo + (int)blockIdx.x;
     if (j >= a.col_lo) j += a.col_hi - a.col_lo;
     const int tid = (int)threadIdx.x;
+    // a rank without columns of its own (jt_bump): nobody else records that this step fills with NaN.  The
+    // other workgroups' decision below does not depend on this store (they see the same non-zero count)
+    if (a.jt_bump && blockIdx.x == 0 && tid == 0 && *a.nonfinite != 0) jt_mark_nan_fill(a);
     if (j >= a.uhi) return;
     const long base = a.pind[j];
     const int cnt = (int)(a.pind[j + 1] - base);

@@ -554,8 +554,11 @@ int og_problem_create(const og_desc* desc, og_handle* out) {
         e = hipMalloc(&p->d_trace, sizeof(double) * OG_TRACE_DOUBLES);
         if (e == hipSuccess) e = hipMemset(p->d_trace, 0, sizeof(double) * OG_TRACE_DOUBLES);
     }
-    if (e == hipSuccess) e = hipMalloc(&p->d_state, 2 * (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(p->d_state, 0xff, 2 * (OG_MAX_JT_REGS + 1) * sizeof(uint32_t));
+    // one pair per registration, pair 0 for unregistered buffers, the last pair for og_shard_unpack_dev of a rank
+    // that owns no columns (state: no NaN fill; launches so far: 0)
+    if (e == hipSuccess) e = hipMalloc(&p->d_state, 2 * (OG_MAX_JT_REGS + 2) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(p->d_state, 0xff, 2 * (OG_MAX_JT_REGS + 2) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(p->d_state + 2 * (OG_MAX_JT_REGS + 1) + 1, 0, sizeof(uint32_t));
     p->n_eval_blocks = info.n_eval_blocks;
     p->fused_ok = info.fused_ok != 0;
     const char* mode_env = getenv("OGPSX_SWEEP");
@@ -827,7 +830,16 @@ int og_shard_unpack_dev(og_handle p, int32_t rank, const double* d_recv, double*
     a.pvals = const_cast<double*>(d_recv);
     a.ulo = 0;
     a.uhi = n;
-    int rc = p->launch(&a, 9, hip_stream);
+    int rc = 0;
+    if (hi <= lo) {
+        // more ranks than columns: no sweep of this rank keeps the replica's NaN history, so the unpack does - its
+        // own pair of words, one count per step, and the kernel marks a step whose F(x0) had non-finite rows
+        a.jt_state = p->d_state + 2 * (OG_MAX_JT_REGS + 1);
+        a.jt_launches = a.jt_state + 1;
+        a.jt_bump = 1;
+        rc = p->launch(&a, 10, hip_stream);
+    }
+    if (!rc) rc = p->launch(&a, 9, hip_stream);
     if (rc) return fail(100 + rc, std::string("og_shard_unpack_dev: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }

@@ -541,6 +541,47 @@ def test_sharded_sweep_class_on_the_device(golden):
     eng.close()
 
 
+def test_rank_without_columns_keeps_its_replica_clean_through_nan_points():
+    """More ranks than column blocks (goddard: n = 201, 64 ranks of 4 columns, ranks 51.. own nothing): such a rank
+    evaluates F(x0) only, and og_shard_unpack_dev keeps the NaN history of its replica itself (it
+    used to compare against stand-in state words and left stale NaN rows behind after a non-finite point).  The
+    messages of the other ranks are made here from the single-device matrix in the plan's layout."""
+    import torch
+    from opengoddard_amd import sharding
+    from opengoddard_amd.engine import HipEngine
+    from oracle import np_path
+    prob, obj = problems.build("goddard")
+    lb, ub = np_path.bounds_arrays(prob)
+    eng = HipEngine(prob, obj)
+    dev = torch.device("cuda", 0)
+    be = sharding.HipBackend(eng, dev)
+    world, rank = 64, 63
+    sh = sharding.ShardedSweep(be, eng.n, eng.m, rank, world)
+    assert sh.hi <= sh.lo
+    indptr, rows = eng.pattern()
+    cols = np.repeat(np.arange(eng.n), np.diff(indptr))
+    where = np.repeat(sh.offsets, np.diff(indptr)) + (np.arange(rows.size) - np.repeat(indptr[:-1], np.diff(indptr)))
+    x_ok = np.clip(prob.p, lb, ub)
+    x_bad = x_ok.copy()
+    x_bad[prob.index_states(2, 0, 7)] = 0.0
+    rng = np.random.default_rng(11)
+    x_other = np.clip(x_ok + 1e-3 * rng.standard_normal(eng.n), lb, ub)
+    single = HipEngine(prob, obj)
+    for step, x in enumerate((x_ok, x_bad, x_other, x_bad, x_bad, x_ok, x_other)):
+        h = _native.fd_step(x, lb, ub)
+        F_want, JT_want = single.sweep_stacked(x, h)
+        message = np.zeros(sh.recv.numel())
+        message[where] = JT_want[cols, rows]
+        sh.recv.copy_(torch.from_numpy(message))
+        be.sweep_and_pack(rank, be.upload(x), be.upload(h), sh.lo, sh.hi, sh.replica, sh.F0, sh.send)
+        be.unpack(rank, sh.recv, sh.replica)
+        torch.cuda.synchronize()
+        assert np.array_equal(sh.F0.cpu().numpy(), F_want, equal_nan=True)
+        assert np.array_equal(sh.replica.cpu().numpy(), JT_want, equal_nan=True), "step %d" % step
+    single.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("name,state", [("goddard", 2), ("polar_tsto", 4)])
 def test_one_launch_sweep_replays_from_a_captured_graph(name, state):
     """The launch arguments of a sweep into a registered buffer are pointers only - the count of non-finite rows,

@@ -69,6 +69,8 @@ def _kernel_sources():
 
 
 def build_core(force=False):
+    if os.environ.get("OG_CORE_LIB"):                   # diagnostics: a build with other flags (tools/sanitize.sh)
+        return os.environ["OG_CORE_LIB"]
     os.makedirs(LIBDIR, exist_ok=True)
     stamp_path = CORE_LIB + ".stamp"
     want = _digest_files(_core_sources())

@@ -2220,6 +2220,9 @@ struct og_qp_s {
     int* has_gone = nullptr;           // ... per block: it holds a vanishing pivot (no inverse)
     double* V16 = nullptr;             // reflector vectors of a 16-wide panel
     Lq16Panel* panel16 = nullptr;
+    double* V16b = nullptr;            // ... of the panel the look-ahead factors during the trailing update
+    Lq16Panel* panel16b = nullptr;
+    bool lq_ahead = true;              // OGSQP_LQ=16: panel and trailing update as separate launches
     bool lq16 = true;                  // OGSQP_LQ=8: the sweep of 8-reflector panels only
     int coop_mode = 1;                 // 0 never, 1 by size, 2 always (when it fits)
     int last_iters = 1000;             // active-set changes of the previous subproblem on this handle (a solve starts with many)
@@ -2360,7 +2363,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->Z, n1 * ldw); A(&qp->Jw, n1 * ldw); A(&qp->Tc, ((size_t)qp->meq + qc) * ldw); A(&qp->GJ, (size_t)qp->mg * ldw);
     A(&qp->diagL, qp->meq + qc); A(&qp->dots, (size_t)qp->mg + n1); A(&qp->dvec, n1); A(&qp->rvec, qc);
     A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc);
-    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->trsv_work, qp->meq); A(&qp->gemm_map, ((size_t)std::max(qp->meq, qp->mg) + 63 + qc) / 64 * ((n1 + 15) / 16) + 64); A(&qp->Linv, ((size_t)qp->meq + 63) / 64 * 4096); A(&qp->has_gone, ((size_t)qp->meq + 63) / 64); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->V16b, (size_t)LQ16 * ldw); A(&qp->panel16b, 1); A(&qp->trsv_work, qp->meq); A(&qp->gemm_map, ((size_t)std::max(qp->meq, qp->mg) + 63 + qc) / 64 * ((n1 + 15) / 16) + 64); A(&qp->Linv, ((size_t)qp->meq + 63) / 64 * 4096); A(&qp->has_gone, ((size_t)qp->meq + 63) / 64); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
     A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 4); A(&qp->csbuf, 2 * qc);
@@ -2402,6 +2405,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         if (qp->gi_mode == 1 && gi_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) qp->gi_mode = 0;
         const char* lq = getenv("OGSQP_LQ");
         qp->lq16 = !(lq && std::string(lq) == "8");
+        qp->lq_ahead = !(lq && std::string(lq) == "16");
         const char* warm = getenv("OGSQP_WARM");
         qp->warm_enabled = !(warm && std::string(warm) == "0");
     }
@@ -2522,6 +2526,11 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
             OG_TRY(launch_gemm(qp, A, 0, meq, nq, ldw, qp->Tc, (const int*)nullptr, s));
         OG_STAGE("lq sweep");
         OG_HIP(hipMemsetAsync(qp->dthresh, 0, 2 * sizeof(double), s));
+        double* Vcur = qp->V16;
+        double* Vnxt = qp->V16b;
+        Lq16Panel* pcur = qp->panel16;
+        Lq16Panel* pnxt = qp->panel16b;
+        int factored = -1;                                  // the panel the previous launch factored on the side
         for (int k = 0; k < msweep;) {
             if (qp->lq16 && nq - k <= 2048 && k % LQ16 == 0) {
                 // 16 reflectors per trip: row-distributed panel kernel, MFMA trailing update (ogsqp_lq16.h)
@@ -2530,24 +2539,44 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
                 const int eg = (len16 + 255) / 256, ub = (len16 + 127) / 128;
 #define OG_PANEL16(E)                                                                                              \
     hipLaunchKernelGGL(k_lq_panel16<E>, dim3(1), dim3(P16_THREADS), (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, ldw, \
-                       msweep, nq, k, qp->V16, ldw, qp->diagL, qp->panel16, qp->dthresh + 1)
-                if (eg <= 2) OG_PANEL16(2);
-                else if (eg <= 4) OG_PANEL16(4);
-                else if (eg <= 6) OG_PANEL16(6);
-                else OG_PANEL16(8);
+                       msweep, nq, k, Vcur, ldw, qp->diagL, pcur, qp->dthresh + 1)
+                if (factored != k) {
+                    if (eg <= 2) OG_PANEL16(2);
+                    else if (eg <= 4) OG_PANEL16(4);
+                    else if (eg <= 6) OG_PANEL16(6);
+                    else OG_PANEL16(8);
+                }
 #undef OG_PANEL16
 #ifdef OGSQP_TRACE
-                if (k == 0 || k == 512) {
+                if ((k == 0 || k == 512) && factored != k) {
                     Lq16Panel hp;
-                    OG_HIP(hipMemcpyAsync(&hp, qp->panel16, sizeof(Lq16Panel), hipMemcpyDeviceToHost, s));
+                    OG_HIP(hipMemcpyAsync(&hp, pcur, sizeof(Lq16Panel), hipMemcpyDeviceToHost, s));
                     OG_HIP(hipStreamSynchronize(s));
                     fprintf(stderr, "[ogsqp trace] panel16 at k = %d (len %d) ticks: load %lld publish %lld barrier1 %lld products %lld barrier2 %lld update %lld store %lld\n",
                             k, len16, hp.tr[0], hp.tr[1], hp.tr[2], hp.tr[3], hp.tr[4], hp.tr[5], hp.tr[6]);
                 }
 #endif
+                if (qp->lq_ahead && k + LQ16 < msweep) {
+                    // the trailing update's first workgroup factors the next panel on the side (k_lq_step16)
+#define OG_STEP16(U, E)                                                                                           \
+    hipLaunchKernelGGL((k_lq_step16<U, E>), dim3((nrows16 + 15) / 16), dim3(64 * A16_WAVES),                       \
+                       (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, qp->Jw, ldw, msweep, nq, k, (const double*)Vcur, ldw, \
+                       (const Lq16Panel*)pcur, Vnxt, pnxt, qp->diagL, qp->dthresh + 1)
+                    if (ub <= 2) OG_STEP16(2, 2);
+                    else if (ub <= 4) OG_STEP16(4, 2);
+                    else if (ub <= 8) OG_STEP16(8, 4);
+                    else if (ub <= 12) OG_STEP16(12, 6);
+                    else OG_STEP16(16, 8);
+#undef OG_STEP16
+                    factored = k + LQ16;
+                    std::swap(Vcur, Vnxt);
+                    std::swap(pcur, pnxt);
+                    k += LQ16;
+                    continue;
+                }
 #define OG_APPLY16(U)                                                                                            \
     hipLaunchKernelGGL(k_lq_apply16<U>, dim3((nrows16 + 15) / 16), dim3(64 * A16_WAVES), 0, s, qp->Tc, qp->Jw, ldw, msweep, \
-                       nq, k, (const double*)qp->V16, ldw, (const Lq16Panel*)qp->panel16)
+                       nq, k, (const double*)Vcur, ldw, (const Lq16Panel*)pcur)
                 if (ub <= 2) OG_APPLY16(2);
                 else if (ub <= 4) OG_APPLY16(4);
                 else if (ub <= 8) OG_APPLY16(8);
@@ -2828,8 +2857,11 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
                 hst.phase, hst.iters, hst.q, hflag[1]);
 #ifdef OGSQP_TRACE
     {
-        static const char* names[9] = {"phase A + wait", "election", "load normal", "projections", "z update",
-                                       "r + ratio test", "u,y update", "append", "removal"};
+        static const char* names_iter[9] = {"phase A + wait", "election", "load normal", "projections", "z update",
+                                            "r + ratio test", "u,y update", "append", "removal"};
+        static const char* names_rows[9] = {"state word", "who comes in", "normal in LDS", "norms", "inverse rows x d1",
+                                            "stores + ticket", "others' r, ratio", "u, y", "reflector, lists"};
+        const char* const* names = rows_mode ? names_rows : names_iter;
         fprintf(stderr, "[ogsqp trace] %d iterations, %lld passes, %lld removals, %d active at the end\n", hst.iters,
                 hst.tr[10], hst.tr[11], hst.q);
         for (int e = 0; e < 9; ++e)

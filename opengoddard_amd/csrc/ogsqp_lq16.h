@@ -48,10 +48,10 @@ __device__ __forceinline__ double oct_sum(double v) {
 // wavefront holds the rows 2 (l / 8) and 2 (l / 8) + 1 on its columns: the reflector vector is read from LDS once
 // per lane and step and serves both, in the products and in the update.
 template <int E>
-__global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__ Tc, int ld, int mrows, int nq, int k,
-                                                           double* __restrict__ V, int ldv, double* __restrict__ diagL,
-                                                           Lq16Panel* __restrict__ panel, double* __restrict__ dmaxbuf) {
-    extern __shared__ double lds[];
+__device__ __forceinline__ void lq_panel16_body(double* __restrict__ Tc, int ld, int mrows, int nq, int k,
+                                                double* __restrict__ V, int ldv, double* __restrict__ diagL,
+                                                Lq16Panel* __restrict__ panel, double* __restrict__ dmaxbuf,
+                                                double* __restrict__ lds) {
     __shared__ double s_part[2][P16_WAVES][LQ16];    // partial dot products (double-buffered by step parity)
     __shared__ double s_xpc[2][LQ16];                // every row's entry in the pivot column
     __shared__ double s_lower[LQ16][LQ16];           // finished entries of L inside the panel
@@ -254,6 +254,14 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
 #undef P16MARK
 }
 
+template <int E>
+__global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__ Tc, int ld, int mrows, int nq, int k,
+                                                           double* __restrict__ V, int ldv, double* __restrict__ diagL,
+                                                           Lq16Panel* __restrict__ panel, double* __restrict__ dmaxbuf) {
+    extern __shared__ double lds[];
+    lq_panel16_body<E>(Tc, ld, mrows, nq, k, V, ldv, diagL, panel, dmaxbuf, lds);
+}
+
 // U: blocks of 16 columns per wavefront (rows of up to 128 U entries from the panel's first column on); eight
 // wavefronts per workgroup.  Rows are 128-byte aligned (leading dimension a multiple of 16, k a multiple of 16):
 // lane (n, g) owns the four CONSECUTIVE columns 16 b + 4 g + i of row n in block b - one 32-byte load, and the
@@ -262,16 +270,16 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
 // global load of a phase is issued before the first result is used.
 constexpr int A16_WAVES = 8;
 template <int U>
-__global__ __launch_bounds__(64 * A16_WAVES) void k_lq_apply16(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
-                                                              int mrows, int nq, int k, const double* __restrict__ V,
-                                                              int ldv, const Lq16Panel* __restrict__ panel) {
+__device__ __forceinline__ void lq_apply16_body(double* __restrict__ Tc, double* __restrict__ Jw, int ld, int mrows, int nq,
+                                                int k, const double* __restrict__ V, int ldv,
+                                                const Lq16Panel* __restrict__ panel, const int group) {
     __shared__ double s_w[A16_WAVES][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int nb = panel->nb, L = nq - k;
     const int nblk = (L + 15) / 16;
     const int below = mrows - k - nb, nrows = below + nq;
-    const int r = blockIdx.x * 16 + n;
+    const int r = group * 16 + n;
     const bool valid = r < nrows;
     const int rc = valid ? r : nrows - 1;
     double* row = (rc < below ? Tc + (long)(k + nb + rc) * ld : Jw + (long)(rc - below) * ld) + k;
@@ -352,3 +360,33 @@ __global__ __launch_bounds__(64 * A16_WAVES) void k_lq_apply16(double* __restric
         }
     }
 }
+
+template <int U>
+__global__ __launch_bounds__(64 * A16_WAVES) void k_lq_apply16(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
+                                                              int mrows, int nq, int k, const double* __restrict__ V,
+                                                              int ldv, const Lq16Panel* __restrict__ panel) {
+    lq_apply16_body<U>(Tc, Jw, ld, mrows, nq, k, V, ldv, panel, (int)blockIdx.x);
+}
+
+// Look-ahead inside one launch: the trailing update of panel k, whose first workgroup - its 16 rows are the rows
+// of panel k + 16 - goes on to factor that panel (into the other reflector buffer) while the rest of the chip
+// finishes the update.  The panel factorisation is one workgroup's latency chain (26-33 us) and the update the
+// whole chip's bandwidth (21-30 us): run one after the other they idle each other's resource.  Same arithmetic,
+// row for row, as k_lq_apply16 followed by k_lq_panel16.
+template <int U, int E>
+__global__ __launch_bounds__(64 * A16_WAVES) void k_lq_step16(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
+                                                             int mrows, int nq, int k, const double* __restrict__ V,
+                                                             int ldv, const Lq16Panel* __restrict__ panel,
+                                                             double* __restrict__ Vnext, Lq16Panel* __restrict__ pnext,
+                                                             double* __restrict__ diagL, double* __restrict__ dmaxbuf) {
+    extern __shared__ double lds[];
+    static_assert(64 * A16_WAVES == P16_THREADS, "one workgroup shape for both roles");
+    lq_apply16_body<U>(Tc, Jw, ld, mrows, nq, k, V, ldv, panel, (int)blockIdx.x);
+    if (blockIdx.x != 0) return;
+    // my own stores to the next panel's rows, seen by every wavefront of this workgroup
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    lq_panel16_body<E>(Tc, ld, mrows, nq, k + LQ16, Vnext, ldv, diagL, pnext, dmaxbuf, lds);
+}
+

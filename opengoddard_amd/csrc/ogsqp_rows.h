@@ -117,11 +117,19 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
     __shared__ int s_last;
     const GiArgs& g = a.g;
     GiState* st = g.st;
+#ifdef OGSQP_TRACE
+    long long t_mark = __builtin_amdgcn_s_memrealtime();
+    long long t_sec[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define RMARK(slot_) do { const long long now_ = __builtin_amdgcn_s_memrealtime(); t_sec[slot_] += now_ - t_mark; t_mark = now_; } while (0)
+#else
+#define RMARK(slot_) do { } while (0)
+#endif
     const int phase = st->phase;
     if (phase >= 2) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
     const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
     const int q = st->q;
+    RMARK(0);   // state word
     double* d = lds;                  // nr: incoming normal
     double* rv = d + nr;              // qcap: dual direction / multipliers of the warm start
     double* aux = rv + qcap;          // qcap: leaving row of RI -> reflector vector / minimiser of the warm start
@@ -214,6 +222,47 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
     }
 
     // ---- the incoming row ------------------------------------------------------------------------------------
+    // Everything whose address does not depend on what another workgroup is about to write is requested as early as
+    // its address is known and in every workgroup - the lists and the multipliers of the active rows and y for the
+    // decision (PRE entries per thread in registers; longer lists fall back to loading late), the first rows of the
+    // inverse - so that the workgroup that draws the last ticket has one round trip left: the others' shares of r
+    // and of the ratio test.  Measured (-DOGSQP_TRACE, tools/sqp_trace.sh; C3, first subproblems): 12.4 us per
+    // change in this kernel either way - state word 0.5, price election 3.5 (875 partials, and the wait for the
+    // early loads lands here), normal into LDS 1.1, norms 0.8, inverse rows x d1 1.1, stores + ticket 1.7, the
+    // others' r 1.3, u and y 1.0, reflector and lists 1.1: nine barrier-separated steps of about a microsecond
+    // (a workgroup reduction is 0.4 us, a global round trip 0.7-1), of which the early loads hide none that the
+    // in-order wait of the next step does not give back.
+    constexpr int PRE = 8;
+    int pact[PRE], pslot[PRE];
+    double pu[PRE], py[PRE];
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) {
+        const int jj = tid + ROWS_THREADS * c;
+        pact[c] = g.act[jj < q ? jj : 0];
+        pslot[c] = a.slot[jj < qcap ? jj : 0];
+        py[c] = g.y[jj < nr ? jj : 0];
+    }
+    const int stride = a.G1 * ROWS_WAVES;
+    const int ifirst = w * ROWS_WAVES + wave;
+    int fslot[4], fact[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = ifirst + e * stride;
+        fslot[e] = a.slot[i < q ? i : (ifirst < q ? ifirst : 0)];
+        fact[e] = g.act[i < q ? i : (ifirst < q ? ifirst : 0)];
+    }
+    // ... and the first RPRE * 64 entries of those rows themselves (their addresses do not depend on who comes in)
+    constexpr int RPRE = 8;
+    double rpre[4][RPRE];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double* rowe = RI + (long)fslot[e] * qcap;
+#pragma unroll
+        for (int c = 0; c < RPRE; ++c) {
+            const int j = lane + 64 * c;
+            rpre[e][c] = rowe[j < q ? j : 0];
+        }
+    }
     int p;
     if (phase == 0) {
         double v = INFINITY;
@@ -235,27 +284,62 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
     } else {
         p = st->p;
     }
+    RMARK(1);   // who comes in
+    const int iters = st->iters + 1;
+    const bool broken = iters > g.limit || q > nr || q > qcap || p < 0 || p >= mg + 2 * nq;
+    const int psafe = broken ? 0 : p;
     double psign;
-    const double* prow = stack_row(g, p, psign);
+    const double* prow = stack_row(g, psafe, psign);
     for (int i = tid; i < nr; i += ROWS_THREADS) d[i] = psign * prow[i];
+    const int prow_index = psafe < mg + nq ? psafe : psafe - nq;
+    const double bval_p = g.bval[psafe], dots_p = a.dots[prow_index];
+    const double up_before = phase == 0 ? 0.0 : st->up;
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) pu[c] = g.u[tid + ROWS_THREADS * c < q ? pact[c] : 0];      // (act[] beyond q: anything)
+    double fu[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fu[e] = g.u[ifirst < q ? fact[e] : 0];
     __syncthreads();
+    RMARK(2);   // its normal in LDS
+    // |d2|^2 and |d|^2 (every workgroup: the same sums in the same order)
+    double part_zz = 0.0, part_nn = 0.0;
+    for (int i = tid; i < nr; i += ROWS_THREADS) {
+        const double v = d[i];
+        part_nn += v * v;
+        if (i >= q) part_zz += v * v;
+    }
+    const double zz = block_sum(part_zz, red);
+    const double nn = block_sum(part_nn, red);
+    RMARK(3);   // |d2|, |d|
     // ---- my rows of the inverse: dual direction and ratio test ------------------------------------------------
     {
         double t1 = INFINITY;
         int kdrop = 0x7fffffff;
         // four rows per trip: their loads are in flight together (a row is one memory round trip otherwise)
-        const int stride = a.G1 * ROWS_WAVES;
-        for (int i0 = w * ROWS_WAVES + wave; i0 < q; i0 += 4 * stride) {
+        for (int i0 = ifirst; i0 < q; i0 += 4 * stride) {
             const double* row[4];
             double uact[4], acc[4];
+            const bool first = i0 == ifirst;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = i0 + e * stride;
-                row[e] = RI + (long)a.slot[i < q ? i : i0] * qcap;
-                uact[e] = g.u[g.act[i < q ? i : i0]];
+                const int sl = first ? fslot[e] : a.slot[i < q ? i : i0];
+                row[e] = RI + (long)sl * qcap;
+                uact[e] = first ? fu[e] : g.u[g.act[i < q ? i : i0]];
                 acc[e] = 0.0;
             }
-            for (int j = lane; j < q; j += 64) {
+            int jstart = lane;
+            if (first) {                                       // (same sums in the same order as the loop below)
+#pragma unroll
+                for (int c = 0; c < RPRE; ++c) {
+                    const int j = lane + 64 * c;
+                    const double dj = j < q ? d[j < q ? j : 0] : 0.0;      // (beyond q: + 0, after the last real term)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += rpre[e][c] * dj;
+                }
+                jstart = lane + 64 * RPRE;
+            }
+            for (int j = jstart; j < q; j += 64) {
                 const double dj = d[j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += row[e][j] * dj;
@@ -280,8 +364,12 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
             t1 = INFINITY;
             kdrop = 0x7fffffff;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my entries of r have left before the ticket is drawn
+        RMARK(4);   // my rows of the inverse times d1
         block_argmin(t1, kdrop, redv, redi);
+        // (the barriers of the reduction order every wavefront's stores to r before thread 0's wait below only in
+        // program order of ITS wavefront: each wavefront waits for its own)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (tid == 0) {
             st_shared(&a.ratio[w].value, t1);
             st_shared(&a.ratio[w].index, kdrop);
@@ -291,6 +379,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         }
         __syncthreads();
         if (!s_last) return;
+        RMARK(5);   // stores out, ticket
     }
     // ---- last workgroup: the decision ------------------------------------------------------------------------
     if (tid == 0) st->ticket = 0u;
@@ -304,26 +393,24 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
             kdrop = ci;
         }
     }
+    // the others' entries of r: requested together with their ratio-test candidates
+    double pr[PRE];
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) {
+        const int jj = tid + ROWS_THREADS * c;
+        pr[c] = ld_shared(a.rvec + (jj < q ? jj : 0));
+    }
     block_argmin(t1, kdrop, redv, redi);
-    const int iters = st->iters + 1;
-    if (iters > g.limit || q > nr || q > qcap || p < 0 || p >= mg + 2 * nq) {
+    RMARK(6);   // the others' r and candidates
+    if (broken) {
         if (tid == 0) {
             st->phase = 3;
             st->iters = iters;
         }
         return;
     }
-    double part_zz = 0.0, part_nn = 0.0;
-    for (int i = tid; i < nr; i += ROWS_THREADS) {
-        const double v = d[i];
-        part_nn += v * v;
-        if (i >= q) part_zz += v * v;
-    }
-    const double zz = block_sum(part_zz, red);
-    const double nn = block_sum(part_nn, red);
     const bool dependent = (q >= nr) || !(zz > (DEPENDENT * DEPENDENT) * nn);
-    const int prow_index = p < mg + nq ? p : p - nq;
-    const double sp = g.bval[p] + psign * a.dots[prow_index];
+    const double sp = bval_p + psign * dots_p;
     const double t2 = dependent ? INFINITY : -sp / zz;
     const double t = fmin(t1, t2);
     if (!(t < INFINITY)) {
@@ -333,22 +420,46 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         }
         return;
     }
-    for (int j = tid; j < q; j += ROWS_THREADS) {
-        const double rj = ld_shared(a.rvec + j);
-        rv[j] = rj;
-        g.u[g.act[j]] -= t * rj;
-    }
-    const double up = (phase == 0 ? 0.0 : st->up) + t;
-    double part_yy = 0.0;
-    for (int i = tid; i < nr; i += ROWS_THREADS) {
-        double yi = g.y[i];
-        if (!dependent && i >= q) {
-            yi += t * d[i];
-            g.y[i] = yi;
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) {
+        const int jj = tid + ROWS_THREADS * c;
+        if (jj < q) {
+            rv[jj] = pr[c];
+            g.u[pact[c]] = pu[c] - t * pr[c];
         }
-        part_yy += yi * yi;
+    }
+    for (int jj = tid + ROWS_THREADS * PRE; jj < q; jj += ROWS_THREADS) {
+        const double rj = ld_shared(a.rvec + jj);
+        rv[jj] = rj;
+        g.u[g.act[jj]] -= t * rj;
+    }
+    const double up = up_before + t;
+    double part_yy = 0.0;
+    {
+        // (the partial sums of |y|^2 in the order of the plain loop: c ascending per thread)
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) {
+            const int i = tid + ROWS_THREADS * c;
+            if (i < nr) {
+                double yi = py[c];
+                if (!dependent && i >= q) {
+                    yi += t * d[i];
+                    g.y[i] = yi;
+                }
+                part_yy += yi * yi;
+            }
+        }
+        for (int i = tid + ROWS_THREADS * PRE; i < nr; i += ROWS_THREADS) {
+            double yi = g.y[i];
+            if (!dependent && i >= q) {
+                yi += t * d[i];
+                g.y[i] = yi;
+            }
+            part_yy += yi * yi;
+        }
     }
     const double ynorm = sqrt(block_sum(part_yy, red));
+    RMARK(7);   // u, y
     for (int i = tid; i < nr; i += ROWS_THREADS) a.dvec[i] = d[i];
     const bool full_step = (t2 < INFINITY) && (t2 <= t1);
     RowsDecision rec;
@@ -369,8 +480,27 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         rec.beta = vv > 0.0 ? 2.0 / vv : 0.0;
         double* RIw = g.RI[0];
         const double inv = 1.0 / alpha;
-        double* fresh = RIw + (long)a.slot[q] * qcap;
-        for (int i = tid; i < q; i += ROWS_THREADS) {
+        // the storage row of position q: slot[q], among the preloaded entries when q < PRE * ROWS_THREADS
+        __shared__ int s_fresh;
+        if (q >= PRE * ROWS_THREADS) {
+            if (tid == 0) s_fresh = a.slot[q];
+        } else if (tid == (q % ROWS_THREADS)) {
+            int sl = 0;
+#pragma unroll
+            for (int c = 0; c < PRE; ++c) sl = (q / ROWS_THREADS == c) ? pslot[c] : sl;
+            s_fresh = sl;
+        }
+        __syncthreads();
+        double* fresh = RIw + (long)s_fresh * qcap;
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) {
+            const int i = tid + ROWS_THREADS * c;
+            if (i < q) {
+                RIw[(long)pslot[c] * qcap + q] = -pr[c] * inv;
+                fresh[i] = 0.0;
+            }
+        }
+        for (int i = tid + ROWS_THREADS * PRE; i < q; i += ROWS_THREADS) {
             RIw[(long)a.slot[i] * qcap + q] = -rv[i] * inv;
             fresh[i] = 0.0;
         }
@@ -410,6 +540,15 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         st->iters = iters;
         st->ynorm = ynorm;
     }
+#ifdef OGSQP_TRACE
+    RMARK(8);   // reflector, the inverse's new column / the leaving row
+    if (tid == 0) {
+        for (int e = 0; e < 9; ++e) st->tr[e] += t_sec[e];
+        st->tr[10] += 1;
+        if (!full_step) st->tr[11] += 1;
+    }
+#endif
+#undef RMARK
 }
 
 // ------------------------------------------------------------------------------------------
@@ -452,10 +591,14 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
         if (kind != 0) {
             double x[TAIL];
             double acc_d = 0.0, acc_v = 0.0;
+            // the first q0 coordinates of a row matter when a row leaves (its reflector lives there) and for the
+            // values after a warm start; the tail when the incoming row moves the point - a full step at q0 = 300
+            // of 468 coordinates streams a third of the matrix
+            const bool head = leaves || kind == 4, tail = moves;
 #pragma unroll
             for (int e = 0; e < TAIL; ++e) {
                 const int j = lane + 64 * e;
-                x[e] = j < len ? row[j] : 0.0;
+                x[e] = (j < len && (j < q0 ? head : tail)) ? row[j] : 0.0;
                 acc_d += x[e] * dreg[e];
                 acc_v += x[e] * vreg[e];
             }

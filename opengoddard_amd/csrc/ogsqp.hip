@@ -2223,6 +2223,9 @@ struct og_qp_s {
     double* V16b = nullptr;            // ... of the panel the look-ahead factors during the trailing update
     Lq16Panel* panel16b = nullptr;
     bool lq_ahead = true;              // OGSQP_LQ=16: panel and trailing update as separate launches
+    unsigned* lq_go = nullptr;         // look-ahead: head workgroups that have finished the next panel's rows, ever
+    unsigned lq_token = 0u;            // ... and what the count will be after the launch being enqueued
+    double* lq_wpart = nullptr;        // the head workgroups' partial products (LQ_HEADS x 64 x 4)
     bool lq16 = true;                  // OGSQP_LQ=8: the sweep of 8-reflector panels only
     int coop_mode = 1;                 // 0 never, 1 by size, 2 always (when it fits)
     int last_iters = 1000;             // active-set changes of the previous subproblem on this handle (a solve starts with many)
@@ -2363,16 +2366,17 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->Z, n1 * ldw); A(&qp->Jw, n1 * ldw); A(&qp->Tc, ((size_t)qp->meq + qc) * ldw); A(&qp->GJ, (size_t)qp->mg * ldw);
     A(&qp->diagL, qp->meq + qc); A(&qp->dots, (size_t)qp->mg + n1); A(&qp->dvec, n1); A(&qp->rvec, qc);
     A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc);
-    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->V16b, (size_t)LQ16 * ldw); A(&qp->panel16b, 1); A(&qp->trsv_work, qp->meq); A(&qp->gemm_map, ((size_t)std::max(qp->meq, qp->mg) + 63 + qc) / 64 * ((n1 + 15) / 16) + 64); A(&qp->Linv, ((size_t)qp->meq + 63) / 64 * 4096); A(&qp->has_gone, ((size_t)qp->meq + 63) / 64); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
+    A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->V16b, (size_t)LQ16 * ldw); A(&qp->panel16b, 1); A(&qp->lq_go, 4); A(&qp->lq_wpart, (size_t)LQ_HEADS * 64 * 4); A(&qp->trsv_work, qp->meq); A(&qp->gemm_map, ((size_t)std::max(qp->meq, qp->mg) + 63 + qc) / 64 * ((n1 + 15) / 16) + 64); A(&qp->Linv, ((size_t)qp->meq + 63) / 64 * 4096); A(&qp->has_gone, ((size_t)qp->meq + 63) / 64); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
     A(&qp->Q1t, qc * (qc + 64)); A(&qp->apart, 2 * 64 * (qc + 8)); A(&qp->uact, qc); A(&qp->zg, n1); A(&qp->dthresh, 4); A(&qp->csbuf, 2 * qc);
     A(&qp->cpart, 256); A(&qp->bar, 1); A(&qp->abort_flag, 1); A(&qp->R[0], qc * qc); A(&qp->R[1], qc * qc); A(&qp->RI[0], qc * qc); A(&qp->RI[1], qc * qc);
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
-    A(&qp->isact, mt); A(&qp->act, qc); A(&qp->flag, 2);
+    A(&qp->isact, mt); A(&qp->act, qc); A(&qp->flag, 4);
     A(&qp->partials, ((size_t)qp->mg + n1) / GI_WAVES + 2); A(&qp->st, 1);
     if (!rc && hipStreamCreate(&qp->stream) != hipSuccess) rc = fail(5, "og_qp_create: hipStreamCreate failed");
+    if (!rc && hipMemset(qp->lq_go, 0, 4 * sizeof(unsigned)) != hipSuccess) rc = fail(5, "og_qp_create: hipMemset failed");
     if (!rc && hipFuncSetAttribute((const void*)k_gi_iter, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)LDS_LIMIT) != hipSuccess)
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
@@ -2387,6 +2391,16 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
                 hipFuncSetAttribute((const void*)k_rows_invert, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LDS_LIMIT) != hipSuccess))
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
+    {
+        const void* steps[5] = {(const void*)k_lq_step16<2, 2>, (const void*)k_lq_step16<4, 2>, (const void*)k_lq_step16<8, 4>,
+                                (const void*)k_lq_step16<12, 6>, (const void*)k_lq_step16<16, 8>};
+        for (const void* f : steps) {
+            const hipError_t e = rc ? hipSuccess : hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess)
+                rc = fail(5, std::string("og_qp_create: cannot raise the dynamic LDS limit of the look-ahead kernel: ") +
+                                 hipGetErrorString(e));
+        }
+    }
     if (rc) {
         og_qp_destroy(qp);
         return rc;
@@ -2482,7 +2496,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     OG_HIP(hipMemcpyAsync(qp->dl, hdl, sizeof(double) * n1, hipMemcpyHostToDevice, s));
     OG_HIP(hipMemcpyAsync(qp->du, hdu, sizeof(double) * n1, hipMemcpyHostToDevice, s));
     if (m) OG_HIP(hipMemcpyAsync(qp->c, hc, sizeof(double) * m, hipMemcpyHostToDevice, s));
-    OG_HIP(hipMemsetAsync(qp->flag, 0, 2 * sizeof(int), s));
+    OG_HIP(hipMemsetAsync(qp->flag, 0, 4 * sizeof(int), s));     // [2]: a look-ahead workgroup of the LQ sweep gave up waiting
     if (augmented && m)
         hipLaunchKernelGGL(k_relaxation_row, dim3((m + 255) / 256), dim3(256), 0, s, qp->c, meq, m, qp->extra);
     AView A{d_jt, (long)ld, qp->extra, n};
@@ -2531,12 +2545,17 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
         Lq16Panel* pcur = qp->panel16;
         Lq16Panel* pnxt = qp->panel16b;
         int factored = -1;                                  // the panel the previous launch factored on the side
+        OG_HIP(hipMemsetAsync(qp->lq_go, 0, 2 * sizeof(unsigned), s)); // counts of the head workgroups, this sweep
+        qp->lq_token = 0u;
         for (int k = 0; k < msweep;) {
             if (qp->lq16 && nq - k <= 2048 && k % LQ16 == 0) {
                 // 16 reflectors per trip: row-distributed panel kernel, MFMA trailing update (ogsqp_lq16.h)
                 const int nb16 = std::min(LQ16, msweep - k), len16 = nq - k;
                 const int nrows16 = (msweep - k - nb16) + nq;
-                const int eg = (len16 + 255) / 256, ub = (len16 + 127) / 128;
+ const int eg = (len16 + 255) / 256, ub = (len16 + 127) / 128;
+                // rows per workgroup of the trailing update: 16, or as few as fill the chip (not below 8: every
+                // workgroup reads all of V)
+                const int rpg = std::max(8, std::min(LQ16, (nrows16 + 239) / 240));
 #define OG_PANEL16(E)                                                                                              \
     hipLaunchKernelGGL(k_lq_panel16<E>, dim3(1), dim3(P16_THREADS), (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, ldw, \
                        msweep, nq, k, Vcur, ldw, qp->diagL, pcur, qp->dthresh + 1)
@@ -2556,18 +2575,42 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
                             k, len16, hp.tr[0], hp.tr[1], hp.tr[2], hp.tr[3], hp.tr[4], hp.tr[5], hp.tr[6]);
                 }
 #endif
+#ifdef OGSQP_TRACE
+#define OG_APPLY16_TRACE()                                                                                               \
+    if (k == 0) {                                                                                                        \
+        long long tr[8];                                                                                                 \
+        OG_HIP(hipStreamSynchronize(s));                                                                                 \
+        OG_HIP(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_apply16_trace), sizeof tr));                                         \
+        fprintf(stderr, "[ogsqp trace] apply16 at k = 0 (len %d, %d rows per workgroup), 10 ns ticks: header %lld loads %lld " \
+                        "product-1 %lld barrier %lld products-2,3 %lld stores %lld\n", len16, rpg, tr[0], tr[1], tr[2],  \
+                tr[3], tr[4], tr[5]);                                                                                    \
+        if (qp->lq_ahead) {                                                                                              \
+            Lq16Panel hp;                                                                                                \
+            OG_HIP(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_head16_trace), sizeof tr));                                      \
+            OG_HIP(hipMemcpy(&hp, pnxt, sizeof(Lq16Panel), hipMemcpyDeviceToHost));                                      \
+            fprintf(stderr, "[ogsqp trace] head workgroup 0, 10 ns ticks: header %lld loads %lld product-1 %lld barrier %lld " \
+                            "exchange %lld products-2,3 + stores issued %lld drain %lld; its panel (shader clocks): load %lld " \
+                            "publish %lld barrier1 %lld products %lld barrier2 %lld update %lld store %lld\n", tr[0], tr[1],  \
+                    tr[2], tr[3], tr[6], tr[4], tr[5], hp.tr[0], hp.tr[1], hp.tr[2], hp.tr[3], hp.tr[4], hp.tr[5], hp.tr[6]); \
+        }                                                                                                                \
+    }
+#else
+#define OG_APPLY16_TRACE() do { } while (0)
+#endif
                 if (qp->lq_ahead && k + LQ16 < msweep) {
-                    // the trailing update's first workgroup factors the next panel on the side (k_lq_step16)
+                    // the launch of the trailing update factors the next panel on the side (k_lq_step16)
 #define OG_STEP16(U, E)                                                                                           \
-    hipLaunchKernelGGL((k_lq_step16<U, E>), dim3((nrows16 + 15) / 16), dim3(64 * A16_WAVES),                       \
-                       (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, qp->Jw, ldw, msweep, nq, k, (const double*)Vcur, ldw, \
-                       (const Lq16Panel*)pcur, Vnxt, pnxt, qp->diagL, qp->dthresh + 1)
+    hipLaunchKernelGGL((k_lq_step16<U, E>), dim3(1 + LQ_HEADS + (std::max(nrows16 - LQ16, 0) + rpg - 1) / rpg),        \
+                       dim3(64 * A16_WAVES), (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, qp->Jw, ldw, msweep, nq, k,   \
+                       (const double*)Vcur, ldw, (const Lq16Panel*)pcur, Vnxt, pnxt, qp->diagL, qp->dthresh + 1, rpg,      \
+                       qp->lq_go, (qp->lq_token += LQ_HEADS), qp->lq_wpart, qp->flag + 2)
                     if (ub <= 2) OG_STEP16(2, 2);
                     else if (ub <= 4) OG_STEP16(4, 2);
                     else if (ub <= 8) OG_STEP16(8, 4);
                     else if (ub <= 12) OG_STEP16(12, 6);
                     else OG_STEP16(16, 8);
 #undef OG_STEP16
+                    OG_APPLY16_TRACE();
                     factored = k + LQ16;
                     std::swap(Vcur, Vnxt);
                     std::swap(pcur, pnxt);
@@ -2575,14 +2618,15 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
                     continue;
                 }
 #define OG_APPLY16(U)                                                                                            \
-    hipLaunchKernelGGL(k_lq_apply16<U>, dim3((nrows16 + 15) / 16), dim3(64 * A16_WAVES), 0, s, qp->Tc, qp->Jw, ldw, msweep, \
-                       nq, k, (const double*)Vcur, ldw, (const Lq16Panel*)pcur)
+    hipLaunchKernelGGL(k_lq_apply16<U>, dim3((nrows16 + rpg - 1) / rpg), dim3(64 * A16_WAVES), 0, s, qp->Tc, qp->Jw, ldw, msweep, \
+                       nq, k, (const double*)Vcur, ldw, (const Lq16Panel*)pcur, rpg)
                 if (ub <= 2) OG_APPLY16(2);
                 else if (ub <= 4) OG_APPLY16(4);
                 else if (ub <= 8) OG_APPLY16(8);
                 else if (ub <= 12) OG_APPLY16(12);
                 else OG_APPLY16(16);
 #undef OG_APPLY16
+                OG_APPLY16_TRACE();
                 k += LQ16;
                 continue;
             }
@@ -2637,9 +2681,11 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     // ---- equality-constrained minimiser: L w1 = -c,  deq = J1 w1 - Y (Y'g)
     OG_STAGE("trsv w1");
     if (meq) launch_trsv(qp, ldw, meq, 0, -1.0, qp->c, qp->w1, s);
-    int hflag[2] = {0, 0};
-    OG_HIP(hipMemcpyAsync(hflag, qp->flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    int hflag[4] = {0, 0, 0, 0};
+    OG_HIP(hipMemcpyAsync(hflag, qp->flag, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     OG_HIP(hipStreamSynchronize(s));
+    if (hflag[2])
+        return fail(7, "og_qp_solve_dev: a look-ahead workgroup of the LQ sweep never saw the others finish (internal error)");
     if (hflag[0]) {                       // a dependent equality row that contradicts the others
         *status = OG_QP_SINGULAR_C;
         return 0;

@@ -47,7 +47,9 @@ __device__ __forceinline__ double oct_sum(double v) {
 // E: groups of 4 columns per lane (rows of up to 256 E entries from the panel's first column on).  Lane l of every
 // wavefront holds the rows 2 (l / 8) and 2 (l / 8) + 1 on its columns: the reflector vector is read from LDS once
 // per lane and step and serves both, in the products and in the update.
-template <int E>
+// COHERENT: the rows were written earlier in the SAME launch by other workgroups (k_lq_step16) with agent-scope
+// stores; they are read past this XCD's L2 the same way.
+template <int E, bool COHERENT = false>
 __device__ __forceinline__ void lq_panel16_body(double* __restrict__ Tc, int ld, int mrows, int nq, int k,
                                                 double* __restrict__ V, int ldv, double* __restrict__ diagL,
                                                 Lq16Panel* __restrict__ panel, double* __restrict__ dmaxbuf,
@@ -79,7 +81,14 @@ __device__ __forceinline__ void lq_panel16_body(double* __restrict__ Tc, int ld,
         for (int e = 0; e < E; ++e) {
             // one 32-byte load (rows are 128-byte aligned from column k on; no branch: the loads go out together)
             const int j = 4 * (64 * e + slot);
-            const dbl4 v = *(const dbl4*)(row + min(j, 4 * ((L - 1) / 4)));
+            const double* src = row + min(j, 4 * ((L - 1) / 4));
+            dbl4 v;
+            if (COHERENT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                v = *(const dbl4*)src;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[h][e][i] = (r < nb && j + i < L) ? v[i] : 0.0;
         }
@@ -269,26 +278,74 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16(double* __restrict__
 // stands for which column as long as both operands agree; the products below are indexed accordingly.)  Every
 // global load of a phase is issued before the first result is used.
 constexpr int A16_WAVES = 8;
-template <int U>
+#ifdef OGSQP_TRACE
+__device__ long long g_apply16_trace[8];     // s_memrealtime ticks (10 ns) per section, one workgroup of the last launch
+__device__ long long g_head16_trace[8];      // ... of head workgroup 0 of the last look-ahead launch
+#define A16MARK(slot_) do { const long long now_ = __builtin_amdgcn_s_memrealtime(); t_sec[slot_] += now_ - t_mark; t_mark = now_; } while (0)
+#else
+#define A16MARK(slot_) do { } while (0)
+#endif
+// HEAD (look-ahead, k_lq_step16): this workgroup is one of LQ_HEADS that share the 16 rows of the NEXT panel by
+// COLUMNS (blocks uoff, uoff + ustride, ... per wavefront): their partial products W' meet in `wpart` (agent-scope
+// stores and loads, a count in `cnt`), and the rows go out with agent-scope stores for the panel workgroup.
+// LDS of the trailing update (declared once per kernel: the look-ahead kernel instantiates the body twice)
+struct A16Shared {
+    double w[A16_WAVES][64][4];                                     // partial W' of the wavefronts
+    __attribute__((aligned(32))) double v[A16_WAVES][16][16];       // one 16 x 16 block of V per wavefront
+};
+struct Lq16Head {
+    double* wpart;           // LQ_HEADS x 64 x 4
+    unsigned* cnt;
+    unsigned expect;
+    int h;
+    int* lost;               // set when the wait below gives up (the host then fails the solve)
+};
+// wait (one thread) until *word has reached `expect`; bounded - a workgroup that never comes would otherwise hang the
+// device - and a wait that gives up says so
+__device__ __forceinline__ void lq_wait_for(unsigned* word, unsigned expect, int* lost) {
+    int spins = 0;
+    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
+        if (++spins > (1 << 22)) {
+            __hip_atomic_store(lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+constexpr int LQ_HEADS = 8;
+template <int U, bool HEAD = false>
 __device__ __forceinline__ void lq_apply16_body(double* __restrict__ Tc, double* __restrict__ Jw, int ld, int mrows, int nq,
                                                 int k, const double* __restrict__ V, int ldv,
-                                                const Lq16Panel* __restrict__ panel, const int group) {
-    __shared__ double s_w[A16_WAVES][64][4];
+                                                const Lq16Panel* __restrict__ panel, const int r0, const int rcount,
+                                                A16Shared& sh, const int uoff = 0, const int ustride = 1,
+                                                const Lq16Head head = Lq16Head()) {
+    constexpr bool COHERENT = HEAD;
+    double (&s_w)[A16_WAVES][64][4] = sh.w;
+    double (&s_v)[A16_WAVES][16][16] = sh.v;
+#define A16_BLOCK(u_) (wv + A16_WAVES * (uoff + ustride * (u_)))
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
+#ifdef OGSQP_TRACE
+    long long t_mark = __builtin_amdgcn_s_memrealtime();
+    long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const int nb = panel->nb, L = nq - k;
+    A16MARK(0);   // panel header
     const int nblk = (L + 15) / 16;
     const int below = mrows - k - nb, nrows = below + nq;
-    const int r = group * 16 + n;
-    const bool valid = r < nrows;
-    const int rc = valid ? r : nrows - 1;
+    // rows r0 .. r0 + rcount - 1 (rcount <= 16: fewer rows per workgroup when 16 would leave compute units idle -
+    // a workgroup streams at what ONE unit's miss queue sustains, ~26 GB/s); the other lanes repeat a row of the
+    // group (same cache lines, nothing stored)
+    const int r = r0 + n;
+    const bool valid = n < rcount && r < nrows;
+    const int rc = valid ? r : min(r0 + n % rcount, nrows - 1);
     double* row = (rc < below ? Tc + (long)(k + nb + rc) * ld : Jw + (long)(rc - below) * ld) + k;
     // my row's segment: blocks wv, wv + 8, ...
     dbl4 x[U], a[U];
     const double* vrow = V + (long)n * ldv;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int b = min(wv + A16_WAVES * u, nblk - 1);
+        const int b = min(A16_BLOCK(u), nblk - 1);
         x[u] = *(const dbl4*)(row + 16 * b + 4 * g);
         a[u] = *(const dbl4*)(vrow + 16 * b + 4 * g);
     }
@@ -296,9 +353,13 @@ __device__ __forceinline__ void lq_apply16_body(double* __restrict__ Tc, double*
     // W' = V X' (reflector 4 i + g in register i, matrix row n); K slot g of MFMA (u, i) is the column 16 b + 4 g + i
     // (four accumulators: a dependent MFMA is 27 ns, four chains run at the issue rate)
     d4 accs[4] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+#ifdef OGSQP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    A16MARK(1);   // loads of the row segments and of V
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int j0 = 16 * (wv + A16_WAVES * u) + 4 * g;
+        const int j0 = 16 * A16_BLOCK(u) + 4 * g;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool in = j0 + i < L;
@@ -309,19 +370,23 @@ __device__ __forceinline__ void lq_apply16_body(double* __restrict__ Tc, double*
     d4 acc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (accs[0][i] + accs[1][i]) + (accs[2][i] + accs[3][i]);
-    // the operands of the last product (V once more, reflector-major: M row m of block b is the column
-    // 16 b + 4 (m & 3) + (m >> 2), so that the result lands in the layout the segment is held in) are requested
-    // before the exchange
+    // the operands of the last product are V once more, reflector-major: M row m of block b is the column
+    // 16 b + 4 (m & 3) + (m >> 2), so that the result lands in the layout the segment is held in.  They are NOT
+    // read again (a second read of V was a third of this workgroup's traffic): the block this wavefront holds -
+    // lane (n, g): V[n][16 b + 4 g + i] - goes through a 2 KB tile of LDS of its own and comes back as
+    // V[4 t + g][16 b + pm]
     const int pm = 4 * (n & 3) + (n >> 2);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int b = min(wv + A16_WAVES * u, nblk - 1);
+        const int j0 = 16 * A16_BLOCK(u) + 4 * g;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[u][t] = V[(long)(4 * t + g) * ldv + 16 * b + pm];
+        for (int i = 0; i < 4; ++i) a[u][i] = j0 + i < L ? a[u][i] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_w[wv][lane][i] = acc[i];
+    A16MARK(2);   // first product
     __syncthreads();
+    A16MARK(3);   // barrier
     double wt[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -329,6 +394,30 @@ __device__ __forceinline__ void lq_apply16_body(double* __restrict__ Tc, double*
 #pragma unroll
         for (int w8 = 0; w8 < A16_WAVES; ++w8) sum += s_w[w8][lane][i];
         wt[i] = sum;
+    }
+    if (HEAD) {
+        // the other head workgroups' columns: partial sums through memory, in the order of the workgroups
+        if (wv == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __hip_atomic_store(head.wpart + ((long)head.h * 64 + lane) * 4 + i, wt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(head.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lq_wait_for(head.cnt, head.expect, head.lost);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double sum = 0.0;
+#pragma unroll
+            for (int hh = 0; hh < LQ_HEADS; ++hh)
+                sum += __hip_atomic_load(head.wpart + ((long)hh * 64 + lane) * 4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wt[i] = sum;
+        }
+        A16MARK(6);   // partial products of the other head workgroups
     }
     // Z' = T' W': A (m' = n, k = 4 t + g) = T[4 t + g][n], B = register t of W'
     d4 z = d4{0.0, 0.0, 0.0, 0.0};
@@ -340,53 +429,102 @@ __device__ __forceinline__ void lq_apply16_body(double* __restrict__ Tc, double*
     // register i of lane (n, g) = M row 4 i + g = column 16 b + 4 g + i of matrix row n
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const bool in = 16 * (wv + A16_WAVES * u) + pm < L;
+        // (LDS operations of one wavefront execute in order: the fences only keep the compiler from reordering)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        *(dbl4*)&s_v[wv][n][4 * g] = a[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double vt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vt[t] = s_v[wv][4 * t + g][pm];
         d4 o = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? a[u][t] : 0.0, z[t], o, 0, 0, 0);
+        for (int t = 0; t < 4; ++t) o = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[t], z[t], o, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[u][i] -= o[i];
-    }
-    if (!valid) return;
+        // block u goes out while the matrix cores work on block u + 1 (measured with -DOGSQP_TRACE at C3: the loads
+        // take 10 us, the stores 6-7 us at the chip's HBM rate, this loop 4.8 us of MFMA issue - one after the other
+        // they added up)
+        const int j0 = 16 * A16_BLOCK(u) + 4 * g;
+        if (valid) {
+            if (COHERENT) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j0 = 16 * (wv + A16_WAVES * u) + 4 * g;
-        if (j0 + 3 < L) {
-            *(dbl4*)(row + j0) = x[u];
-        } else {
+                for (int i = 0; i < 4; ++i)
+                    if (j0 + i < L) __hip_atomic_store(row + j0 + i, x[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (j0 + 3 < L) {
+                *(dbl4*)(row + j0) = x[u];
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (j0 + i < L) row[j0 + i] = x[u][i];
+                for (int i = 0; i < 4; ++i)
+                    if (j0 + i < L) row[j0 + i] = x[u][i];
+            }
         }
     }
+    A16MARK(4);   // T product, tiles, last product, stores issued
+#ifdef OGSQP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    A16MARK(5);   // stores
+    if (!HEAD && r0 >= 5 * rcount && r0 < 6 * rcount && tid == 0)
+        for (int e = 0; e < 8; ++e) g_apply16_trace[e] = t_sec[e];
+    if (HEAD && head.h == 0 && tid == 0)
+        for (int e = 0; e < 8; ++e) g_head16_trace[e] = t_sec[e];
+#endif
+#undef A16_BLOCK
 }
 
 template <int U>
 __global__ __launch_bounds__(64 * A16_WAVES) void k_lq_apply16(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
                                                               int mrows, int nq, int k, const double* __restrict__ V,
-                                                              int ldv, const Lq16Panel* __restrict__ panel) {
-    lq_apply16_body<U>(Tc, Jw, ld, mrows, nq, k, V, ldv, panel, (int)blockIdx.x);
+                                                              int ldv, const Lq16Panel* __restrict__ panel, int rpg) {
+    __shared__ A16Shared sh;
+    lq_apply16_body<U>(Tc, Jw, ld, mrows, nq, k, V, ldv, panel, (int)blockIdx.x * rpg, rpg, sh);
 }
 
-// Look-ahead inside one launch: the trailing update of panel k, whose first workgroup - its 16 rows are the rows
-// of panel k + 16 - goes on to factor that panel (into the other reflector buffer) while the rest of the chip
-// finishes the update.  The panel factorisation is one workgroup's latency chain (26-33 us) and the update the
-// whole chip's bandwidth (21-30 us): run one after the other they idle each other's resource.  Same arithmetic,
-// row for row, as k_lq_apply16 followed by k_lq_panel16.
+// Look-ahead inside one launch.  The panel factorisation is one workgroup's latency chain (26-33 us) and the
+// trailing update the whole chip's bandwidth (21-29 us); run one after the other they idle each other's resource.
+// Here the launch that applies panel k also factors panel k + 16 (into the other reflector buffer):
+//   workgroups 1 .. LQ_HEADS  update the 16 rows of the next panel, an eighth of the COLUMNS each.  (A workgroup
+//                             streams at what ONE compute unit's miss queue sustains, ~38 GB/s measured, and issues
+//                             its 96 MFMAs per SIMD at one per 27 ns: all 16 rows in one workgroup take as long as the
+//                             whole update (22-27 us), two rows per workgroup still 15 us because every one of them
+//                             reads all of V and runs all of the MFMAs.)  Their partial products meet in memory
+//                             (Lq16Head), the rows go out with agent-scope stores, and they count themselves done;
+//   workgroup 0               waits for that count (the eight are resident before any other workgroup of the launch and
+//                             wait only for each other), reads the rows past its L2 and factors the panel;
+//   the others                the rest of the update, rpg rows each.
+// The head rows' W' is summed in another order than k_lq_apply16 sums it (eight column slices instead of eight
+// wavefronts): same reflectors to rounding, not to the bit.
 template <int U, int E>
 __global__ __launch_bounds__(64 * A16_WAVES) void k_lq_step16(double* __restrict__ Tc, double* __restrict__ Jw, int ld,
                                                              int mrows, int nq, int k, const double* __restrict__ V,
                                                              int ldv, const Lq16Panel* __restrict__ panel,
                                                              double* __restrict__ Vnext, Lq16Panel* __restrict__ pnext,
-                                                             double* __restrict__ diagL, double* __restrict__ dmaxbuf) {
+                                                             double* __restrict__ diagL, double* __restrict__ dmaxbuf, int rpg,
+                                                             unsigned* __restrict__ sync, unsigned expect,
+                                                             double* __restrict__ wpart, int* __restrict__ lost) {
     extern __shared__ double lds[];
+    __shared__ A16Shared sh;
     static_assert(64 * A16_WAVES == P16_THREADS, "one workgroup shape for both roles");
-    lq_apply16_body<U>(Tc, Jw, ld, mrows, nq, k, V, ldv, panel, (int)blockIdx.x);
-    if (blockIdx.x != 0) return;
-    // my own stores to the next panel's rows, seen by every wavefront of this workgroup
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    lq_panel16_body<E>(Tc, ld, mrows, nq, k + LQ16, Vnext, ldv, diagL, pnext, dmaxbuf, lds);
+    constexpr int UH = (U + LQ_HEADS - 1) / LQ_HEADS;
+    // (the heads come first in the grid: they are dispatched before everything else and start together)
+    const int b = (int)blockIdx.x == LQ_HEADS ? 0 : (int)blockIdx.x < LQ_HEADS ? (int)blockIdx.x + 1 : (int)blockIdx.x;
+    if (b == 0) {
+        if (threadIdx.x == 0) lq_wait_for(sync + 1, expect, lost);
+        __syncthreads();
+        lq_panel16_body<E, true>(Tc, ld, mrows, nq, k + LQ16, Vnext, ldv, diagL, pnext, dmaxbuf, lds);
+    } else if (b <= LQ_HEADS) {
+        Lq16Head head;
+        head.wpart = wpart;
+        head.cnt = sync;
+        head.expect = expect;
+        head.h = b - 1;
+        head.lost = lost;
+        lq_apply16_body<UH, true>(Tc, Jw, ld, mrows, nq, k, V, ldv, panel, 0, LQ16, sh, b - 1, LQ_HEADS, head);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wavefront: its stores have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        lq_apply16_body<U>(Tc, Jw, ld, mrows, nq, k, V, ldv, panel, LQ16 + (b - 1 - LQ_HEADS) * rpg, rpg, sh);
+    }
 }
-

@@ -14,6 +14,6 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:14]:
     import re
-    nm=re.search(r"(k_\w+|ogk_\w+|__amd\w+)", r["Name"]); nm=nm.group(1) if nm else r["Name"][:34]
+    nm=re.search(r"((k_\w+|ogk_\w+|__amd\w+)(<[\d, ]+>)?)", r["Name"]); nm=nm.group(1) if nm else r["Name"][:34]
     print("%-22s calls %7s total %9.2f ms avg %9.2f us  %5.1f%%"%(nm[:22], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e3, 100*float(r["TotalDurationNs"])/tot))
 PY

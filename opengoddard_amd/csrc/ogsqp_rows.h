@@ -114,6 +114,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
     __shared__ double redv[ROWS_WAVES];
     __shared__ int redi[ROWS_WAVES];
     __shared__ double red[ROWS_WAVES];
+    __shared__ double red2[2 * ROWS_WAVES];
     __shared__ int s_last;
     const GiArgs& g = a.g;
     GiState* st = g.st;
@@ -124,10 +125,21 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
 #else
 #define RMARK(slot_) do { } while (0)
 #endif
-    const int phase = st->phase;
-    if (phase >= 2) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
     const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
+    // the partial results of the pricing are requested together with the state word (they are only looked at in
+    // phase 0): one round trip instead of two.  At most 2048 of them - the grid of k_rows_apply
+    constexpr int PRE = 8;
+    double ppv[PRE];
+    int ppi[PRE];
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) {
+        const int b = tid + ROWS_THREADS * c;
+        ppv[c] = a.price[b < a.G2 ? b : 0].value;
+        ppi[c] = a.price[b < a.G2 ? b : 0].index;
+    }
+    const int phase = st->phase;
+    if (phase >= 2) return;
     const int q = st->q;
     RMARK(0);   // state word
     double* d = lds;                  // nr: incoming normal
@@ -226,15 +238,15 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
     // its address is known and in every workgroup - the lists and the multipliers of the active rows and y for the
     // decision (PRE entries per thread in registers; longer lists fall back to loading late), the first rows of the
     // inverse - so that the workgroup that draws the last ticket has one round trip left: the others' shares of r
-    // and of the ratio test.  Measured (-DOGSQP_TRACE, tools/sqp_trace.sh; C3, first subproblems): 12.4 us per
-    // change in this kernel either way - state word 0.5, price election 3.5 (875 partials, and the wait for the
-    // early loads lands here), normal into LDS 1.1, norms 0.8, inverse rows x d1 1.1, stores + ticket 1.7, the
-    // others' r 1.3, u and y 1.0, reflector and lists 1.1: nine barrier-separated steps of about a microsecond
-    // (a workgroup reduction is 0.4 us, a global round trip 0.7-1), of which the early loads hide none that the
-    // in-order wait of the next step does not give back.
-    constexpr int PRE = 8;
+    // and of the ratio test.  Measured (-DOGSQP_TRACE, tools/sqp_trace.sh; C3, first subproblems): 11.3 us per change
+    // in this kernel (12.4 before the requests were ordered by who is waited for first) - state word 0.5, price
+    // election 2.2 (875 partials), normal into LDS 2.0, norms 0.4, inverse rows x d1 1.1, stores + ticket 1.8, the
+    // others' r 1.4, u and y 1.0, reflector and lists 1.0.  What is left is the chain itself: state -> price -> row p
+    // -> (product) -> store acknowledged -> ticket -> the others' r, six dependent trips through memory of about a
+    // microsecond each (agent-scope traffic goes past the L2), and seven workgroup reductions of 0.4 us.
     int pact[PRE], pslot[PRE];
     double pu[PRE], py[PRE];
+    const int fresh_slot = a.slot[q < qcap ? q : 0];          // storage row of position q, should a row join
 #pragma unroll
     for (int c = 0; c < PRE; ++c) {
         const int jj = tid + ROWS_THREADS * c;
@@ -251,23 +263,21 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         fslot[e] = a.slot[i < q ? i : (ifirst < q ? ifirst : 0)];
         fact[e] = g.act[i < q ? i : (ifirst < q ? ifirst : 0)];
     }
-    // ... and the first RPRE * 64 entries of those rows themselves (their addresses do not depend on who comes in)
-    constexpr int RPRE = 8;
-    double rpre[4][RPRE];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const double* rowe = RI + (long)fslot[e] * qcap;
-#pragma unroll
-        for (int c = 0; c < RPRE; ++c) {
-            const int j = lane + 64 * c;
-            rpre[e][c] = rowe[j < q ? j : 0];
-        }
-    }
     int p;
     if (phase == 0) {
         double v = INFINITY;
         int idx = 0x7fffffff;
-        for (int b = tid; b < a.G2; b += ROWS_THREADS) {
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) {
+            const bool in = tid + ROWS_THREADS * c < a.G2;
+            const double pv = in ? ppv[c] : INFINITY;
+            const int pi = in ? ppi[c] : 0x7fffffff;
+            if (pv < v || (pv == v && pi < idx)) {
+                v = pv;
+                idx = pi;
+            }
+        }
+        for (int b = tid + ROWS_THREADS * PRE; b < a.G2; b += ROWS_THREADS) {
             const double pv = a.price[b].value;
             const int pi = a.price[b].index;
             if (pv < v || (pv == v && pi < idx)) {
@@ -285,6 +295,19 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         p = st->p;
     }
     RMARK(1);   // who comes in
+    // the first RPRE * 64 entries of my first rows of the inverse (their addresses do not depend on who comes in;
+    // the list entries they hang on have arrived during the election)
+    constexpr int RPRE = 8;
+    double rpre[4][RPRE];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double* rowe = RI + (long)fslot[e] * qcap;
+#pragma unroll
+        for (int c = 0; c < RPRE; ++c) {
+            const int j = lane + 64 * c;
+            rpre[e][c] = rowe[j < q ? j : 0];
+        }
+    }
     const int iters = st->iters + 1;
     const bool broken = iters > g.limit || q > nr || q > qcap || p < 0 || p >= mg + 2 * nq;
     const int psafe = broken ? 0 : p;
@@ -308,8 +331,20 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         part_nn += v * v;
         if (i >= q) part_zz += v * v;
     }
-    const double zz = block_sum(part_zz, red);
-    const double nn = block_sum(part_nn, red);
+    // (one exchange for both: each the sum of its wavefronts' sums in their order, as block_sum has it)
+    part_zz = wave_sum(part_zz);
+    part_nn = wave_sum(part_nn);
+    if (lane == 0) {
+        red2[wave] = part_zz;
+        red2[ROWS_WAVES + wave] = part_nn;
+    }
+    __syncthreads();
+    double zz = 0.0, nn = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < ROWS_WAVES; ++wv) {
+        zz += red2[wv];
+        nn += red2[ROWS_WAVES + wv];
+    }
     RMARK(3);   // |d2|, |d|
     // ---- my rows of the inverse: dual direction and ratio test ------------------------------------------------
     {
@@ -480,18 +515,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         rec.beta = vv > 0.0 ? 2.0 / vv : 0.0;
         double* RIw = g.RI[0];
         const double inv = 1.0 / alpha;
-        // the storage row of position q: slot[q], among the preloaded entries when q < PRE * ROWS_THREADS
-        __shared__ int s_fresh;
-        if (q >= PRE * ROWS_THREADS) {
-            if (tid == 0) s_fresh = a.slot[q];
-        } else if (tid == (q % ROWS_THREADS)) {
-            int sl = 0;
-#pragma unroll
-            for (int c = 0; c < PRE; ++c) sl = (q / ROWS_THREADS == c) ? pslot[c] : sl;
-            s_fresh = sl;
-        }
-        __syncthreads();
-        double* fresh = RIw + (long)s_fresh * qcap;
+        double* fresh = RIw + (long)fresh_slot * qcap;
 #pragma unroll
         for (int c = 0; c < PRE; ++c) {
             const int i = tid + ROWS_THREADS * c;

@@ -312,7 +312,10 @@ __device__ __forceinline__ void lq_wait_for(unsigned* word, unsigned expect, int
         __builtin_amdgcn_s_sleep(1);
     }
 }
-constexpr int LQ_HEADS = 8;
+#ifndef OGSQP_LQ_HEADS
+#define OGSQP_LQ_HEADS 8
+#endif
+constexpr int LQ_HEADS = OGSQP_LQ_HEADS;
 template <int U, bool HEAD = false>
 __device__ __forceinline__ void lq_apply16_body(double* __restrict__ Tc, double* __restrict__ Jw, int ld, int mrows, int nq,
                                                 int k, const double* __restrict__ V, int ldv,

@@ -572,6 +572,45 @@ def test_gpu_warm_started_active_set_reaches_the_same_solution():
 
 
 @pytest.mark.gpu
+def test_gpu_lq_sweep_forms_agree(monkeypatch):
+    """The three forms of the LQ sweep - 16-reflector panels with the next panel factored during the trailing update
+    (default: k_lq_step16, head workgroups + panel workgroup inside one launch), the same panels as separate
+    launches (OGSQP_LQ=16) and round 2's 8-reflector panels (OGSQP_LQ=8) - are the same Householder sweep with sums
+    in different orders: the same step to rounding, the same active set and number of changes, on random problems
+    with several panels and on the baseline configuration's first subproblem shape (n = 500, 300 equalities)."""
+    rng = np.random.default_rng(23)
+    cases = [(int(rng.integers(40, 130)), None, None) for _ in range(6)] + [(500, 300, 240)]
+    for n, meq, mg in cases:
+        meq = int(rng.integers(n // 3, 2 * n // 3)) if meq is None else meq
+        mg = int(rng.integers(1, n)) if mg is None else mg
+        Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+        A, cc = np.vstack([C, G]), np.concatenate([c, h])
+        results = {}
+        for form in ("ahead", "16", "8"):
+            if form == "ahead":
+                monkeypatch.delenv("OGSQP_LQ", raising=False)
+            else:
+                monkeypatch.setenv("OGSQP_LQ", form)
+            core = _sqp_native.QpCore(n, meq, mg)            # the switch is read when the handle is made
+            core.set_factor(Z)
+            d, mult, bm, status, iters = core.solve(A, g, cc, lb, ub)
+            results[form] = (d, mult, status, iters, sorted(core.get_active().tolist()))
+            # the same handle again: the counters of the look-ahead start over with every sweep
+            core.set_factor(Z)
+            core.set_active()
+            d2, _, _, status2, iters2 = core.solve(A, g, cc, lb, ub)
+            assert status2 == status and iters2 == iters and np.array_equal(d2, d)
+            core.close()
+        d0, m0, s0, i0, a0 = results["ahead"]
+        assert s0 == 1
+        for form in ("16", "8"):
+            d, mult, status, iters, active = results[form]
+            assert (status, iters, active) == (s0, i0, a0), (n, meq, mg, form)
+            assert np.max(np.abs(d - d0)) <= 1e-11 * max(1.0, np.abs(d0).max())
+            assert np.max(np.abs(mult - m0)) <= 1e-9 * max(1.0, np.abs(m0).max())
+
+
+@pytest.mark.gpu
 def test_device_resident_jacobian_equals_host_staged():
     """og_qp_solve_dev on the Jacobian the sweep kernel left in HBM == og_qp_solve on its host copy;
     og_jt_times gives the cost gradient and the gradient of the Lagrangian."""

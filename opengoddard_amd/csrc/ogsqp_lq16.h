@@ -48,7 +48,9 @@ __device__ __forceinline__ double oct_sum(double v) {
 // wavefront holds the rows 2 (l / 8) and 2 (l / 8) + 1 on its columns: the reflector vector is read from LDS once
 // per lane and step and serves both, in the products and in the update.
 // COHERENT: the rows were written earlier in the SAME launch by other workgroups (k_lq_step16) with agent-scope
-// stores; they are read past this XCD's L2 the same way.
+// (write-through) stores and the caller has seen their count: an agent-scope acquire fence drops whatever this
+// compute unit and its XCD's L2 may still hold of them, then they are read like any rows (48 eight-byte
+// agent-scope loads per lane instead took 4 us where the plain 32-byte loads take 1.3).
 template <int E, bool COHERENT = false>
 __device__ __forceinline__ void lq_panel16_body(double* __restrict__ Tc, int ld, int mrows, int nq, int k,
                                                 double* __restrict__ V, int ldv, double* __restrict__ diagL,
@@ -73,6 +75,7 @@ __device__ __forceinline__ void lq_panel16_body(double* __restrict__ Tc, int ld,
 #define P16MARK(slot_) do { } while (0)
 #endif
     double x[2][E][4];
+    if (COHERENT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int r = 2 * rp + h;
@@ -82,13 +85,7 @@ __device__ __forceinline__ void lq_panel16_body(double* __restrict__ Tc, int ld,
             // one 32-byte load (rows are 128-byte aligned from column k on; no branch: the loads go out together)
             const int j = 4 * (64 * e + slot);
             const double* src = row + min(j, 4 * ((L - 1) / 4));
-            dbl4 v;
-            if (COHERENT) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                v = *(const dbl4*)src;
-            }
+            const dbl4 v = *(const dbl4*)src;
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[h][e][i] = (r < nb && j + i < L) ? v[i] : 0.0;
         }
@@ -201,27 +198,8 @@ __device__ __forceinline__ void lq_panel16_body(double* __restrict__ Tc, int ld,
             P16MARK(5);   // scalars + update
         }
     }
-    // V (zero rows beyond nb), the finished entries of L, the diagonal
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = 2 * rp + h;
-        double* vout = V + (long)r * ldv;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int j = 4 * (64 * e + slot);
-            if (j + 3 < L) {
-                dbl4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = r < nb ? x[h][e][i] : 0.0;
-                *(dbl4*)(vout + j) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (j + i < L) vout[j + i] = r < nb ? x[h][e][i] : 0.0;
-            }
-        }
-    }
-    __syncthreads();
+    // T first, in wavefront 0 (which wrote V V' and the betas itself: no barrier), while the other wavefronts send
+    // their part of V on its way
     // T by forward accumulation; row a of T depends only on itself: thread a does row a, the row in registers and
     // the loops unrolled (entries left of the diagonal are zero, so no bound on c is needed): the LDS reads of
     // V V' have static addresses and go out ahead of the dependent multiply-adds
@@ -242,6 +220,26 @@ __device__ __forceinline__ void lq_panel16_body(double* __restrict__ Tc, int ld,
         }
 #pragma unroll
         for (int c = 0; c < LQ16; ++c) s_T[a][c] = Tr[c];
+    }
+    // V (zero rows beyond nb), the finished entries of L, the diagonal
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 2 * rp + h;
+        double* vout = V + (long)r * ldv;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int j = 4 * (64 * e + slot);
+            if (j + 3 < L) {
+                dbl4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = r < nb ? x[h][e][i] : 0.0;
+                *(dbl4*)(vout + j) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j + i < L) vout[j + i] = r < nb ? x[h][e][i] : 0.0;
+            }
+        }
     }
     __syncthreads();
     for (int e = tid; e < LQ16 * LQ16; e += P16_THREADS) {

@@ -778,12 +778,14 @@ __global__ __launch_bounds__(1024) void k_trsv(const double* __restrict__ Tc, in
 // workgroup of k_trsv at one CU's bandwidth (282 us for the 3.8 MB of L at C3).  x holds scale * rhs on entry
 // (k_trsv_prepare, which also leaves max |rhs| in scal[0]) and the solution at the end.
 __global__ __launch_bounds__(256) void k_trsv_prepare(const double* __restrict__ rhs, int meq, double scale_rhs,
-                                                      double* __restrict__ x, double* __restrict__ scal) {
+                                                      double* __restrict__ x, double* __restrict__ scal,
+                                                      double* __restrict__ pending) {
     __shared__ double red[4];
     double biggest = 0.0;
     for (int i = threadIdx.x; i < meq; i += 256) {
         const double v = scale_rhs * rhs[i];
         x[i] = v;
+        if (pending) pending[i] = __longlong_as_double(0x7ff8dead5eedcafell);     // k_trsv_chain: "not solved yet"
         biggest = fmax(biggest, fabs(v));
     }
     for (int off = 32; off > 0; off >>= 1) biggest = fmax(biggest, __shfl_xor(biggest, off));
@@ -942,6 +944,171 @@ __global__ __launch_bounds__(256) void k_trsv_block(const double* __restrict__ T
     }
     if (blockIdx.x == 0 && tid < bs) sol[i0 + tid] = xb[tid];
 }
+
+// The blocked solve as ONE launch: workgroup b owns block row b of L (64 rows) and there is no launch per block -
+// sixteen kernel boundaries and sixteen small grids at C3 (8.6 us each) become a chain of hand-offs through memory.
+// Forward (L x = rhs): workgroup b subtracts L(b, c) x_c from its right-hand side for c = 0 .. b - 1 as the x_c
+// appear, then x_b = inv(L_bb) r_b (k_trsv_invert; pivot by pivot when the block has a vanishing pivot) and publishes
+// it.  Transposed (L' x = rhs): the same from the last block down, with the tiles L(c, b)'.  Publication is the
+// solution vector itself: it starts as a NaN with a payload no computation produces (k_trsv_prepare), the owner
+// stores the values with agent scope, readers poll them with agent-scope loads.  At most 128 workgroups (n <= 8191):
+// all resident, each waits only for workgroups before it in the chain, and a wait that gives up says so (flag[2]).
+// Per block the chain pays one trip through memory and two 64 x 64 products (~2.7 us); all other tiles of a block
+// row are applied while the chain is still further up.
+constexpr unsigned long long TRSV_PENDING = 0x7ff8dead5eedcafeull;
+__global__ __launch_bounds__(256) void k_trsv_chain(const double* __restrict__ Tc, int ld, const double* __restrict__ diagL,
+                                                    int meq, int transposed, const double* __restrict__ rhs,
+                                                    double* __restrict__ sol, const double* __restrict__ scal,
+                                                    const double* __restrict__ dthresh, int* __restrict__ flag,
+                                                    const double* __restrict__ Linv, const int* __restrict__ has_gone) {
+    __shared__ double blk[64 * 65];
+    __shared__ double r[64], xs[64], xb[64];
+    __shared__ double part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (meq + 63) / 64;
+    const int b = transposed ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;     // the chain's order = the grid's
+    const int i0 = b * 64, bs = min(64, meq - i0);
+    const double tiny = dthresh[0], tol = CONSISTENT * (1.0 + scal[0]);
+    if (tid < 64) r[tid] = tid < bs ? rhs[i0 + tid] : 0.0;
+    // operands of the block's own step, requested before the chain is waited for
+    const bool gone_block = has_gone[b] != 0;
+    const double* inv = Linv + (long)b * 64 * 64;
+    double iv[16];
+    {
+        const int row = lane, q = wave;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int c0 = 16 * q + c;
+            iv[c] = transposed ? inv[(long)c0 * 64 + row] : inv[(long)row * 64 + c0];
+        }
+    }
+    // tiles of the block row (forward: L(b, c), thread = (row tid / 4, columns 16 (tid % 4) ..); transposed: L(c, b),
+    // wavefront = 16 rows of the tile, lane = column - both read 128-byte pieces of rows of L)
+    const int steps = transposed ? nblk - 1 - b : b;
+    auto load_tile = [&](int c, double (&t)[16]) {
+        if (!transposed) {
+            const int row = tid >> 2, q = tid & 3;
+            const double* src = Tc + (long)(i0 + min(row, bs - 1)) * ld + c * 64 + 16 * q;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t[e] = src[e];
+        } else {
+            const int cs = min(64, meq - c * 64);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 16 * wave + e;
+                t[e] = Tc[(long)(c * 64 + min(row, cs - 1)) * ld + i0 + min(lane, bs - 1)];
+            }
+        }
+    };
+    double tile[16];
+    if (steps > 0) load_tile(transposed ? nblk - 1 : 0, tile);
+    __syncthreads();
+    for (int sidx = 0; sidx < steps; ++sidx) {
+        const int c = transposed ? nblk - 1 - sidx : sidx;
+        const int cs = min(64, meq - c * 64);
+        double next[16];
+        if (sidx + 1 < steps) load_tile(transposed ? c - 1 : c + 1, next);
+        // x_c: wavefront 0 polls it
+        if (wave == 0) {
+            double v = 0.0;
+            int spins = 0;
+            while (true) {
+                v = lane < cs ? __hip_atomic_load(sol + c * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                const bool pending = (unsigned long long)__double_as_longlong(v) == TRSV_PENDING;
+                if (!__any(pending)) break;
+                if (++spins > (1 << 22)) {
+                    if (lane == 0) __hip_atomic_store(flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            xs[lane] = v;
+        }
+        __syncthreads();
+        if (!transposed) {
+            const int row = tid >> 2, q = tid & 3;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                a0 = fma(tile[e], xs[16 * q + e], a0);
+                a1 = fma(tile[e + 1], xs[16 * q + e + 1], a1);
+            }
+            double acc = a0 + a1;
+            acc += dpp_f64<0xB1>(acc);     // the four threads of a row are neighbours: quad sums
+            acc += dpp_f64<0x4E>(acc);
+            if (q == 0 && row < bs) r[row] -= acc;
+        } else {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                a0 = fma(tile[e], 16 * wave + e < cs ? xs[16 * wave + e] : 0.0, a0);
+                a1 = fma(tile[e + 1], 16 * wave + e + 1 < cs ? xs[16 * wave + e + 1] : 0.0, a1);
+            }
+            part[wave][lane] = a0 + a1;
+            __syncthreads();
+            if (wave == 0 && lane < bs) r[lane] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[e] = next[e];
+    }
+    // the block's own step
+    if (!gone_block) {
+        const int row = lane, q = wave;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            const int c0 = 16 * q + c;
+            acc0 = fma(iv[c], c0 < bs ? r[c0] : 0.0, acc0);
+            acc1 = fma(iv[c + 1], c0 + 1 < bs ? r[c0 + 1] : 0.0, acc1);
+        }
+        part[q][row] = acc0 + acc1;
+        __syncthreads();
+        if (wave == 0) xb[lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    } else {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int e = tid + 256 * t, rr = e >> 6, c = e & 63;
+            v[t] = Tc[(long)(i0 + min(rr, bs - 1)) * ld + i0 + c];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int e = tid + 256 * t, rr = e >> 6, c = e & 63;
+            blk[rr * 65 + c] = (rr < bs && c < rr) ? v[t] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const double dlane = lane < bs ? diagL[i0 + lane] : 1.0;
+            double xv = lane < bs ? r[lane] : 0.0;
+            if (!transposed) {
+                for (int c = 0; c < bs; ++c) {
+                    const double dc = readlane_f64(dlane, c), num = readlane_f64(xv, c);
+                    const bool gone = !(fabs(dc) > tiny);
+                    if (gone && fabs(num) > tol && lane == 0) flag[0] = 1;
+                    const double xc = gone ? 0.0 : num / dc;
+                    if (lane == c)
+                        xv = xc;
+                    else if (lane > c)
+                        xv -= blk[lane * 65 + c] * xc;
+                }
+            } else {
+                for (int c = bs - 1; c >= 0; --c) {
+                    const double dc = readlane_f64(dlane, c);
+                    const double xc = !(fabs(dc) > tiny) ? 0.0 : readlane_f64(xv, c) / dc;
+                    if (lane == c)
+                        xv = xc;
+                    else if (lane < c)
+                        xv -= blk[c * 65 + lane] * xc;
+                }
+            }
+            xb[lane] = xv;
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < bs) __hip_atomic_store(sol + i0 + lane, xb[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // out[k] = base[k] + sum_i M[i*ld + k] * x[i]   (k < ncols, i < nrows): 64 columns per workgroup,
@@ -2313,8 +2480,18 @@ int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs,
     if (!transposed)       // (the forward solve comes first in a subproblem: the inverses serve the transposed one too)
         hipLaunchKernelGGL(k_trsv_invert, dim3((meq + 63) / 64), dim3(64), 0, s, qp->Tc, ldw, qp->diagL, meq, qp->dthresh,
                            qp->Linv, qp->has_gone);
-    hipLaunchKernelGGL(k_trsv_prepare, dim3(1), dim3(256), 0, s, rhs, meq, scale_rhs, qp->trsv_work, qp->dthresh + 2);
+    static const bool per_block = getenv("OGSQP_TRSV") && std::string(getenv("OGSQP_TRSV")) == "block";
     const int nblk = (meq + 63) / 64;
+    if (!per_block && nblk <= 128 && x != rhs) {
+        // one launch: a chain of hand-offs between the block rows' workgroups (k_trsv_chain)
+        hipLaunchKernelGGL(k_trsv_prepare, dim3(1), dim3(256), 0, s, rhs, meq, scale_rhs, qp->trsv_work, qp->dthresh + 2, x);
+        hipLaunchKernelGGL(k_trsv_chain, dim3(nblk), dim3(256), 0, s, qp->Tc, ldw, qp->diagL, meq, transposed,
+                           (const double*)qp->trsv_work, x, qp->dthresh + 2, qp->dthresh, qp->flag, (const double*)qp->Linv,
+                           (const int*)qp->has_gone);
+        return 0;
+    }
+    hipLaunchKernelGGL(k_trsv_prepare, dim3(1), dim3(256), 0, s, rhs, meq, scale_rhs, qp->trsv_work, qp->dthresh + 2,
+                       (double*)nullptr);
     for (int bi = 0; bi < nblk; ++bi) {
         const int b = transposed ? nblk - 1 - bi : bi;
         const int i0 = b * 64, bs = std::min(64, meq - i0);

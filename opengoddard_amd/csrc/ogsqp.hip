@@ -2390,6 +2390,7 @@ struct og_qp_s {
     double* V16b = nullptr;            // ... of the panel the look-ahead factors during the trailing update
     Lq16Panel* panel16b = nullptr;
     bool lq_ahead = true;              // OGSQP_LQ=16: panel and trailing update as separate launches
+    int trsv_mode = 0;                 // OGSQP_TRSV: 0 one chained launch, 1 ("block") a launch per block, 2 ("single")
     unsigned* lq_go = nullptr;         // look-ahead: head workgroups that have finished the next panel's rows, ever
     unsigned lq_token = 0u;            // ... and what the count will be after the launch being enqueued
     double* lq_wpart = nullptr;        // the head workgroups' partial products (LQ_HEADS x 64 x 4)
@@ -2470,8 +2471,7 @@ int launch_gemm(og_qp_s* qp, const AView& A, int col0, int rows, int nq, int ldw
 
 int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs, const double* rhs, double* x,
                 hipStream_t s) {
-    static const bool single = getenv("OGSQP_TRSV") && std::string(getenv("OGSQP_TRSV")) == "single";
-    if (single || meq <= 128) {
+    if (qp->trsv_mode == 2 || meq <= 128) {
         const size_t trsv_lds = (size_t)(meq + 64 * 65) * sizeof(double);
         hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), trsv_lds, s, qp->Tc, ldw, qp->diagL, meq, transposed, scale_rhs,
                            rhs, x, qp->dthresh, qp->flag);
@@ -2480,9 +2480,8 @@ int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs,
     if (!transposed)       // (the forward solve comes first in a subproblem: the inverses serve the transposed one too)
         hipLaunchKernelGGL(k_trsv_invert, dim3((meq + 63) / 64), dim3(64), 0, s, qp->Tc, ldw, qp->diagL, meq, qp->dthresh,
                            qp->Linv, qp->has_gone);
-    static const bool per_block = getenv("OGSQP_TRSV") && std::string(getenv("OGSQP_TRSV")) == "block";
     const int nblk = (meq + 63) / 64;
-    if (!per_block && nblk <= 128 && x != rhs) {
+    if (qp->trsv_mode == 0 && nblk <= 128 && x != rhs) {
         // one launch: a chain of hand-offs between the block rows' workgroups (k_trsv_chain)
         hipLaunchKernelGGL(k_trsv_prepare, dim3(1), dim3(256), 0, s, rhs, meq, scale_rhs, qp->trsv_work, qp->dthresh + 2, x);
         hipLaunchKernelGGL(k_trsv_chain, dim3(nblk), dim3(256), 0, s, qp->Tc, ldw, qp->diagL, meq, transposed,
@@ -2597,6 +2596,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         const char* lq = getenv("OGSQP_LQ");
         qp->lq16 = !(lq && std::string(lq) == "8");
         qp->lq_ahead = !(lq && std::string(lq) == "16");
+        const char* tr = getenv("OGSQP_TRSV");
+        qp->trsv_mode = (tr && std::string(tr) == "block") ? 1 : (tr && std::string(tr) == "single") ? 2 : 0;
         const char* warm = getenv("OGSQP_WARM");
         qp->warm_enabled = !(warm && std::string(warm) == "0");
     }

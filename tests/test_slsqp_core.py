@@ -573,7 +573,7 @@ def test_gpu_warm_started_active_set_reaches_the_same_solution():
 
 @pytest.mark.gpu
 def test_gpu_lq_sweep_forms_agree(monkeypatch):
-    """The three forms of the LQ sweep - 16-reflector panels with the next panel factored during the trailing update
+    """(Also the three forms of the blocked triangular solves, OGSQP_TRSV.)  The three forms of the LQ sweep - 16-reflector panels with the next panel factored during the trailing update
     (default: k_lq_step16, head workgroups + panel workgroup inside one launch), the same panels as separate
     launches (OGSQP_LQ=16) and round 2's 8-reflector panels (OGSQP_LQ=8) - are the same Householder sweep with sums
     in different orders: the same step to rounding, the same active set and number of changes, on random problems
@@ -586,11 +586,13 @@ def test_gpu_lq_sweep_forms_agree(monkeypatch):
         Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
         A, cc = np.vstack([C, G]), np.concatenate([c, h])
         results = {}
-        for form in ("ahead", "16", "8"):
-            if form == "ahead":
-                monkeypatch.delenv("OGSQP_LQ", raising=False)
-            else:
+        for form in ("ahead", "16", "8", "trsv-block", "trsv-single"):
+            monkeypatch.delenv("OGSQP_LQ", raising=False)
+            monkeypatch.delenv("OGSQP_TRSV", raising=False)
+            if form in ("16", "8"):
                 monkeypatch.setenv("OGSQP_LQ", form)
+            elif form.startswith("trsv-"):               # the triangular solves: one chained launch (default) / per block / one workgroup
+                monkeypatch.setenv("OGSQP_TRSV", form[5:])
             core = _sqp_native.QpCore(n, meq, mg)            # the switch is read when the handle is made
             core.set_factor(Z)
             d, mult, bm, status, iters = core.solve(A, g, cc, lb, ub)
@@ -603,7 +605,7 @@ def test_gpu_lq_sweep_forms_agree(monkeypatch):
             core.close()
         d0, m0, s0, i0, a0 = results["ahead"]
         assert s0 == 1
-        for form in ("16", "8"):
+        for form in ("16", "8", "trsv-block", "trsv-single"):
             d, mult, status, iters, active = results[form]
             assert (status, iters, active) == (s0, i0, a0), (n, meq, mg, form)
             assert np.max(np.abs(d - d0)) <= 1e-11 * max(1.0, np.abs(d0).max())

@@ -414,6 +414,36 @@ def test_gpu_qp_relaxed_incompatible_and_singular_cases(update, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("trsv", ["chain", "block"])
+def test_gpu_redundant_equality_in_the_blocked_triangular_solves(trsv, monkeypatch):
+    """More than 128 equalities: the triangular solves run blocked (64 x 64 inverse blocks; one chained launch, or one
+    launch per block).  An equality that repeats an earlier one leaves a vanishing pivot inside a block - that block
+    goes pivot by pivot: the repetition is dropped (zero multiplier, every constraint satisfied, the restatement's
+    step), a contradicting repetition is "singular matrix C" - with the dependent row in the first, a middle and
+    the last block."""
+    if trsv == "block":
+        monkeypatch.setenv("OGSQP_TRSV", "block")
+    rng = np.random.default_rng(31)
+    n, meq, mg = 320, 200, 40
+    Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+    for where, src in ((30, 3), (100, 70), (199, 150)):
+        for shift, expect in ((0.0, 1), (0.5, 6)):
+            C3, c3 = C.copy(), c.copy()
+            C3[where] = 2.0 * C[src]
+            c3[where] = 2.0 * c[src] + shift
+            ref = slsqp_np.qp_solve(Z, g, C3, c3, G, h, lb, ub, lq="lapack")
+            core = _sqp_native.QpCore(n, meq, mg)
+            core.set_factor(Z)
+            dd, mult, bm, status, _ = core.solve(np.vstack([C3, G]), g, np.concatenate([c3, h]), lb, ub)
+            assert status == ref[3] == expect, (where, shift)
+            if expect == 1:
+                assert np.max(np.abs(dd - ref[0])) <= 1e-9 * max(1.0, np.abs(ref[0]).max())
+                assert np.max(np.abs(C3 @ dd + c3)) <= 1e-9 and np.min(G @ dd + h) >= -1e-9
+                assert mult[where] == 0.0
+            core.close()
+
+
+@pytest.mark.gpu
 def test_gpu_bfgs_update_matches_restatement():
     rng = np.random.default_rng(3)
     n = 57

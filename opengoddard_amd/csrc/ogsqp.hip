@@ -2568,8 +2568,11 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
                                     (int)LDS_LIMIT) != hipSuccess))
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
     {
-        const void* steps[5] = {(const void*)k_lq_step16<2, 2>, (const void*)k_lq_step16<4, 2>, (const void*)k_lq_step16<8, 4>,
-                                (const void*)k_lq_step16<12, 6>, (const void*)k_lq_step16<16, 8>};
+        const void* steps[13] = {(const void*)k_lq_step16<2, 1>, (const void*)k_lq_step16<2, 2>, (const void*)k_lq_step16<4, 1>,
+                                 (const void*)k_lq_step16<4, 2>, (const void*)k_lq_step16<8, 2>, (const void*)k_lq_step16<8, 3>,
+                                 (const void*)k_lq_step16<8, 4>, (const void*)k_lq_step16<12, 4>, (const void*)k_lq_step16<12, 5>,
+                                 (const void*)k_lq_step16<12, 6>, (const void*)k_lq_step16<16, 6>, (const void*)k_lq_step16<16, 7>,
+                                 (const void*)k_lq_step16<16, 8>};
         for (const void* f : steps) {
             const hipError_t e = rc ? hipSuccess : hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess)
@@ -2738,10 +2741,18 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     hipLaunchKernelGGL(k_lq_panel16<E>, dim3(1), dim3(P16_THREADS), (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, ldw, \
                        msweep, nq, k, Vcur, ldw, qp->diagL, pcur, qp->dthresh + 1)
                 if (factored != k) {
-                    if (eg <= 2) OG_PANEL16(2);
-                    else if (eg <= 4) OG_PANEL16(4);
-                    else if (eg <= 6) OG_PANEL16(6);
-                    else OG_PANEL16(8);
+                    // (E = groups of 256 columns, exactly: the panel's steps are bound by the multiply-adds it issues,
+                    // padding included)
+                    switch (eg) {
+                        case 1: OG_PANEL16(1); break;
+                        case 2: OG_PANEL16(2); break;
+                        case 3: OG_PANEL16(3); break;
+                        case 4: OG_PANEL16(4); break;
+                        case 5: OG_PANEL16(5); break;
+                        case 6: OG_PANEL16(6); break;
+                        case 7: OG_PANEL16(7); break;
+                        default: OG_PANEL16(8); break;
+                    }
                 }
 #undef OG_PANEL16
 #ifdef OGSQP_TRACE
@@ -2782,11 +2793,13 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
                        dim3(64 * A16_WAVES), (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, qp->Jw, ldw, msweep, nq, k,   \
                        (const double*)Vcur, ldw, (const Lq16Panel*)pcur, Vnxt, pnxt, qp->diagL, qp->dthresh + 1, rpg,      \
                        qp->lq_go, (qp->lq_token += LQ_HEADS), qp->lq_wpart, qp->flag + 2)
-                    if (ub <= 2) OG_STEP16(2, 2);
-                    else if (ub <= 4) OG_STEP16(4, 2);
-                    else if (ub <= 8) OG_STEP16(8, 4);
-                    else if (ub <= 12) OG_STEP16(12, 6);
-                    else OG_STEP16(16, 8);
+                    // U by the length of the rows now, E by the length of the NEXT panel's rows (exact)
+                    const int en = (len16 - LQ16 + 255) / 256;
+                    if (ub <= 2) { if (en <= 1) OG_STEP16(2, 1); else OG_STEP16(2, 2); }
+                    else if (ub <= 4) { if (en <= 1) OG_STEP16(4, 1); else OG_STEP16(4, 2); }
+                    else if (ub <= 8) { if (en <= 2) OG_STEP16(8, 2); else if (en == 3) OG_STEP16(8, 3); else OG_STEP16(8, 4); }
+                    else if (ub <= 12) { if (en <= 4) OG_STEP16(12, 4); else if (en == 5) OG_STEP16(12, 5); else OG_STEP16(12, 6); }
+                    else { if (en <= 6) OG_STEP16(16, 6); else if (en == 7) OG_STEP16(16, 7); else OG_STEP16(16, 8); }
 #undef OG_STEP16
                     OG_APPLY16_TRACE();
                     factored = k + LQ16;

@@ -21,7 +21,7 @@ runh polar_tsto_shipped
 runh polar_tsto
 runh polar_tsto --maxiter 400
 runh low_thrust
-runh launch4 --max-restarts 1 --maxiter 6
+runh launch4 --max-restarts 1 --maxiter 4
 # what a new problem shape pays before its first sweep (forced rebuild of its kernel module)
 cold=$R/gpurun_out/${rnd}_cold_start.jsonl
 : > $cold

@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_trsv_chain(const double* __restrict__ T
                 v = lane < cs ? __hip_atomic_load(sol + c * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
                 const bool pending = (unsigned long long)__double_as_longlong(v) == TRSV_PENDING;
                 if (!__any(pending)) break;
-                if (++spins > (1 << 22)) {
+                if (++spins > (1 << 25)) {     // (about a second: a workgroup that comes this late is not coming)
                     if (lane == 0) __hip_atomic_store(flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }

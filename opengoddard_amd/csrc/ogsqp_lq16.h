@@ -303,7 +303,7 @@ struct Lq16Head {
 __device__ __forceinline__ void lq_wait_for(unsigned* word, unsigned expect, int* lost) {
     int spins = 0;
     while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
-        if (++spins > (1 << 22)) {
+        if (++spins > (1 << 25)) {     // (about a second: a workgroup that comes this late is not coming)
             __hip_atomic_store(lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }

@@ -143,7 +143,13 @@ def build_module(header_source, digest=None, force=False, out_suffix="", parts=N
     kernels = os.path.join(CSRC, "ogk_kernels.hip")
     split = os.environ.get("OG_MODULE_PARTS", "") != "1" if parts is None else bool(parts)
     wanted = [part_path(out, i) for i in range(len(MODULE_PARTS))] if split else [out]
-    if not force and all(os.path.exists(path) for path in wanted):
+    # <module>.so is part 0 of a split build or a whole module, and only a stamp file tells which: a one-piece request
+    # must not take a part 0 left by a split (or interrupted) build for the whole thing
+    whole_stamp = out + ".whole"
+    cached = all(os.path.exists(path) for path in wanted) and (split or os.path.exists(whole_stamp))
+    if split and os.path.exists(whole_stamp) and os.path.exists(out):
+        cached = True                   # a whole module serves a split request too: it holds every kernel
+    if not force and cached:
         return out
     header = os.path.join(JITDIR, "og_gen_%s.h" % digest)
     with tempfile.NamedTemporaryFile("w", dir=JITDIR, suffix=".h", delete=False) as fh:
@@ -152,21 +158,30 @@ def build_module(header_source, digest=None, force=False, out_suffix="", parts=N
     os.replace(tmp_header, header)
 
     def compile_part(index):
+        """-> (temporary file, target); the caller renames, in an order a concurrent reader can rely on"""
         target = wanted[index]
         tmp = target + ".tmp%d" % os.getpid()
         define = ["-DOGK_PART=%d" % MODULE_PARTS[index]] if split else []
         _run([hipcc()] + HIP_FLAGS + define + ["-I" + CSRC, "-DOG_GEN_HEADER=\"%s\"" % header, kernels, "-o", tmp])
-        os.replace(tmp, target)
+        return tmp, target
 
     if not split:
         for stale in (part_path(out, i) for i in range(1, len(MODULE_PARTS))):      # a one-piece module has no parts
             if os.path.exists(stale):
                 os.remove(stale)
-        compile_part(0)
+        if os.path.exists(whole_stamp):
+            os.remove(whole_stamp)
+        os.replace(*compile_part(0))
+        with open(whole_stamp, "w") as fh:
+            fh.write(digest + "\n")
         return out
+    if os.path.exists(whole_stamp):
+        os.remove(whole_stamp)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=len(wanted)) as pool:
-        # part 0 last to land: a reader that finds <module>.so finds its parts
-        for _ in pool.map(compile_part, range(len(wanted) - 1, -1, -1)):
-            pass
+        built = list(pool.map(compile_part, range(len(wanted))))
+    # every part is compiled before any lands; parts 1.. first and part 0 last: a reader that finds <module>.so finds
+    # its parts (the loader opens <module>.so and then looks for the parts next to it)
+    for tmp, target in built[1:] + built[:1]:
+        os.replace(tmp, target)
     return out

@@ -336,7 +336,7 @@ def trace_problem(prob, obj):
     saved = prob.p
     prob.p = sym_p
     try:
-        with _tr.intercept_interp1d():
+        with _tr.tracing(graph):
             cost = prob._assemble_cost(obj)
             ceq = prob._assemble_equality(obj)
             cineq = prob.inequality(prob, obj)
@@ -397,7 +397,11 @@ def _make_groups(P):
             phases = {P.mv[y[1]].phase for y in ys}
             if len(phases) != 1 or any(y[2] != 0 or y[3] != 1 for y in ys) or \
                     ln != P.nodes[next(iter(phases))]:
-                raise _tr.TraceError("collocation products may only appear in defect rows")
+                raise _tr.TraceError(
+                    "a defect row mixes the collocation product with a dynamics term that is not ONE expression over "
+                    "all nodes of the phase (a right-hand side assembled from slices - rhs[:k] = ...; rhs[k:] = ... - "
+                    "or a collocation product used outside the defect rows): write the right-hand side as one vector "
+                    "expression (np.where for a switch over the nodes)")
             ph = next(iter(phases))
             if ph not in defect:
                 defect[ph] = Group("defect", ln, ph)
@@ -496,7 +500,8 @@ _UN_C = {"neg": "-(%s)", "sqrt": "ogm::sqrt_(%s)", "exp": "ogm::exp_(%s)", "log"
          "cosh": "ogm::cosh_(%s)", "expm1": "ogm::expm1_(%s)", "log1p": "ogm::log1p_(%s)",
          "log2": "ogm::log2_(%s)", "log10": "ogm::log10_(%s)", "cbrt": "ogm::cbrt_(%s)"}
 _BIN_C = {"add": "%s + %s", "sub": "%s - %s", "mul": "%s * %s", "div": "%s / %s",
-          "atan2": "ogm::atan2_(%s, %s)", "hypot": "ogm::hypot_(%s, %s)", "pow": "ogm::pow_(%s, %s)"}
+          "atan2": "ogm::atan2_(%s, %s)", "hypot": "ogm::hypot_(%s, %s)", "pow": "ogm::pow_(%s, %s)",
+          "mod": "ogm::mod_(%s, %s)", "fmod": "ogm::fmod_(%s, %s)"}
 _CMP_C = {"lt": "<", "le": "<=", "gt": ">", "ge": ">=", "eq": "==", "ne": "!="}
 
 

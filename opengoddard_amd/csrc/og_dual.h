@@ -117,6 +117,19 @@ OG_HDI ogdual hypot_(const ogdual x, const ogdual y) {
 }
 OG_HDI ogdual hypot_(const ogdual x, const double y) { return hypot_(x, ogdual(y)); }
 OG_HDI ogdual hypot_(const double x, const ogdual y) { return hypot_(ogdual(x), y); }
+// remainder (the divisor's sign, Python's %) and fmod (the dividend's sign): a - q b with q constant between jumps
+OG_HDI ogdual mod_(const ogdual a, const ogdual b) {
+    const double q = floor_(a.v / b.v);
+    return ogdual(mod_(a.v, b.v), a.d - ((b.d == 0.0 || q - q != 0.0) ? 0.0 : q * b.d));
+}
+OG_HDI ogdual mod_(const ogdual a, const double b) { return ogdual(mod_(a.v, b), a.d); }
+OG_HDI ogdual mod_(const double a, const ogdual b) { return mod_(ogdual(a), b); }
+OG_HDI ogdual fmod_(const ogdual a, const ogdual b) {
+    const double q = trunc_(a.v / b.v);
+    return ogdual(fmod_(a.v, b.v), a.d - ((b.d == 0.0 || q - q != 0.0) ? 0.0 : q * b.d));
+}
+OG_HDI ogdual fmod_(const ogdual a, const double b) { return ogdual(fmod_(a.v, b), a.d); }
+OG_HDI ogdual fmod_(const double a, const ogdual b) { return fmod_(ogdual(a), b); }
 // x ** y: d = x^y (y' log x + y x' / x); a part whose factor does not depend on the seeded variable stays out (0 log 0)
 OG_HDI ogdual pow_(const ogdual x, const ogdual y) {
     const double p = pow_(x.v, y.v);

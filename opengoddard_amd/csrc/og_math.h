@@ -579,12 +579,30 @@ OG_HD double hypot_(double x, double y) {
     const double h = sqrt_(s2);
     return scalb_(h + err / (2.0 * h), e);
 }
+// floor / trunc / fmod are exact operations (the result is always representable): the compiler's builtins give the
+// same bits on both sides (v_floor_f64 / v_trunc_f64 and ocml's exact fmod on gfx950, libm on x86)
+OG_HD double floor_(double x) { return __builtin_floor(x); }
+OG_HD double trunc_(double x) { return __builtin_trunc(x); }
+OG_HD double fmod_(double a, double b) { return __builtin_fmod(a, b); }
+// np.remainder / np.mod / Python's %: npy_remainder of numpy/_core/src/npymath/npy_math_internal.h.src - fmod, moved
+// to the divisor's sign; fmod's NaN for a zero divisor
+OG_HD double mod_(double a, double b) {
+    double m = fmod_(a, b);
+    if (b == 0.0) return m;
+    if (m != 0.0) {
+        if ((b < 0.0) != (m < 0.0)) m += b;
+    } else {
+        m = from_bits((bits_of(b) & 0x8000000000000000ULL));       // copysign(0, b)
+    }
+    return m;
+}
 // x ** y for a traced exponent: exp(y log x) for x > 0 (NumPy calls libm's pow there: this is |y log x| ulp away from
 // it at worst, a few ulp for the exponents models use); pow's special cases for the rest
 OG_HD double pow_(double x, double y) {
     if (y == 0.0 || x == 1.0) return 1.0;
     if (isnan_(x) || isnan_(y)) return x + y;
-    if (y == (double)(int)y && fabs_(y) <= 64.0 && x - x == 0.0) {
+    // the bound first: a float-to-int cast is undefined beyond INT_MAX / for inf, and host and device saturate differently
+    if (fabs_(y) <= 64.0 && y == (double)(int)y && x - x == 0.0) {
         // a small whole exponent (at run time): square and multiply, exact where the products are
         int k = (int)fabs_(y);
         double base = x, acc = 1.0;
@@ -597,7 +615,7 @@ OG_HD double pow_(double x, double y) {
     }
     if (x > 0.0) return exp_(y * log_(x));
     const double inf = from_bits(0x7ff0000000000000ULL);
-    const bool yint = (y == (double)(long long)y) && fabs_(y) < 9.0e15;
+    const bool yint = fabs_(y) < 9.0e15 && (y == (double)(long long)y);
     const bool yodd = yint && (((long long)y) & 1LL);
     if (x == 0.0) {
         const bool neg = (bits_of(x) >> 63) != 0 && yodd;

@@ -405,10 +405,12 @@ class Problem:
         core = options.pop("sqp_core", None) or os.environ.get("OG_SQP_CORE", DEFAULT_SQP_CORE)
         if core not in ("scipy", "hip", "auto"):
             raise ValueError("sqp_core must be 'scipy', 'hip' or 'auto', got %r" % (core,))
-        if core == "auto":
+        auto = core == "auto"
+        if auto:
             # a stand-in engine of the test-suite (ENGINE_FACTORY) has no device-resident Jacobian for the HIP core
             core = "hip" if (self.number_of_variables >= AUTO_HIP_FROM and ENGINE_FACTORY is None) else "scipy"
         self.sqp_core_used = core
+        self.sqp_core_fallback = None
 
         jacobian = options.pop("jacobian", None) or os.environ.get("OG_JACOBIAN", "fd")
         if jacobian not in ("fd", "exact"):
@@ -431,6 +433,18 @@ class Problem:
         else:
             engine = _default_engine(self, obj, devices=devices)
         self._engine = engine
+        if core == "hip" and auto:
+            # 'auto' never makes a problem unsolvable that the reference's core solves (slowly): the HIP core needs
+            # torch for its device buffers and has capacity limits (include/ogsqp.h) - when it cannot be built for this
+            # problem the solve goes to SciPy's core and says so (sqp_core_used / sqp_core_fallback)
+            from . import sqp as _sqp
+            reason = _sqp.prepare(engine)
+            if reason is not None:
+                import warnings
+                warnings.warn("Problem.solve: the HIP SQP core is not available for this problem (%s); "
+                              "using SciPy's SLSQP core" % reason, RuntimeWarning, stacklevel=2)
+                core = self.sqp_core_used = "scipy"
+                self.sqp_core_fallback = reason
         if jacobian == "exact":
             if not hasattr(engine, "exact_stacked"):
                 raise ValueError("this engine has no exact-Jacobian mode")

@@ -86,6 +86,48 @@ class DeviceJacobian:
         return self.d_JT.data_ptr()
 
 
+# capacity of the QP core (include/ogsqp.h, csrc/ogsqp.hip og_qp_create / rows_lds_bytes): row segments of the panel
+# kernels hold n + 1 <= 8192 entries; the active-set kernels keep three vectors of the null-space dimension in LDS
+MAX_N1 = 8192
+MAX_NULL_SPACE = 6736
+
+
+def _cache(engine):
+    """(DeviceJacobian, QpCore) of an engine, built once: the restarts of Problem.solve reuse buffers and work space."""
+    cache = getattr(engine, "_sqp_cache", None)
+    if cache is None:
+        n, meq, mineq = engine.n, engine.m_eq, engine.m_ineq
+        cache = (DeviceJacobian(engine), _sqp_native.QpCore(n, meq, mineq, device=engine.device))
+        try:
+            engine._sqp_cache = cache
+        except AttributeError:
+            pass
+    return cache
+
+
+def prepare(engine):
+    """Can the HIP core run this engine's problem?  None when it can (device buffers and QP work space are then
+    built and cached on the engine), otherwise the reason as text.  ``Problem.solve(sqp_core="auto")`` asks before it
+    commits to the HIP core; ``sqp_core="hip"`` does not ask and fails loudly."""
+    n, meq = int(engine.n), int(engine.m_eq)
+    if n + 1 > MAX_N1:
+        return "n + 1 = %d exceeds the QP core's %d-entry row segments" % (n + 1, MAX_N1)
+    if n + 1 - meq > MAX_NULL_SPACE:
+        return "null space of the equalities (%d) exceeds the active-set kernels' limit of %d" % (n + 1 - meq,
+                                                                                                 MAX_NULL_SPACE)
+    try:
+        import torch
+    except Exception as exc:                                   # torch is optional everywhere else in the package
+        return "torch is not importable (%s)" % (exc,)
+    if not torch.cuda.is_available():
+        return "torch sees no GPU"
+    try:
+        _cache(engine)
+    except (RuntimeError, ImportError, OSError) as exc:        # SqpNativeError is a RuntimeError
+        return "building the QP core failed: %s" % (exc,)
+    return None
+
+
 def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivative=None, disp=False,
                        callback=None, iprint=1):
     """Minimise with the engine's callbacks.  ``engine`` is a :class:`~.engine.HipEngine`;
@@ -97,14 +139,7 @@ def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivati
     ub = np.asarray(ub, dtype=float)
     x = np.clip(np.asarray(x0, dtype=float), lb, ub)
     # device buffers and the QP work space belong to the engine: the restarts of Problem.solve reuse them
-    cache = getattr(engine, "_sqp_cache", None)
-    if cache is None:
-        cache = (DeviceJacobian(engine), _sqp_native.QpCore(n, meq, mineq, device=engine.device))
-        try:
-            engine._sqp_cache = cache
-        except AttributeError:
-            pass
-    jacobian, core = cache
+    jacobian, core = _cache(engine)
     timing = {"callbacks": 0.0, "qp": 0.0, "bfgs": 0.0, "qp_iterations": 0, "qp_solves": 0}
     unit0 = np.zeros(m + 1)
     unit0[0] = 1.0

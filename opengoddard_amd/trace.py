@@ -27,6 +27,11 @@ class TraceError(RuntimeError):
     """A callback did something the tracer cannot turn into device code."""
 
 
+class TraceAttributeError(TraceError, AttributeError):
+    """An ndarray attribute the tracer does not model.  Also an ``AttributeError``, so that duck-typing probes
+    (``hasattr(v, "dtype")``, ``getattr(v, "shape", None)``) answer False / the default instead of raising."""
+
+
 # ----------------------------------------------------------------------------- graph nodes
 class Graph:
     """Hash-consed expression DAG.  A node is a tuple; ``length`` None means scalar."""
@@ -67,6 +72,67 @@ class Graph:
         return self.add(("cvec", idx), int(arr.shape[0]))
 
 
+def _graph_parts(g, nid, start, count):
+    """Node ids (vectors, or scalars counting as one element) whose concatenation is ``nid[start:start+count]``.
+    Looks through ``cat`` and ``slice`` nodes and cuts constant vectors directly, so that repeated item assignment
+    into one buffer keeps a FLAT graph (depth O(1), not one nesting level per assignment)."""
+    if count <= 0:
+        return []
+    node, total = g.nodes[nid], g.length[nid]
+    if total is None:
+        return [nid]
+    if node[0] == "cat":
+        out, at = [], 0
+        for child in node[1]:
+            ln = g.length[child]
+            ln = 1 if ln is None else ln
+            lo, hi = max(start, at), min(start + count, at + ln)
+            if lo < hi:
+                out.extend(_graph_parts(g, child, lo - at, hi - lo))
+            at += ln
+        return out
+    if node[0] == "slice":
+        return _graph_parts(g, node[1], node[2] + start, count)
+    if start == 0 and count == total:
+        return [nid]
+    if node[0] == "cvec":
+        return [g.cvec(g.cvecs[node[1]][start:start + count])]
+    return [g.add(("slice", nid, start, count), count)]
+
+
+def _graph_cat(g, ids):
+    """One node for the concatenation of ``ids``: nested concatenations are flattened and neighbouring constants
+    merged into one constant vector."""
+    flat = []
+    for nid in ids:
+        if g.nodes[nid][0] == "cat":
+            flat.extend(g.nodes[nid][1])
+        else:
+            flat.append(nid)
+    merged, run = [], []
+
+    def flush():
+        if len(run) == 1:
+            merged.append(run[0][0])
+        elif run:
+            merged.append(g.cvec(np.concatenate([v for _, v in run])))
+        del run[:]
+    for nid in flat:
+        node = g.nodes[nid]
+        if node[0] == "cvec":
+            run.append((nid, g.cvecs[node[1]]))
+        elif node[0] == "const":
+            run.append((nid, np.array([const_value(node)])))
+        else:
+            flush()
+            merged.append(nid)
+    flush()
+    total = sum(1 if g.length[nid] is None else g.length[nid] for nid in merged)
+    if len(merged) == 1 and g.length[merged[0]] is not None:
+        return merged[0]
+    return g.add(("cat", tuple(merged)), total)
+
+
 def const_value(node):
     return float(np.frombuffer(node[1], dtype=np.float64)[0])
 
@@ -81,6 +147,7 @@ _UNARY = {
 _BINARY = {
     np.add: "add", np.subtract: "sub", np.multiply: "mul", np.true_divide: "div",
     np.maximum: "max", np.minimum: "min", np.arctan2: "atan2", np.hypot: "hypot",
+    np.remainder: "mod",                                 # np.mod is np.remainder: the sign of the divisor (Python's %)
 }
 _COMPARE = {
     np.less: "lt", np.less_equal: "le", np.greater: "gt", np.greater_equal: "ge",
@@ -119,6 +186,7 @@ class Sym:
         self._version = 0
         self._view_of = view_of            # (parent Sym, start, length) for slice views
         self._seen = view_of[0]._version if view_of else 0
+        self._frozen = None                # why writing through this name cannot be traced (strided / column views)
 
     @property
     def id(self):
@@ -135,6 +203,9 @@ class Sym:
     @id.setter
     def id(self, nid):
         """In-place change of what this name stands for (masked assignment, ``+=`` ...)."""
+        if self._frozen:
+            raise TraceError("writing through %s is not traceable (NumPy would change the array it views)"
+                             % self._frozen)
         self._id = nid
         self._version += 1
         v = self._view_of
@@ -221,9 +292,9 @@ class Sym:
     def __getattr__(self, name):
         # (only reached for attributes that do not exist) an ndarray method the tracer does not model must be a
         # tracing error like every other untraceable construct, not an AttributeError from nowhere
-        if name.startswith("__") or name in ("g", "_id", "_version", "_view_of", "_seen"):
+        if name.startswith("__") or name in ("g", "_id", "_version", "_view_of", "_seen", "_frozen"):
             raise AttributeError(name)
-        raise TraceError("ndarray.%s is not traceable on a decision-variable expression" % name)
+        raise TraceAttributeError("ndarray.%s is not traceable on a decision-variable expression" % name)
 
     # ------------------------------------------------------------------ lifting
     def _lift(self, other):
@@ -266,6 +337,8 @@ class Sym:
         return Sym(self.g, self.g.add(("un", op, self.id), self.length))
 
     def _binary(self, op, other, swap=False):
+        if isinstance(other, SymMat):
+            return NotImplemented                       # the matrix's reflected operator takes it
         other = self._lift(other)
         if other is NotImplemented:
             return NotImplemented
@@ -292,6 +365,10 @@ class Sym:
     def __rmul__(self, o): return self._binary("mul", o, swap=True)
     def __truediv__(self, o): return self._binary("div", o)
     def __rtruediv__(self, o): return self._binary("div", o, swap=True)
+    def __mod__(self, o): return self._binary("mod", o)
+    def __rmod__(self, o): return self._binary("mod", o, swap=True)
+    def __matmul__(self, o): return matmul(self, o)
+    def __rmatmul__(self, o): return matmul(o, self)
     def __lt__(self, o): return self._compare("lt", o)
     def __le__(self, o): return self._compare("le", o)
     def __gt__(self, o): return self._compare("gt", o)
@@ -376,7 +453,10 @@ class Sym:
             if step != 1:
                 # x[::-1], x[::2]: a copy-like gather of single elements (NumPy makes a view; nothing in a callback
                 # writes through a strided view, and the tracer refuses it: the result is not assignable)
-                return take(self, list(range(start, stop, step)))
+                out = take(self, list(range(start, stop, step)))
+                if isinstance(out, Sym):
+                    out._frozen = "a strided view x[%s:%s:%s]" % (key.start, key.stop, key.step)
+                return out
             ln = max(0, stop - start)
             if start == 0 and ln == n:
                 return Sym(self.g, self.id, view_of=(self, 0, n))
@@ -392,10 +472,17 @@ class Sym:
         raise TraceError("unsupported index %r on a traced vector" % (key,))
 
     # ------------------------------------------------------------------ reductions (ndarray methods)
+    @staticmethod
+    def _axis_1d(axis, what):
+        if axis not in (None, 0, -1):
+            raise TraceError("%s(axis=%r) of a 1-D traced vector" % (what, axis))
+
     def sum(self, axis=None):
+        self._axis_1d(axis, "sum")
         return pairwise_sum(self)
 
     def mean(self, axis=None):
+        self._axis_1d(axis, "mean")
         if self.length is None:
             return Sym(self.g, self.id)
         return pairwise_sum(self)._binary("div", float(self.length))
@@ -403,14 +490,24 @@ class Sym:
     def dot(self, other):
         return dot(self, other)
 
+    def prod(self, axis=None):
+        self._axis_1d(axis, "prod")
+        return prod(self)
+
     def min(self, axis=None):
+        self._axis_1d(axis, "min")
         return reduce_tree(self, "min")
 
     def max(self, axis=None):
+        self._axis_1d(axis, "max")
         return reduce_tree(self, "max")
 
     def cumsum(self, axis=None):
+        self._axis_1d(axis, "cumsum")
         return cumsum(self)
+
+    def fill(self, value):
+        self._assign_range(0, self.size, value)
 
     def __setitem__(self, key, value):
         # in-place boolean-mask assignment: x[mask] = scalar  ->  x = where(mask, scalar, x)
@@ -422,7 +519,72 @@ class Sym:
                 raise TraceError("mask length mismatch")
             self.id = self.g.add(("where", key.id, v.id, self.id), self.length)
             return
-        raise TraceError("only boolean-mask assignment (x[x < a] = a) is traceable")
+        if isinstance(key, Sym):
+            raise TraceError("assignment through a traced index is not traceable (only a traced comparison as a mask)")
+        n = self.length
+        if n is None:
+            raise TraceError("item assignment to a traced scalar")
+        if isinstance(key, type(Ellipsis)):
+            key = slice(None)
+        if isinstance(key, tuple):
+            if len(key) == 1:
+                return self.__setitem__(key[0], value)
+            raise TraceError("%d indices on a 1-D traced vector" % len(key))
+        if isinstance(key, (numbers.Integral, np.integer)):
+            i = _norm_index(key, n)
+            self._assign_range(i, 1, value, scalar_target=True)
+            return
+        if isinstance(key, slice):
+            start, stop, step = key.indices(n)
+            if step == 1:
+                self._assign_range(start, max(0, stop - start), value)
+                return
+            targets = list(range(start, stop, step))
+        else:
+            idx = np.asarray(key)
+            if idx.ndim == 1 and idx.dtype == np.bool_:
+                if idx.size != n:
+                    raise IndexError("boolean index of length %d on a traced vector of length %d" % (idx.size, n))
+                targets = np.nonzero(idx)[0].tolist()
+            elif idx.ndim == 1 and np.issubdtype(idx.dtype, np.integer):
+                targets = [_norm_index(i, n) for i in idx.tolist()]
+            else:
+                raise TraceError("unsupported index %r in an assignment to a traced vector" % (key,))
+        # scattered targets: element by element, in order (NumPy: the last write to a repeated index wins)
+        v = self._lift(value)
+        if v is NotImplemented:
+            raise TraceError("cannot assign %r into a traced vector" % (type(value),))
+        if v.length not in (None, 1, len(targets)):
+            raise ValueError("shape mismatch: value of length %d assigned to %d elements" % (v.length, len(targets)))
+        for k, i in enumerate(targets):
+            self._assign_range(i, 1, v if v.length is None else v[0 if v.length == 1 else k], scalar_target=True)
+
+    def _assign_range(self, start, count, value, scalar_target=False):
+        """``self[start:start+count] = value`` (NumPy broadcasting of a scalar / one-element value)."""
+        g, n = self.g, self.length
+        if count == 0:
+            return
+        v = self._lift(value)
+        if v is NotImplemented:
+            if isinstance(value, SymMat):
+                raise TraceError("assigning a 2-D traced value into a 1-D traced vector")
+            raise TraceError("cannot assign %r into a traced vector" % (type(value),))
+        if v.length is None or (v.length == 1 and count != 1):
+            vid = v.id if v.length is None else g.add(("idx", v.id, 0), None)
+            if count == 1:
+                new = [vid]
+            elif g.nodes[vid][0] == "const":
+                new = [g.cvec(np.full(count, const_value(g.nodes[vid])))]
+            else:
+                # a traced scalar spread over the range: s * 1.0 is s for every s (NaN and -0.0 included)
+                new = [Sym(g, g.cvec(np.ones(count)))._binary("mul", Sym(g, vid)).id]
+        elif v.length == count:
+            new = [g.add(("idx", v.id, 0), None)] if (scalar_target and count == 1) else _graph_parts(g, v.id, 0, count)
+        else:
+            raise ValueError("could not broadcast a traced value of length %d into %d elements" % (v.length, count))
+        cur = self.id
+        ids = _graph_parts(g, cur, 0, start) + new + _graph_parts(g, cur, start + count, n - start - count)
+        self.id = _graph_cat(g, ids)
 
     # ------------------------------------------------------------------ NumPy protocol
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
@@ -437,6 +599,23 @@ class Sym:
         if ufunc is np.sign:
             x = inputs[0]
             return where(x > 0.0, 1.0, where(x < 0.0, -1.0, x._binary("mul", 0.0)))
+        if any(isinstance(v, SymMat) for v in inputs):
+            return SymMat._ufunc(ufunc, inputs)
+        if ufunc is np.heaviside:
+            x, h0 = inputs
+            if not isinstance(x, Sym):
+                raise TraceError("np.heaviside with a traced second argument only")
+            # NumPy: NaN -> NaN, 0 -> h0, < 0 -> 0, > 0 -> 1
+            return where(x < 0.0, 0.0, where(x > 0.0, 1.0, where(x == 0.0, h0, x)))
+        if ufunc is np.matmul:
+            return matmul(inputs[0], inputs[1])
+        if ufunc is np.fmod:
+            a, b = inputs
+            me, other, swap = (a, b, False) if isinstance(a, Sym) else (b, a, True)
+            out = me._binary("fmod", other, swap)
+            if out is NotImplemented:
+                raise TraceError("unsupported operand for fmod")
+            return out
         if ufunc in (np.fmax, np.fmin):                 # (NaN handling aside: a NaN row is caught either way)
             ufunc = np.maximum if ufunc is np.fmax else np.minimum
         if ufunc is np.power:
@@ -467,46 +646,107 @@ class Sym:
         return out
 
     def __array_function__(self, func, types, args, kwargs):
-        if func in (np.hstack, np.concatenate):
-            return cat(list(args[0]))
-        if func is np.append:
-            return cat([args[0], args[1]])
-        if func is np.where and len(args) == 3:
-            return where(*args)
-        if func is np.clip:
-            x, lo, hi = args[0], args[1], args[2]
-            return np.minimum(np.maximum(x, lo), hi)
-        if func is np.sum and len(args) == 1 and not kwargs:
-            return pairwise_sum(args[0])
-        if func is np.mean and len(args) == 1 and not kwargs:
-            return args[0].mean()
-        if func is np.dot and len(args) == 2 and not kwargs:
-            return dot(args[0], args[1])
-        if func in (np.min, np.amin) and len(args) == 1 and not kwargs:
-            return reduce_tree(args[0], "min")
-        if func in (np.max, np.amax) and len(args) == 1 and not kwargs:
-            return reduce_tree(args[0], "max")
-        if func is np.cumsum and len(args) == 1 and not kwargs:
-            return cumsum(args[0])
-        if func is np.roll and len(args) == 2 and not kwargs:
-            return roll(args[0], args[1])
-        if func is np.flip and len(args) == 1 and not kwargs:
-            return args[0][::-1]
-        if func is np.take and len(args) == 2 and not kwargs:
-            return args[0][np.asarray(args[1])]
-        if func is np.interp and len(args) == 3 and not kwargs:
-            return np_interp(args[0], args[1], args[2])
-        if func is np.diff and len(args) == 1 and not kwargs:
-            return args[0][1:] - args[0][:-1]
-        if func in (np.shape,):
-            return args[0].shape
-        if func in (np.size,):
-            return args[0].size
-        if func in (np.ndim,):
-            return args[0].ndim
-        if func is np.copy:
-            return args[0].copy()
-        raise TraceError("NumPy function %s is not traceable" % getattr(func, "__name__", func))
+        return _array_function(func, args, kwargs)
+
+
+def _axis_of(kwargs, args, pos):
+    """The ``axis`` of a reduction call (keyword or positional); every other keyword is refused by name."""
+    extra = set(kwargs) - {"axis"}
+    if extra:
+        raise TraceError("keyword%s %s of a NumPy reduction are not traceable"
+                         % ("s" if len(extra) > 1 else "", ", ".join(sorted(extra))))
+    if "axis" in kwargs:
+        return kwargs["axis"]
+    return args[pos] if len(args) > pos else None
+
+
+def _array_function(func, args, kwargs):
+    """NumPy functions (``__array_function__`` protocol) on traced vectors and matrices."""
+    name = getattr(func, "__name__", str(func))
+    if func in (np.hstack, np.concatenate):
+        axis = kwargs.get("axis", 0) if func is np.concatenate else 0
+        items = list(args[0])
+        if any(isinstance(it, SymMat) for it in items):
+            if func is np.concatenate and axis in (0, -2):
+                return SymMat.vstack(items)
+            raise TraceError("np.%s of 2-D traced values along axis %r is not traceable" % (name, axis))
+        if axis not in (0, -1, None):
+            raise TraceError("np.concatenate(axis=%r) of 1-D traced values" % (axis,))
+        return cat(items)
+    if func is np.append:
+        return cat([args[0], args[1]])
+    if func in (np.vstack, getattr(np, "row_stack", None)):
+        return SymMat.vstack(list(args[0]))
+    if func is np.stack:
+        axis = kwargs.get("axis", args[1] if len(args) > 1 else 0)
+        mat = SymMat.vstack(list(args[0]), rows_only=True)
+        if axis in (0, -2):
+            return mat
+        if axis in (1, -1):
+            return mat.T
+        raise TraceError("np.stack(axis=%r) of traced vectors" % (axis,))
+    if func is np.column_stack:
+        return SymMat.vstack(list(args[0]), rows_only=True).T
+    if func is np.where and len(args) == 3:
+        return where(*args)
+    if func is np.clip:
+        x, lo, hi = args[0], args[1], args[2]
+        return np.minimum(np.maximum(x, lo), hi)
+    if func in (np.sum, np.mean, np.prod, np.min, np.amin, np.max, np.amax) and len(args) >= 1:
+        axis = _axis_of(kwargs, args, 1)
+        op = {np.sum: "sum", np.mean: "mean", np.prod: "prod", np.min: "min", np.amin: "min", np.max: "max",
+              np.amax: "max"}[func]
+        x = args[0]
+        if isinstance(x, SymMat):
+            return x._reduce(op, axis)
+        if axis not in (None, 0, -1):
+            raise TraceError("np.%s(axis=%r) of a 1-D traced vector" % (name, axis))
+        return getattr(x, op)()
+    if func is np.dot and len(args) == 2 and not kwargs:
+        return dot(args[0], args[1])
+    if func is np.matmul and len(args) == 2 and not kwargs:
+        return matmul(args[0], args[1])
+    if func is np.cumsum and len(args) == 1 and not kwargs:
+        return cumsum(args[0])
+    if func is np.roll and len(args) == 2 and not kwargs:
+        return roll(args[0], args[1])
+    if func is np.flip and len(args) == 1 and not kwargs:
+        return args[0][::-1]
+    if func is np.take and len(args) == 2 and not kwargs:
+        return args[0][np.asarray(args[1])]
+    if func is np.interp and len(args) == 3 and not kwargs:
+        return np_interp(args[0], args[1], args[2])
+    if func is np.diff and len(args) == 1 and not kwargs:
+        return args[0][1:] - args[0][:-1]
+    if func in (getattr(np, "trapz", None), getattr(np, "trapezoid", None)) and func is not None:
+        return trapezoid(*args, **kwargs)
+    if func in (np.zeros_like, np.ones_like, np.empty_like, np.full_like):
+        extra = set(kwargs) - {"dtype", "fill_value"}
+        if extra or (kwargs.get("dtype") is not None and np.dtype(kwargs["dtype"]) != np.float64):
+            raise TraceError("np.%s of a traced value with %s" % (name, ", ".join(sorted(kwargs))))
+        fill = {np.zeros_like: 0.0, np.ones_like: 1.0, np.empty_like: 0.0}.get(func)
+        if func is np.full_like:
+            fill = kwargs.get("fill_value", args[1] if len(args) > 1 else None)
+        return _filled_like(args[0], fill)
+    if func in (np.shape,):
+        return args[0].shape
+    if func in (np.size,):
+        return args[0].size
+    if func in (np.ndim,):
+        return args[0].ndim
+    if func is np.copy:
+        return args[0].copy()
+    if func is np.ravel:
+        return args[0].ravel()
+    if func is np.transpose and len(args) == 1:
+        return args[0].T
+    if func is np.atleast_1d and len(args) == 1:
+        x = args[0]
+        return cat([x]) if isinstance(x, Sym) and x.length is None else x
+    if func is np.squeeze and len(args) == 1 and not kwargs:
+        x = args[0]
+        return x[0] if isinstance(x, Sym) and x.length == 1 else x
+    raise TraceError("NumPy function %s is not traceable" % name)
 
 
 def _ones_like(s):
@@ -758,6 +998,525 @@ class intercept_interp1d:
     def __exit__(self, *exc):
         if self._cls is not None:
             self._cls.__call__ = self._orig
+        return False
+
+
+def prod(vec):
+    """``np.prod``: ``multiply.reduce`` runs left to right (only additions are summed pairwise in NumPy)."""
+    if not isinstance(vec, Sym):
+        return np.prod(vec)
+    n = vec.length
+    if n is None:
+        return Sym(vec.g, vec.id)
+    if n == 0:
+        return Sym(vec.g, vec.g.const(1.0))
+    acc = vec[0]
+    for i in range(1, n):
+        acc = acc * vec[i]
+    return acc
+
+
+def matmul(a, b):
+    """``a @ b`` with traced operands: vector @ vector (as ``np.dot``), constant matrix @ traced vector, traced
+    vector @ constant matrix - each entry one ``np.dot`` (BLAS order in NumPy: equal to rounding, not bit for bit)."""
+    if isinstance(a, SymMat) or isinstance(b, SymMat):
+        raise TraceError("@ with a 2-D traced operand is not traceable (constant matrix @ traced vector is)")
+    if isinstance(a, Sym) and a.length is None or isinstance(b, Sym) and b.length is None:
+        raise ValueError("matmul: input operand does not have enough dimensions")
+    if isinstance(a, Sym) and isinstance(b, Sym):
+        return dot(a, b)
+    if isinstance(b, Sym):
+        A = np.asarray(a, dtype=np.float64)
+        if A.ndim == 1:
+            return dot(A, b)
+        if A.ndim == 2 and A.shape[1] == b.length:
+            return cat([dot(A[i], b) for i in range(A.shape[0])])
+    else:
+        B = np.asarray(b, dtype=np.float64)
+        if B.ndim == 1:
+            return dot(a, B)
+        if B.ndim == 2 and B.shape[0] == a.length:
+            return cat([dot(a, np.ascontiguousarray(B[:, j])) for j in range(B.shape[1])])
+    raise TraceError("@: only 1-D traced vectors with constant 1-D / 2-D operands of matching shape are traceable")
+
+
+def trapezoid(y, x=None, dx=1.0, axis=-1):
+    """``np.trapz`` / ``np.trapezoid`` of 1-D data, NumPy's own formula and order:
+    ``(d * (y[1:] + y[:-1]) / 2.0).sum()`` with ``d = np.diff(x)`` or the scalar ``dx``."""
+    if isinstance(y, SymMat) or isinstance(x, SymMat):
+        raise TraceError("np.trapz of a 2-D traced value")
+    if axis not in (-1, 0):
+        raise TraceError("np.trapz(axis=%r) of a 1-D traced vector" % (axis,))
+    if not isinstance(y, Sym):
+        g = _find_graph([x, dx])
+        if g is None:
+            return (getattr(np, "trapezoid", None) or np.trapz)(y, x=x, dx=dx)
+        y = Sym(g, g.const(0.0))._lift(np.asarray(y, dtype=np.float64))
+    if x is None:
+        d = dx
+    else:
+        xs = x if isinstance(x, Sym) else np.asarray(x, dtype=np.float64)
+        d = xs[1:] - xs[:-1]
+    return pairwise_sum(d * (y[1:] + y[:-1]) / 2.0)
+
+
+def _filled_like(like, fill):
+    if isinstance(like, SymMat):
+        return SymMat([_filled_like(r, fill) for r in like.rows])
+    g = like.g
+    if isinstance(fill, Sym):
+        base = Sym(g, g.cvec(np.ones(like.size))) if like.length is not None else Sym(g, g.const(1.0))
+        return base * fill
+    if like.length is None:
+        return Sym(g, g.const(float(fill)))
+    return Sym(g, g.cvec(np.full(like.length, float(fill))))
+
+
+class SymMat:
+    """A small 2-D traced array: a list of equally long traced rows.  Enough for what callbacks do with one - build it
+    (``np.array([a, b])``, ``np.vstack``, ``np.stack``, ``np.zeros((r, n))`` filled row by row), index it, transpose it,
+    combine it elementwise and reduce it along an axis, in NumPy's order of operations.  ``m[i]`` IS the row (writes go
+    through, as with NumPy's view); a column ``m[:, j]`` and the transpose are read-only copies here."""
+
+    __array_priority__ = 1001.0
+
+    def __init__(self, rows):
+        rows = list(rows)
+        if not rows:
+            raise TraceError("an empty 2-D traced array")
+        self.g = rows[0].g
+        width = rows[0].length
+        for r in rows:
+            if not isinstance(r, Sym) or r.length is None or r.length != width:
+                raise TraceError("the rows of a 2-D traced array must be traced vectors of one length")
+        self.rows = rows
+
+    # -------------------------------------------------------------- construction
+    @staticmethod
+    def _row(g, item, width=None):
+        probe = Sym(g, g.const(0.0))
+        if isinstance(item, Sym):
+            if item.length is None:
+                if width is None:
+                    raise TraceError("a traced scalar where a row was expected")
+                return _filled_like(Sym(g, g.cvec(np.zeros(width))), item)
+            return item
+        arr = np.asarray(item, dtype=np.float64)
+        if arr.ndim == 0 and width is not None:
+            return Sym(g, g.cvec(np.full(width, float(arr))))
+        if arr.ndim != 1:
+            raise TraceError("cannot make a row of a 2-D traced array out of an array of shape %r" % (arr.shape,))
+        return Sym(g, g.cvec(arr))
+
+    @classmethod
+    def vstack(cls, items, rows_only=False):
+        g = None
+        for it in items:
+            if isinstance(it, (Sym, SymMat)):
+                g = it.g
+                break
+        rows = []
+        for it in items:
+            if isinstance(it, SymMat):
+                if rows_only:
+                    raise TraceError("np.stack of 2-D traced arrays")
+                rows.extend(Sym(g, r.id) for r in it.rows)
+            elif isinstance(it, Sym):
+                rows.append(Sym(g, it.id) if it.length is not None else cat([it]))
+            else:
+                arr = np.asarray(it, dtype=np.float64)
+                if arr.ndim == 2 and not rows_only:
+                    rows.extend(cls._row(g, arr[i]) for i in range(arr.shape[0]))
+                elif arr.ndim == 0:
+                    rows.append(Sym(g, g.cvec(arr.reshape(1))))
+                else:
+                    rows.append(cls._row(g, arr))
+        return cls(rows)
+
+    @classmethod
+    def filled(cls, g, shape, fill):
+        return cls([Sym(g, g.cvec(np.full(int(shape[1]), float(fill)))) for _ in range(int(shape[0]))])
+
+    # -------------------------------------------------------------- basics
+    @property
+    def shape(self):
+        return (len(self.rows), self.rows[0].length)
+
+    ndim = 2
+
+    @property
+    def size(self):
+        return len(self.rows) * self.rows[0].length
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __iter__(self):
+        return iter(self.rows)
+
+    def __bool__(self):
+        raise TraceError("Python control flow on a traced value")
+
+    def __array__(self, *a, **k):
+        raise TraceError("a 2-D traced value was passed to a NumPy routine the tracer does not understand")
+
+    def __repr__(self):
+        return "SymMat(%d x %d)" % self.shape
+
+    def copy(self):
+        return SymMat([r.copy() for r in self.rows])
+
+    @property
+    def T(self):
+        r, c = self.shape
+        cols = []
+        for j in range(c):
+            col = cat([self.rows[i][j] for i in range(r)])
+            col._frozen = "a transposed view m.T"
+            cols.append(col)
+        return SymMat(cols)
+
+    def transpose(self):
+        return self.T
+
+    def ravel(self, order="C"):
+        if order != "C":
+            raise TraceError("ravel(order=%r) of a 2-D traced array" % (order,))
+        return cat([Sym(self.g, r.id) for r in self.rows])
+
+    flatten = ravel
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        if tuple(shape) in ((-1,), (self.size,)):
+            return self.ravel()
+        if tuple(shape) == self.shape:
+            return self
+        raise TraceError("reshape%r of a 2-D traced array" % (tuple(shape),))
+
+    def __getattr__(self, name):
+        if name.startswith("__") or name in ("g", "rows"):
+            raise AttributeError(name)
+        raise TraceAttributeError("ndarray.%s is not traceable on a 2-D traced array" % name)
+
+    # -------------------------------------------------------------- indexing
+    def _row_index(self, i):
+        return _norm_index(i, len(self.rows))
+
+    def __getitem__(self, key):
+        if isinstance(key, (numbers.Integral, np.integer)):
+            return self.rows[self._row_index(key)]
+        if isinstance(key, slice):
+            picked = self.rows[key]
+            return SymMat(picked) if picked else np.zeros((0, self.shape[1]))
+        if isinstance(key, tuple) and len(key) == 2:
+            ri, ci = key
+            if isinstance(ri, (numbers.Integral, np.integer)):
+                return self.rows[self._row_index(ri)][ci]
+            if isinstance(ri, slice):
+                picked = self.rows[ri]
+                if isinstance(ci, (numbers.Integral, np.integer)):
+                    col = cat([r[ci] for r in picked])
+                    if isinstance(col, Sym):
+                        col._frozen = "a column view m[:, j]"
+                    return col
+                if isinstance(ci, slice) and ci == slice(None):
+                    return SymMat(picked)
+                sub = [r[ci] for r in picked]
+                for r in sub:
+                    if isinstance(r, Sym):
+                        r._frozen = "a sub-block view m[a:b, c:d]"
+                return SymMat(sub)
+        raise TraceError("unsupported index %r on a 2-D traced array" % (key,))
+
+    def __setitem__(self, key, value):
+        if isinstance(key, (numbers.Integral, np.integer)):
+            self.rows[self._row_index(key)][:] = value
+            return
+        if isinstance(key, slice):
+            key = (key, slice(None))
+        if isinstance(key, tuple) and len(key) == 2:
+            ri, ci = key
+            if isinstance(ri, (numbers.Integral, np.integer)):
+                self.rows[self._row_index(ri)][ci] = value
+                return
+            if isinstance(ri, slice):
+                picked = self.rows[ri]
+                if isinstance(value, SymMat):
+                    if len(value.rows) != len(picked):
+                        raise ValueError("shape mismatch in an assignment to a 2-D traced array")
+                    for r, v in zip(picked, value.rows):
+                        r[ci] = v
+                    return
+                if isinstance(ci, (numbers.Integral, np.integer)):
+                    v = value if isinstance(value, Sym) else np.asarray(value, dtype=np.float64)
+                    scalar = (isinstance(v, Sym) and v.length is None) or (not isinstance(v, Sym) and v.ndim == 0)
+                    if not scalar and len(v) != len(picked):
+                        raise ValueError("shape mismatch in an assignment to a column of a 2-D traced array")
+                    for k, r in enumerate(picked):
+                        r[ci] = v if scalar else v[k]
+                    return
+                arr = value if isinstance(value, Sym) else np.asarray(value, dtype=np.float64)
+                if not isinstance(arr, Sym) and arr.ndim == 2:
+                    if arr.shape[0] != len(picked):
+                        raise ValueError("shape mismatch in an assignment to a 2-D traced array")
+                    for r, v in zip(picked, arr):
+                        r[ci] = v
+                    return
+                for r in picked:                         # one row (or a scalar) broadcast over the rows
+                    r[ci] = arr
+                return
+        raise TraceError("unsupported index %r in an assignment to a 2-D traced array" % (key,))
+
+    # -------------------------------------------------------------- elementwise
+    def _operand_rows(self, other):
+        """The other operand of an elementwise operation, row by row (NumPy broadcasting against (r, c))."""
+        r, c = self.shape
+        if isinstance(other, SymMat):
+            if other.shape == (r, c):
+                return other.rows
+            if other.shape == (1, c):
+                return [other.rows[0]] * r
+            if other.shape == (r, 1):
+                return [row[0] for row in other.rows]
+            raise TraceError("shape mismatch in a traced elementwise operation: %r vs %r" % (self.shape, other.shape))
+        if isinstance(other, Sym):
+            if other.length in (None, 1, c):
+                return [other] * r
+            raise TraceError("shape mismatch in a traced elementwise operation: %r vs (%d,)" % (self.shape, other.length))
+        if isinstance(other, (numbers.Real, np.bool_)):
+            return [other] * r
+        arr = np.asarray(other, dtype=np.float64)
+        if arr.ndim <= 1 and arr.size in (1, c):
+            return [arr if arr.size == c and arr.ndim == 1 else float(arr.reshape(-1)[0])] * r
+        if arr.ndim == 2 and arr.shape == (r, c):
+            return [arr[i] for i in range(r)]
+        if arr.ndim == 2 and arr.shape == (r, 1):
+            return [float(arr[i, 0]) for i in range(r)]
+        if arr.ndim == 2 and arr.shape == (1, c):
+            return [arr[0]] * r
+        raise TraceError("shape mismatch in a traced elementwise operation: %r vs %r" % (self.shape, arr.shape))
+
+    def _map(self, fn, other=None, swap=False):
+        if other is None:
+            return SymMat([fn(row) for row in self.rows])
+        others = self._operand_rows(other)
+        out = []
+        for row, o in zip(self.rows, others):
+            v = fn(o, row) if swap else fn(row, o)
+            if v is NotImplemented:
+                raise TraceError("unsupported operand in a 2-D traced operation")
+            out.append(v if v.length is not None else cat([v]))
+        return SymMat(out)
+
+    @staticmethod
+    def _ufunc(ufunc, inputs):
+        if len(inputs) == 1:
+            return inputs[0]._map(lambda r: ufunc(r))
+        a, b = inputs
+        if isinstance(a, SymMat):
+            return a._map(lambda x, y: ufunc(x, y), b)
+        return b._map(lambda x, y: ufunc(x, y), a, swap=True)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method != "__call__" or kwargs.get("out") is not None:
+            raise TraceError("ufunc method %s.%s is not traceable" % (ufunc.__name__, method))
+        return SymMat._ufunc(ufunc, inputs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        return _array_function(func, args, kwargs)
+
+    def __neg__(self): return self._map(lambda r: -r)
+    def __pos__(self): return self.copy()
+    def __abs__(self): return self._map(abs)
+    def __add__(self, o): return self._map(lambda a, b: a + b, o)
+    def __radd__(self, o): return self._map(lambda a, b: a + b, o, swap=True)
+    def __sub__(self, o): return self._map(lambda a, b: a - b, o)
+    def __rsub__(self, o): return self._map(lambda a, b: a - b, o, swap=True)
+    def __mul__(self, o): return self._map(lambda a, b: a * b, o)
+    def __rmul__(self, o): return self._map(lambda a, b: a * b, o, swap=True)
+    def __truediv__(self, o): return self._map(lambda a, b: a / b, o)
+    def __rtruediv__(self, o): return self._map(lambda a, b: a / b, o, swap=True)
+    def __pow__(self, o): return self._map(lambda a, b: a ** b, o)
+    def __rpow__(self, o): return self._map(lambda a, b: a ** b, o, swap=True)
+    def __mod__(self, o): return self._map(lambda a, b: a % b, o)
+    def __lt__(self, o): return self._map(lambda a, b: a < b, o)
+    def __le__(self, o): return self._map(lambda a, b: a <= b, o)
+    def __gt__(self, o): return self._map(lambda a, b: a > b, o)
+    def __ge__(self, o): return self._map(lambda a, b: a >= b, o)
+    __hash__ = None
+
+    def _inplace(self, fn, o):
+        others = self._operand_rows(o)
+        for row, v in zip(self.rows, others):
+            fn(row, v)
+        return self
+
+    def __iadd__(self, o): return self._inplace(lambda r, v: r.__iadd__(v), o)
+    def __isub__(self, o): return self._inplace(lambda r, v: r.__isub__(v), o)
+    def __imul__(self, o): return self._inplace(lambda r, v: r.__imul__(v), o)
+    def __itruediv__(self, o): return self._inplace(lambda r, v: r.__itruediv__(v), o)
+
+    def __matmul__(self, o):
+        return matmul(self, o)
+
+    def __rmatmul__(self, o):
+        return matmul(o, self)
+
+    # -------------------------------------------------------------- reductions
+    def _reduce(self, op, axis):
+        """NumPy's order: along the last (contiguous) axis a row is reduced like a 1-D vector (pairwise sums); along
+        axis 0 the rows are combined one after the other, elementwise; over both axes the C-ordered buffer is one
+        1-D reduction."""
+        r, c = self.shape
+        if axis is None:
+            flat = self.ravel()
+            return getattr(flat, op)()
+        if axis in (1, -1):
+            return cat([getattr(Sym(self.g, row.id), op)() for row in self.rows])
+        if axis in (0, -2):
+            if op in ("sum", "mean"):
+                acc = Sym(self.g, self.rows[0].id)
+                for row in self.rows[1:]:
+                    acc = acc + row
+                return acc / float(r) if op == "mean" else acc
+            if op == "prod":
+                acc = Sym(self.g, self.rows[0].id)
+                for row in self.rows[1:]:
+                    acc = acc * row
+                return acc
+            acc = Sym(self.g, self.rows[0].id)
+            for row in self.rows[1:]:
+                acc = acc._binary(op, row)
+            return acc
+        raise TraceError("%s(axis=%r) of a 2-D traced array" % (op, axis))
+
+    def sum(self, axis=None): return self._reduce("sum", axis)
+    def mean(self, axis=None): return self._reduce("mean", axis)
+    def prod(self, axis=None): return self._reduce("prod", axis)
+    def min(self, axis=None): return self._reduce("min", axis)
+    def max(self, axis=None): return self._reduce("max", axis)
+
+
+# ----------------------------------------------------------------------------- NumPy constructors while tracing
+_ACTIVE_GRAPH = None
+_OWN_MODULES = ("numpy", "scipy", __name__.rsplit(".", 1)[0] + ".optimize", __name__, __name__.rsplit(".", 1)[0] + ".codegen")
+
+
+def _from_user_code(depth=2):
+    """Was the patched constructor called by a callback (and not by NumPy / SciPy internals or this package's own
+    mirror of the reference classes, which must keep getting plain arrays)?"""
+    import sys
+    mod = sys._getframe(depth).f_globals.get("__name__", "")
+    return not any(mod == own or mod.startswith(own + ".") for own in _OWN_MODULES)
+
+
+def _has_traced(obj, depth=0):
+    if isinstance(obj, (Sym, SymMat)):
+        return True
+    if isinstance(obj, (list, tuple)) and depth < 3:
+        return any(_has_traced(o, depth + 1) for o in obj)
+    return False
+
+
+class tracing_numpy:
+    """While the callbacks are traced, the NumPy constructors a callback uses to make its OUTPUT buffer -
+    ``np.zeros / ones / empty / full (n)`` and ``((r, n))`` - return traced constants, so that ``out[i] = expression``
+    records an assignment instead of asking NumPy to store a traced value in a float array; ``np.array`` /
+    ``np.asarray`` of traced pieces build traced vectors / 2-D arrays.  Calls from NumPy's and SciPy's own code and
+    from this package's mirror classes are passed through untouched."""
+
+    NAMES = ("zeros", "ones", "empty", "full", "array", "asarray", "asanyarray")
+
+    def __init__(self, graph):
+        self.graph = graph
+
+    def __enter__(self):
+        global _ACTIVE_GRAPH
+        self._saved_graph = _ACTIVE_GRAPH
+        _ACTIVE_GRAPH = self.graph
+        self._orig = {name: getattr(np, name) for name in self.NAMES}
+        orig = self._orig
+
+        def make_filled(name, fill_of):
+            def ctor(shape, *args, **kwargs):
+                g = _ACTIVE_GRAPH
+                dtype = kwargs.get("dtype", args[1] if name == "full" and len(args) > 1 else
+                                   (args[0] if name != "full" and args else None))
+                plain = (g is None or not _from_user_code() or set(kwargs) - {"dtype", "fill_value"}
+                         or (dtype is not None and np.dtype(dtype) != np.float64))
+                fill = fill_of(args, kwargs)
+                if not plain and not isinstance(fill, Sym):
+                    if isinstance(shape, (numbers.Integral, np.integer)):
+                        shape = (int(shape),)
+                    if isinstance(shape, (tuple, list)) and all(isinstance(v, (numbers.Integral, np.integer)) for v in shape):
+                        if len(shape) == 1 and shape[0] > 0:
+                            return Sym(g, g.cvec(np.full(int(shape[0]), float(fill))))
+                        if len(shape) == 2 and shape[0] > 0 and shape[1] > 0:
+                            return SymMat.filled(g, shape, fill)
+                return orig[name](shape, *args, **kwargs)
+            ctor.__name__ = name
+            return ctor
+
+        def array(obj, *args, **kwargs):
+            if _ACTIVE_GRAPH is not None and _has_traced(obj):
+                dtype = kwargs.get("dtype", args[0] if args else None)
+                if dtype is not None and np.dtype(dtype) != np.float64:
+                    raise TraceError("np.array(..., dtype=%s) of traced values: callbacks are traced in float64" % (dtype,))
+                return _array_of(obj, copy=kwargs.get("copy", True) is not False)
+            return orig["array"](obj, *args, **kwargs)
+
+        def asarray(obj, *args, **kwargs):
+            if _ACTIVE_GRAPH is not None and _has_traced(obj):
+                return _array_of(obj, copy=False)
+            return orig["asarray"](obj, *args, **kwargs)
+
+        def asanyarray(obj, *args, **kwargs):
+            if _ACTIVE_GRAPH is not None and _has_traced(obj):
+                return _array_of(obj, copy=False)
+            return orig["asanyarray"](obj, *args, **kwargs)
+
+        np.zeros = make_filled("zeros", lambda a, k: 0.0)
+        np.ones = make_filled("ones", lambda a, k: 1.0)
+        np.empty = make_filled("empty", lambda a, k: 0.0)
+        np.full = make_filled("full", lambda a, k: k["fill_value"] if "fill_value" in k else a[0])
+        np.array, np.asarray, np.asanyarray = array, asarray, asanyarray
+        return self
+
+    def __exit__(self, *exc):
+        global _ACTIVE_GRAPH
+        for name, fn in self._orig.items():
+            setattr(np, name, fn)
+        _ACTIVE_GRAPH = self._saved_graph
+        return False
+
+
+def _array_of(obj, copy=True):
+    """``np.array(obj)`` where ``obj`` is, or contains, traced values."""
+    if isinstance(obj, (Sym, SymMat)):
+        return obj.copy() if copy else obj
+    items = list(obj)
+    if all((isinstance(it, Sym) and it.length is None) or isinstance(it, (numbers.Real, np.bool_))
+           or (isinstance(it, np.ndarray) and it.ndim == 0) for it in items):
+        return cat(items)                                      # a list of scalars: a 1-D vector
+    return SymMat.vstack([_array_of(it) if isinstance(it, (list, tuple)) and _has_traced(it) else it for it in items],
+                         rows_only=True)
+
+
+class tracing:
+    """Everything that is patched while callbacks run on the symbolic decision vector."""
+
+    def __init__(self, graph):
+        self._ctx = (intercept_interp1d(), tracing_numpy(graph))
+
+    def __enter__(self):
+        for c in self._ctx:
+            c.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        for c in reversed(self._ctx):
+            c.__exit__(*exc)
         return False
 
 

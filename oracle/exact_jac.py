@@ -54,6 +54,15 @@ def _hypot(a, b):
         return h + 1j * np.where(h != 0, (_re(a) * np.imag(a) + _re(b) * np.imag(b)) / h, 0.0)
 
 
+def _mod(a, b, which):
+    """remainder / fmod: piecewise a - q b with q = floor (trunc) of a / b constant between the jumps"""
+    ra, rb = _re(a), _re(b)
+    with np.errstate(all="ignore"):
+        q = np.floor(ra / rb) if which == "mod" else np.trunc(ra / rb)
+        val = np.remainder(ra, rb) if which == "mod" else np.fmod(ra, rb)
+        return val + 1j * (np.imag(a) - np.where(np.isfinite(q), q, 0.0) * np.imag(b))
+
+
 class _ComplexEval(program_eval._Eval):
     def __init__(self, P, x, D):
         super().__init__(P, np.real(x), D)
@@ -77,6 +86,8 @@ class _ComplexEval(program_eval._Eval):
             out = _cbrt(self.elem(node[2], length, memo))
         elif tag == "bin" and node[1] == "hypot":
             out = _hypot(self.elem(node[2], length, memo), self.elem(node[3], length, memo))
+        elif tag == "bin" and node[1] in ("mod", "fmod"):
+            out = _mod(self.elem(node[2], length, memo), self.elem(node[3], length, memo), node[1])
         elif tag == "bin" and node[1] in ("max", "min", "atan2"):
             a, b = self.elem(node[2], length, memo), self.elem(node[3], length, memo)
             out = {"max": _max, "min": _min, "atan2": _atan2}[node[1]](a, b)

@@ -15,7 +15,8 @@ _UN = {"neg": np.negative, "sqrt": np.sqrt, "exp": np.exp, "log": np.log, "sin":
        "acos": np.arccos, "tanh": np.tanh, "sinh": np.sinh, "cosh": np.cosh, "expm1": np.expm1,
        "log1p": np.log1p, "log2": np.log2, "log10": np.log10, "cbrt": np.cbrt}
 _BIN = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.true_divide,
-        "max": np.maximum, "min": np.minimum, "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power}
+        "max": np.maximum, "min": np.minimum, "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power,
+        "mod": np.remainder, "fmod": np.fmod}
 _CMP = {"lt": np.less, "le": np.less_equal, "gt": np.greater, "ge": np.greater_equal,
         "eq": np.equal, "ne": np.not_equal}
 

@@ -260,9 +260,73 @@ def wide_reductions():
     return prob, Params()
 
 
+def preallocated_outputs():
+    """Round 4: callbacks that BUILD their result the way users write them - ``out = np.zeros(n)`` filled by item and
+    by slice, ``np.empty`` + in-place slice arithmetic, ``np.zeros_like``, ``np.array([...])`` of traced scalars,
+    ``np.vstack`` / 2-D buffers with ``axis=`` reductions, ``np.prod``, ``%``, ``np.trapz``, ``np.heaviside``."""
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+
+    def dynamics(prob, obj, section):
+        n = prob.nodes[section]
+        x = prob.states(0, section)
+        v = prob.states(1, section)
+        u = prob.controls(0, section)
+        acc = np.zeros(n)                                # allocated in the callback ...
+        acc[:] = u - 0.3 * v * np.heaviside(v, 0.5)      # ... filled through a slice
+        acc *= 1.0 + 0.1 * (x % 0.37)                    # in-place arithmetic; Python's % on traced values
+        drift = np.zeros_like(x)
+        drift += 0.01 * np.mod(x, -0.6)
+        dx = Dynamics(prob, section)
+        dx[0] = v + drift
+        dx[1] = acc
+        return dx()
+
+    def equality(prob, obj):
+        x = prob.states_all_section(0)
+        v = prob.states_all_section(1)
+        t = prob.time_update()
+        ends = np.array([x[0] - 0.1, v[0], x[-1] * v[-1]])            # np.array of traced scalars
+        both = np.vstack([x[0:6], v[0:6], np.linspace(0.0, 1.0, 6)])    # 2-D of traced rows
+        rows = Condition()
+        rows.equal(ends, np.array([0.0, 0.2, 0.05]))
+        rows.equal(both.sum(axis=0)[1:4], 0.3)
+        rows.equal(trapz(v * v, t), 0.4)
+        rows.equal(np.prod(1.0 + 0.1 * x[0:5]), 1.2)
+        return rows()
+
+    def inequality(prob, obj):
+        u = prob.controls_all_section(0)
+        x = prob.states_all_section(0)
+        out = np.empty(8)
+        for i in range(4):
+            out[i] = 2.0 - u[i] * u[i + 1]
+        out[4:] = 3.0 - np.abs(x[4:8])
+        out[1:3] *= 2.0                                  # in-place arithmetic on a slice of the buffer
+        out[::4] = out[::4] + 0.5                        # strided targets
+        table = np.zeros((2, 5))
+        table[0] = u[0:5]
+        table[1, :] = x[0:5] ** 2
+        table[:, 4] = np.array([u[5], 0.25])
+        rows = Condition()
+        rows.lower_bound(out, 0.0)
+        rows.upper_bound(table.max(axis=0) + table.mean(axis=1)[0], 6.0)
+        rows.lower_bound(np.stack([u[0:3], x[0:3]], axis=1).ravel(), -4.0)
+        return rows()
+
+    prob = Problem([0.0, 1.2], [18], [2], [1], 3)
+    rng = np.random.default_rng(23)
+    prob.p[:-1] = rng.uniform(-1.0, 1.0, prob.number_of_variables - 1)
+    prob.dynamics = [dynamics]
+    prob.cost = lambda prob, obj: np.sum(np.array([prob.controls(0, 0)[0:9], prob.controls(0, 0)[9:18]]) ** 2)
+    prob.equality = equality
+    prob.inequality = inequality
+    return prob, Params()
+
+
 CASES = {"bryson_denham": bryson_denham, "ragged_two_phase": ragged_two_phase,
          "smooth_knots": smooth_knots, "running_cost_shapes": running_cost_shapes,
-         "wide_functions": wide_functions, "wide_reductions": wide_reductions}
+         "wide_functions": wide_functions, "wide_reductions": wide_reductions,
+         "preallocated_outputs": preallocated_outputs}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

@@ -45,7 +45,7 @@ def test_twin_exact_jacobian_matches_complex_step(name):
         assert np.max(np.abs(JE - JC) / scale) <= 1e-13
 
 
-@pytest.mark.parametrize("case", ["wide_functions", "wide_reductions"])
+@pytest.mark.parametrize("case", ["wide_functions", "wide_reductions", "preallocated_outputs"])
 def test_twin_exact_jacobian_of_the_widened_function_set(case):
     """Round 3's functions and reductions in exact mode: the derivative rules of og_dual.h (tanh, sinh, cosh, expm1,
     log1p, log2, log10, cbrt, hypot, x ** y) and the expanded sums against complex-step differentiation."""

@@ -26,6 +26,8 @@ void v_atan2(const double* yy, const double* xx, double* o, int n) { for (int i 
 V1(expm1) V1(log1p) V1(sinh) V1(cosh) V1(tanh) V1(log2) V1(log10) V1(cbrt)
 void v_hypot(const double* a, const double* b, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = ogm::hypot_(a[i], b[i]); }
 void v_pow(const double* a, const double* b, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = ogm::pow_(a[i], b[i]); }
+void v_mod(const double* a, const double* b, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = ogm::mod_(a[i], b[i]); }
+void v_fmod(const double* a, const double* b, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = ogm::fmod_(a[i], b[i]); }
 }
 """
 
@@ -201,3 +203,25 @@ def test_hypot_pow_and_special_values_of_the_widened_set(lib):
     assert call(lib, "v_cosh", [0.0, 800.0, -800.0]).tolist() == [1.0, inf, inf]
     assert call(lib, "v_sinh", [800.0, -800.0]).tolist() == [inf, -inf]
     assert call2(lib, "v_hypot", [inf, nan, 0.0, 3.0], [nan, 1.0, 0.0, 4.0]).tolist()[::3] == [inf, 5.0]
+
+
+def test_mod_and_fmod_are_numpys_bit_for_bit(lib):
+    """np.remainder (= np.mod, Python's %: the divisor's sign) and np.fmod (the dividend's sign) are exact operations:
+    the device functions must give NumPy's bits, signed zeros and special values included."""
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-50, 50, 200000) * 10.0 ** rng.integers(-3, 6, 200000)
+    b = rng.uniform(-5, 5, 200000)
+    b[b == 0.0] = 1.0
+    for name, ref in (("v_mod", np.remainder), ("v_fmod", np.fmod)):
+        assert np.array_equal(call2(lib, name, a, b), ref(a, b))
+        assert np.array_equal(call2(lib, name, np.round(a), np.round(b) + (np.round(b) == 0)),
+                              ref(np.round(a), np.round(b) + (np.round(b) == 0)))
+    inf, nan = np.inf, np.nan
+    aa = np.array([6.0, -6.0, 6.0, -6.0, 0.0, -0.0, 5.0, 5.0, inf, 5.0, -5.0, nan, 1.0, 7.5, -7.5])
+    bb = np.array([3.0, 3.0, -3.0, -3.0, 2.0, 2.0, 0.0, -0.0, 2.0, inf, inf, 1.0, nan, -2.0, 2.0])
+    with np.errstate(all="ignore"):
+        for name, ref in (("v_mod", np.remainder), ("v_fmod", np.fmod)):
+            got, want = call2(lib, name, aa, bb), ref(aa, bb)
+            assert np.array_equal(got, want, equal_nan=True)
+            assert np.array_equal(np.signbit(got), np.signbit(want)) or np.array_equal(
+                np.signbit(got[~np.isnan(want)]), np.signbit(want[~np.isnan(want)]))

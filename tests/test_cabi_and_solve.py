@@ -144,3 +144,35 @@ def test_shipped_example_scripts_run_unmodified(tag, script, golden, lgl_golden,
     P = codegen.trace_problem(prob, obj)
     assert np.array_equal(program_eval.evaluate(P, prob, G["x"][1]), G["F"][1])
     assert "struct OgGen" in codegen.emit_header(P)
+
+
+@pytest.mark.parametrize("name,delimiter,tag", [("brachistochrone", ",", ""), ("polar_tsto_shipped", ",", ""),
+                                                 ("polar_tsto_shipped", ";", "_semicolon")])
+def test_to_csv_writes_the_reference_bytes(name, delimiter, tag, lgl_golden, tmp_path, capsys):
+    """``Problem.to_csv`` (the reference's wire format, ``optimize.py:844-863``) against
+    files written by the reference itself (tools/make_golden_csv.py): header text, delimiter, ``%.18e``, column order
+    and - with the reference's own LGL nodes injected - every byte.  With this package's nodes the file has the same
+    shape and differs only in the time column's last place."""
+    from conftest import inject_reference_lgl
+    want = open(os.path.join(ROOT, "tests", "golden", "to_csv_%s%s.csv" % (name, tag)), "rb").read()
+
+    def write(inject):
+        prob, obj = problems.build(name)
+        if inject:
+            inject_reference_lgl(prob, lgl_golden)
+        rng = np.random.default_rng(20260928)                  # the point of tools/make_golden_csv.py: move()
+        prob.p = rng.uniform(0.1, 1.0, prob.p.size)
+        prob.p[-prob.number_of_section:] = np.cumsum(rng.uniform(0.2, 0.7, prob.number_of_section))
+        path = tmp_path / ("out_%d.csv" % inject)
+        prob.to_csv(str(path), delimiter=delimiter)
+        assert 'Completed saving "%s"' % path in capsys.readouterr().out       # the reference's message
+        return open(path, "rb").read()
+
+    assert write(True) == want
+    own = write(False)
+    own_lines, want_lines = own.decode().splitlines(), want.decode().splitlines()
+    assert own_lines[0] == want_lines[0] and len(own_lines) == len(want_lines)
+    a = np.array([[float(v) for v in line.split(delimiter)] for line in own_lines[1:]])
+    b = np.array([[float(v) for v in line.split(delimiter)] for line in want_lines[1:]])
+    assert np.array_equal(a[:, 1:], b[:, 1:])                                   # states and controls: the same numbers
+    assert np.max(np.abs(a[:, 0] - b[:, 0])) <= 4e-15 * max(1.0, np.abs(b[:, 0]).max())

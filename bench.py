@@ -185,7 +185,18 @@ def sqp_first_qp_parity(eng, prob, lb, ub):
         core.set_active()
         d, mult, bm, status, iters = core.solve(A, g, c, lo, hi, True, 100.0)
         assert status == ref[3] == 1, "relaxed first QP: exit mode %d, restatement %d" % (status, ref[3])
+    hip_active = sorted(int(v) for v in core.get_active())
     core.close()
+    # the referee (oracle/qp_referee.py): the exact step of THIS subproblem on the reported active set, by iterative
+    # refinement with np.longdouble residuals - how far each of the two solvers is from it
+    from oracle import qp_referee
+    mg = A.shape[0] - meq
+    ref_active = sorted(j if kind == "g" else mg + 2 * j + (1 if kind == "u" else 0) for kind, j in ref[5]["active"])
+    if relaxed:
+        Zr, gr, Ar, lor, hir = Za, np.append(g, 0.0), Aa, lo, hi
+    else:
+        Zr, gr, Ar, lor, hir = np.eye(n), g, A, lb - x, ub - x
+    dist, _, rinfo = qp_referee.distances(Zr, gr, Ar, c, lor, hir, meq, ref_active, {"hip": d, "restatement": ref[0]})
     scale = max(1.0, float(np.abs(ref[0]).max()))
     step_err = float(np.max(np.abs(d - ref[0])) / scale)
     # vertex solutions at these sizes are ill-conditioned (tests/test_slsqp_core.py measures the amplification):
@@ -195,6 +206,11 @@ def sqp_first_qp_parity(eng, prob, lb, ub):
     return {"parity_checked": True, "first_qp_relaxed": relaxed, "first_qp_exit_mode": int(status),
             "first_qp_step_error_rel": step_err, "first_qp_active_set_changes": int(iters),
             "first_qp_active_set_changes_restatement": int(ref[5]["ldp_iterations"]),
+            "first_qp_same_active_set": hip_active == ref_active,
+            "first_qp_distance_to_refined_solution": {"hip": dist["hip"], "restatement": dist["restatement"],
+                                                      "active_rows": rinfo["active_rows"],
+                                                      "referee_converged_to": max(rinfo["step_moved"][-3:]),
+                                                      "referee": "oracle/qp_referee.py (np.longdouble residuals)"},
             "checker": "oracle/slsqp_np.py qp_solve (LAPACK LQ), %.1f s of CPU" % (time.perf_counter() - t0)}
 
 

@@ -421,13 +421,11 @@ class Problem:
         devices = options.pop("devices", None)
         if devices is None and os.environ.get("OG_DEVICES"):
             devices = [int(v) for v in os.environ["OG_DEVICES"].split(",")]
-        if devices is not None and len(devices) > 1 and (ENGINE_FACTORY is not None or core == "hip"):
-            # not silently: the HIP SQP core consumes the Jacobian on ONE device (sqp.DeviceJacobian sweeps there), and a
-            # stand-in engine has no devices at all
+        if devices is not None and len(devices) > 1 and ENGINE_FACTORY is not None:
+            # not silently: a stand-in engine has no devices at all
             import warnings
-            warnings.warn("Problem.solve: devices=%r is not used with %s; the sweep runs on device %d only"
-                          % (list(devices), "a stand-in engine" if ENGINE_FACTORY is not None else "sqp_core='hip'",
-                             int(devices[0])), RuntimeWarning, stacklevel=2)
+            warnings.warn("Problem.solve: devices=%r is not used with a stand-in engine" % (list(devices),),
+                          RuntimeWarning, stacklevel=2)
         if ENGINE_FACTORY is not None:
             engine = ENGINE_FACTORY(self, obj)
         else:

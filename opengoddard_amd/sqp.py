@@ -48,7 +48,14 @@ class SqpResult(dict):
 
 
 class DeviceJacobian:
-    """The transposed FD Jacobian of one engine, resident in HBM (torch owns the allocation)."""
+    """The transposed FD Jacobian of one engine, resident in HBM.
+
+    One device: torch owns ``x | h | F0 | J_T`` and the sweep writes into them (``og_fd_sweep_dev``).  An engine
+    made with ``devices=[d0, d1, ...]`` shards the FD columns of every sweep over those GPUs
+    (``og_multi_fd_sweep_enqueue``: one launch per device, one all-gather of the packed non-zeros) and the QP core
+    reads device d0's replica of the whole matrix in place (``og_multi_replica_dev(g = 0)``), stream-ordered behind
+    the exchange - the Jacobian takes no trip through the host either way.  The exact-Jacobian mode is a
+    single-device kernel and uses the first form."""
 
     def __init__(self, engine):
         import torch
@@ -56,34 +63,75 @@ class DeviceJacobian:
             raise RuntimeError("the HIP SQP core needs a GPU (no CPU fallback)")
         self.engine = engine
         self.torch = torch
-        dev = torch.device("cuda", engine.device)
         self.n, self.ld = engine.n, engine.m                 # ld = 1 + m_eq + m_ineq
-        self.d_x = torch.empty(self.n, dtype=torch.float64, device=dev)
-        self.d_h = torch.empty(self.n, dtype=torch.float64, device=dev)
-        self.d_F0 = torch.empty(self.ld, dtype=torch.float64, device=dev)
-        self.d_JT = torch.empty(self.n * self.ld, dtype=torch.float64, device=dev)
-        self.stream = torch.cuda.current_stream(dev).cuda_stream
-        # persistent-zero output: every sweep of the solve writes the non-zeros only (include/ogpsx.h)
-        engine.register_jt_dev(self.d_JT.data_ptr(), 0, self.n, self.stream)
+        self._own = None                                     # (x, h, F0, JT, stream) of the one-device form
+        self._multi = None
+        multi = getattr(engine, "_multi", None)
+        if multi is not None and multi.value:
+            import ctypes as C
+            jt, f0, stream = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            _native.check(engine._lib.og_multi_replica_dev(multi, 0, C.byref(jt), C.byref(f0), C.byref(stream)),
+                          "og_multi_replica_dev")
+            self._multi = (multi, jt.value, f0.value, stream.value or 0)
+        else:
+            self._single()
+        self._last = "multi" if self._multi else "own"
+
+    def _single(self):
+        if self._own is None:
+            torch, engine = self.torch, self.engine
+            dev = torch.device("cuda", engine.device)
+            d_x = torch.empty(self.n, dtype=torch.float64, device=dev)
+            d_h = torch.empty(self.n, dtype=torch.float64, device=dev)
+            d_F0 = torch.empty(self.ld, dtype=torch.float64, device=dev)
+            d_JT = torch.empty(self.n * self.ld, dtype=torch.float64, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            # persistent-zero output: every sweep of the solve writes the non-zeros only (include/ogpsx.h)
+            engine.register_jt_dev(d_JT.data_ptr(), 0, self.n, stream)
+            self._own = (d_x, d_h, d_F0, d_JT, stream)
+        return self._own
 
     def sweep(self, x, lb, ub):
         """One FD sweep at ``x`` (SciPy's step rule); returns F(x) on the host."""
         torch = self.torch
         h = _native.fd_step(x, lb, ub)
         self.last_step = h
-        self.d_x.copy_(torch.from_numpy(np.ascontiguousarray(x)))
-        if getattr(self.engine, "jacobian_mode", "fd") == "exact":
-            self.engine.exact_dev(self.d_x.data_ptr(), 0, self.n, self.d_JT.data_ptr(), self.d_F0.data_ptr(),
-                                  self.stream)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        exact = getattr(self.engine, "jacobian_mode", "fd") == "exact"
+        if self._multi and not exact:
+            multi, _, d_f0, _ = self._multi
+            lib = self.engine._lib
+            _native.check(lib.og_multi_fd_sweep_enqueue(multi, _native.dptr(x), _native.dptr(h)),
+                          "og_multi_fd_sweep_enqueue")
+            F0 = np.empty(self.ld)
+            # (synchronises device d0: its replica is complete when its stream - sweep, exchange, unpack - is)
+            _native.check(lib.og_device_read(int(self.engine.device), d_f0, F0.ctypes.data, 8 * self.ld),
+                          "og_device_read")
+            self._last = "multi"
+            return F0
+        d_x, d_h, d_F0, d_JT, stream = self._single()
+        self._last = "own"
+        d_x.copy_(torch.from_numpy(x))
+        if exact:
+            self.engine.exact_dev(d_x.data_ptr(), 0, self.n, d_JT.data_ptr(), d_F0.data_ptr(), stream)
         else:
-            self.d_h.copy_(torch.from_numpy(h))
-            self.engine.sweep_dev(self.d_x.data_ptr(), self.d_h.data_ptr(), 0, self.n, self.d_JT.data_ptr(),
-                                  self.d_F0.data_ptr(), self.stream)
-        return self.d_F0.cpu().numpy()
+            d_h.copy_(torch.from_numpy(h))
+            self.engine.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), 0, self.n, d_JT.data_ptr(), d_F0.data_ptr(), stream)
+        return d_F0.cpu().numpy()
 
     @property
     def ptr(self):
-        return self.d_JT.data_ptr()
+        """Device address of the matrix the LAST sweep wrote."""
+        return self._multi[1] if self._last == "multi" else self._own[3].data_ptr()
+
+    @property
+    def stream(self):
+        return self._multi[3] if self._last == "multi" else self._own[4]
+
+    @property
+    def sharded_over(self):
+        """Number of devices the last sweep was split over."""
+        return len(self.engine.devices) if self._last == "multi" else 1
 
 
 # capacity of the QP core (include/ogsqp.h, csrc/ogsqp.hip og_qp_create / rows_lds_bytes): row segments of the panel

@@ -122,6 +122,37 @@ def test_gpu_exact_jacobian_is_bit_identical_to_the_twin(name, layout, monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,count", [("polar_tsto", 160), ("low_thrust", 120), ("launch4", 72)])
+def test_gpu_exact_jacobian_against_complex_step_at_baseline_sizes(name, count):
+    """VERDICT r3 next #5a: at C3, C4 and C5 the GPU's exact Jacobian against ``oracle/exact_jac.py`` - complex-step
+    differentiation of the lowered program with NumPy's own complex functions, run on the box - which shares neither
+    the generated header nor ``og_dual.h`` with the kernel (the twin does).  A spread of columns over every variable
+    block plus all final-time columns (the heavy ones), at a generic point; the structural zeros outside are checked
+    through the full matrix's zero pattern against the FD sweep's."""
+    from opengoddard_amd.engine import HipEngine
+    prob, obj = problems.build(name)
+    eng = HipEngine(prob, obj)
+    lb, ub = np_path.bounds_arrays(prob)
+    x = _points(prob, lb, ub)[1]
+    n, S = eng.n, len(prob.nodes)
+    cols = np.unique(np.r_[np.linspace(0, n - S - 1, count).astype(int), np.arange(n - S, n)]).astype(np.int32)
+    F0, JE = eng.exact_stacked(x)
+    assert np.array_equal(F0, eng.eval_stacked(x)) and np.all(np.isfinite(JE))
+    JC = exact_jac.jacobian(eng.program, prob, x, list(cols))
+    scale = np.maximum(1.0, np.abs(JC).max(axis=0))[None, :]
+    assert np.max(np.abs(JE[cols] - JC) / scale) <= 1e-12
+    # column ranges give the same rows
+    lo, hi = n // 3, n // 3 + 40
+    assert np.array_equal(eng.exact_stacked(x, lo, hi)[1], JE[lo:hi])
+    # nothing outside the FD sweep's structural pattern (og_pattern is the traced dependency pattern of both)
+    indptr, rows = eng.pattern()
+    mask = np.zeros(JE.shape, dtype=bool)
+    mask[np.repeat(np.arange(n), np.diff(indptr)), rows] = True
+    assert not np.any(JE[~mask])
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("update", ["single", "coop"])
 @pytest.mark.parametrize("name,maxiter,ftol,converges", [("goddard", 600, 1e-10, True),
                                                          ("polar_tsto_shipped", 40, 1e-6, False)])

@@ -47,3 +47,32 @@ def test_solve_records_q13_like_the_reference():
     x = np.frombuffer(eng._jac_key, dtype=np.float64)
     assert np.array_equal(prob.p[:-1], x[:-1]) and prob.p[-1] == x[-1] + h[-1]
     eng.close()
+
+
+def test_devices_and_the_hip_sqp_core_work_together(monkeypatch, capsys):
+    """``Problem.solve(devices=[...])`` with the default SQP core at a size BASELINE shards (C4, split in 4).
+    The FD columns of every sweep are split over the listed devices (peer mode lets the 1-GPU box list device 0 four times:
+    four sub-handles, four streams, the real exchange), the QP core reads device d0's replica in place - and the run is
+    the single-device run, bit for bit: the sharded matrix is the same matrix, so every iterate is the same."""
+    import warnings
+    monkeypatch.setenv("OGPSX_GATHER", "peer")
+
+    def run(devices):
+        prob, obj = problems.build("low_thrust")
+        prob.maxIterator = 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)          # no "devices= is not used" warning any more
+            prob.solve(obj, maxiter=8, devices=devices)
+        capsys.readouterr()
+        eng = prob._engine
+        jac = eng._sqp_cache[0]
+        out = (prob.last_result.x.copy(), prob.p.copy(), prob.last_result.nit, prob.last_result.nfev,
+               prob.last_result.fun, prob.sqp_core_used, jac.sharded_over)
+        eng.close()
+        return out
+
+    one = run(None)
+    four = run([0, 0, 0, 0])
+    assert one[5] == four[5] == "hip" and one[6] == 1 and four[6] == 4
+    assert np.array_equal(one[0], four[0]) and np.array_equal(one[1], four[1])
+    assert one[2:5] == four[2:5]

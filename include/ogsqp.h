@@ -97,6 +97,13 @@ int og_qp_solve(og_qp_handle qp, const double* A, const double* g, const double*
 int og_qp_get_active(og_qp_handle qp, int32_t* ids, int32_t capacity, int32_t* count);
 int og_qp_set_active(og_qp_handle qp, const int32_t* ids, int32_t count);
 
+/* How many subproblems of this handle were solved twice: the default kernels of the LQ sweep (look-ahead inside one
+ * launch) and of the triangular solves (one chained launch) hand data between workgroups of a launch with bounded
+ * waits; when a wait gives up - a device shared with other streams or tenants - og_qp_solve(_dev) re-runs the
+ * subproblem with the separate-launch forms (same result to rounding) instead of failing.  OGSQP_SPIN_LIMIT=<n>
+ * shortens the bound (tests force the path with 1).  No reference counterpart. */
+int og_qp_recoveries(og_qp_handle qp, int32_t* count);
+
 /* Powell-damped BFGS (slsqp label 260-320) on the factor: s = step, eta = change of the
  * Lagrangian gradient, Bs = B s.  *reset_needed = 1 when the update is undefined (s'Bs or the
  * damped s'eta not positive) and the factor was left unchanged. */

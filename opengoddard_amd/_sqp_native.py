@@ -29,6 +29,7 @@ SIGNATURES = {
                               _dp, _ip, _ip]),
     "og_qp_get_active": (C.c_int, [C.c_void_p, _ip, C.c_int32, _ip]),
     "og_qp_set_active": (C.c_int, [C.c_void_p, _ip, C.c_int32]),
+    "og_qp_recoveries": (C.c_int, [C.c_void_p, _ip]),
     "og_qp_bfgs": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "og_jt_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _dp, _dp, C.c_void_p]),
     "og_qp_last_error": (C.c_char_p, []),
@@ -145,6 +146,12 @@ class QpCore:
         """Replace the warm-start rows; ``set_active()`` makes the next solve start from the empty active set."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         check(self._lib.og_qp_set_active(self._handle, ids.ctypes.data_as(_ip), int(ids.size)), "og_qp_set_active")
+
+    def recoveries(self):
+        """Subproblems that were re-run with the separate-launch kernels after an inter-workgroup wait gave up."""
+        count = C.c_int32(0)
+        check(self._lib.og_qp_recoveries(self._handle, C.byref(count)), "og_qp_recoveries")
+        return count.value
 
     def bfgs(self, s, eta, Bs):
         """Damped BFGS on the factor; returns True when the caller has to reset instead."""

@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void k_trsv_block(const double* __restrict__ T
 // it.  Transposed (L' x = rhs): the same from the last block down, with the tiles L(c, b)'.  Publication is the
 // solution vector itself: it starts as a NaN with a payload no computation produces (k_trsv_prepare), the owner
 // stores the values with agent scope, readers poll them with agent-scope loads.  At most 128 workgroups (n <= 8191):
-// all resident, each waits only for workgroups before it in the chain, and a wait that gives up says so (flag[2]).
+// all resident, each waits only for workgroups before it in the chain, and a wait that gives up says so (flag[3]).
 // Per block the chain pays one trip through memory and two 64 x 64 products (~2.7 us); all other tiles of a block
 // row are applied while the chain is still further up.
 constexpr unsigned long long TRSV_PENDING = 0x7ff8dead5eedcafeull;
@@ -960,7 +960,8 @@ __global__ __launch_bounds__(256) void k_trsv_chain(const double* __restrict__ T
                                                     int meq, int transposed, const double* __restrict__ rhs,
                                                     double* __restrict__ sol, const double* __restrict__ scal,
                                                     const double* __restrict__ dthresh, int* __restrict__ flag,
-                                                    const double* __restrict__ Linv, const int* __restrict__ has_gone) {
+                                                    const double* __restrict__ Linv, const int* __restrict__ has_gone,
+                                                    int spin_limit) {
     __shared__ double blk[64 * 65];
     __shared__ double r[64], xs[64], xb[64];
     __shared__ double part[4][64];
@@ -1016,8 +1017,8 @@ __global__ __launch_bounds__(256) void k_trsv_chain(const double* __restrict__ T
                 v = lane < cs ? __hip_atomic_load(sol + c * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
                 const bool pending = (unsigned long long)__double_as_longlong(v) == TRSV_PENDING;
                 if (!__any(pending)) break;
-                if (++spins > (1 << 25)) {     // (about a second: a workgroup that comes this late is not coming)
-                    if (lane == 0) __hip_atomic_store(flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > spin_limit) {    // (2^25 by default, about a second: a workgroup that comes this late is not coming)
+                    if (lane == 0) __hip_atomic_store(flag + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -2389,6 +2390,8 @@ struct og_qp_s {
     Lq16Panel* panel16 = nullptr;
     double* V16b = nullptr;            // ... of the panel the look-ahead factors during the trailing update
     Lq16Panel* panel16b = nullptr;
+    int spin_limit = 1 << 25;          // bound of the inter-workgroup waits (OGSQP_SPIN_LIMIT: tests force a loss with 1)
+    int recoveries = 0;                // subproblems re-run with the separate-launch forms after a wait gave up
     bool lq_ahead = true;              // OGSQP_LQ=16: panel and trailing update as separate launches
     int trsv_mode = 0;                 // OGSQP_TRSV: 0 one chained launch, 1 ("block") a launch per block, 2 ("single")
     unsigned* lq_go = nullptr;         // look-ahead: head workgroups that have finished the next panel's rows, ever
@@ -2486,7 +2489,7 @@ int launch_trsv(og_qp_s* qp, int ldw, int meq, int transposed, double scale_rhs,
         hipLaunchKernelGGL(k_trsv_prepare, dim3(1), dim3(256), 0, s, rhs, meq, scale_rhs, qp->trsv_work, qp->dthresh + 2, x);
         hipLaunchKernelGGL(k_trsv_chain, dim3(nblk), dim3(256), 0, s, qp->Tc, ldw, qp->diagL, meq, transposed,
                            (const double*)qp->trsv_work, x, qp->dthresh + 2, qp->dthresh, qp->flag, (const double*)qp->Linv,
-                           (const int*)qp->has_gone);
+                           (const int*)qp->has_gone, qp->spin_limit);
         return 0;
     }
     hipLaunchKernelGGL(k_trsv_prepare, dim3(1), dim3(256), 0, s, rhs, meq, scale_rhs, qp->trsv_work, qp->dthresh + 2,
@@ -2601,6 +2604,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         qp->lq_ahead = !(lq && std::string(lq) == "16");
         const char* tr = getenv("OGSQP_TRSV");
         qp->trsv_mode = (tr && std::string(tr) == "block") ? 1 : (tr && std::string(tr) == "single") ? 2 : 0;
+        const char* spin = getenv("OGSQP_SPIN_LIMIT");
+        if (spin && atoi(spin) > 0) qp->spin_limit = atoi(spin);
         const char* warm = getenv("OGSQP_WARM");
         qp->warm_enabled = !(warm && std::string(warm) == "0");
     }
@@ -2643,9 +2648,11 @@ int og_qp_set_factor(og_qp_handle qp, const double* Z) {
     return 0;
 }
 
-int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const double* g, const double* c,
-                    const double* dl, const double* du, int32_t augmented, double rho, double* d, double* mult,
-                    double* bound_mult, int32_t* status, int32_t* iterations, void* hip_stream) {
+// One attempt at the subproblem.  *lost = 1 (and nothing of the handle's state changed: the factor, the warm-start
+// list) when an inter-workgroup wait of the look-ahead sweep or of the chained triangular solves gave up.
+static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, const double* g, const double* c,
+                            const double* dl, const double* du, int32_t augmented, double rho, double* d, double* mult,
+                            double* bound_mult, int32_t* status, int32_t* iterations, void* hip_stream, int* lost) {
     if (!qp || !d_jt || !g || !dl || !du || !d || !mult || !bound_mult || !status)
         return fail(2, "og_qp_solve_dev: null argument");
     if (qp->m > 0 && !c) return fail(2, "og_qp_solve_dev: null constraint values");
@@ -2792,7 +2799,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     hipLaunchKernelGGL((k_lq_step16<U, E>), dim3(1 + LQ_HEADS + (std::max(nrows16 - LQ16, 0) + rpg - 1) / rpg),        \
                        dim3(64 * A16_WAVES), (size_t)2 * 256 * E * sizeof(double), s, qp->Tc, qp->Jw, ldw, msweep, nq, k,   \
                        (const double*)Vcur, ldw, (const Lq16Panel*)pcur, Vnxt, pnxt, qp->diagL, qp->dthresh + 1, rpg,      \
-                       qp->lq_go, (qp->lq_token += LQ_HEADS), qp->lq_wpart, qp->flag + 2)
+                       qp->lq_go, (qp->lq_token += LQ_HEADS), qp->lq_wpart, qp->flag + 2, qp->spin_limit)
                     // U by the length of the rows now, E by the length of the NEXT panel's rows (exact)
                     const int en = (len16 - LQ16 + 255) / 256;
                     if (ub <= 2) { if (en <= 1) OG_STEP16(2, 1); else OG_STEP16(2, 2); }
@@ -2875,8 +2882,10 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     int hflag[4] = {0, 0, 0, 0};
     OG_HIP(hipMemcpyAsync(hflag, qp->flag, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     OG_HIP(hipStreamSynchronize(s));
-    if (hflag[2])
-        return fail(7, "og_qp_solve_dev: a look-ahead workgroup of the LQ sweep never saw the others finish (internal error)");
+    if (hflag[2] || hflag[3]) {          // a look-ahead workgroup of the sweep / a block of the chained solve gave up waiting
+        *lost = 1;
+        return 0;
+    }
     if (hflag[0]) {                       // a dependent equality row that contradicts the others
         *status = OG_QP_SINGULAR_C;
         return 0;
@@ -3127,7 +3136,13 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     OG_HIP(hipMemcpyAsync(bound_mult, qp->bm, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
     if (meq) OG_HIP(hipMemcpyAsync(mult, qp->lam, sizeof(double) * meq, hipMemcpyDeviceToHost, s));
     if (mg) OG_HIP(hipMemcpyAsync(mult + meq, qp->u, sizeof(double) * mg, hipMemcpyDeviceToHost, s));
+    // (the transposed chained solve for the multipliers ran after the first look at the flags)
+    OG_HIP(hipMemcpyAsync(hflag, qp->flag, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     OG_HIP(hipStreamSynchronize(s));
+    if (hflag[2] || hflag[3]) {
+        *lost = 1;
+        return 0;
+    }
     if (rows_mode && nr > 0) {
         // the rows active at this solution, in the numbering of og_qp_get_active: where the next subproblem starts
         std::vector<int> act((size_t)std::max(hst.q, 1));
@@ -3154,6 +3169,38 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     }
     if (!augmented) std::swap(qp->Z, qp->Jw);   // Z Q: same B, what og_qp_bfgs updates next
     *status = OG_QP_SOLVED;
+    return 0;
+}
+
+int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const double* g, const double* c,
+                    const double* dl, const double* du, int32_t augmented, double rho, double* d, double* mult,
+                    double* bound_mult, int32_t* status, int32_t* iterations, void* hip_stream) {
+    int lost = 0;
+    int rc = qp_solve_attempt(qp, d_jt, ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status, iterations,
+                              hip_stream, &lost);
+    if (rc || !lost) return rc;
+    // The look-ahead sweep and the chained triangular solves hand data between workgroups of ONE launch and assume the
+    // workgroups they wait for are resident; on a device shared with other streams, ranks or tenants that may not hold,
+    // and a bounded wait gives up.  Nothing was committed: the subproblem is solved again with the forms that wait for
+    // nothing (panel and update as separate launches, a launch per block of the triangular solves) - SciPy's core has
+    // no such failure mode, so neither does this one.
+    const bool ahead = qp->lq_ahead;
+    const int trsv = qp->trsv_mode;
+    qp->lq_ahead = false;
+    if (qp->trsv_mode == 0) qp->trsv_mode = 1;
+    ++qp->recoveries;
+    lost = 0;
+    rc = qp_solve_attempt(qp, d_jt, ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status, iterations, hip_stream,
+                          &lost);
+    qp->lq_ahead = ahead;
+    qp->trsv_mode = trsv;
+    if (!rc && lost) return fail(7, "og_qp_solve_dev: a wait gave up in the forms that have none (internal error)");
+    return rc;
+}
+
+int og_qp_recoveries(og_qp_handle qp, int32_t* count) {
+    if (!qp || !count) return fail(2, "og_qp_recoveries: null argument");
+    *count = qp->recoveries;
     return 0;
 }
 

@@ -296,14 +296,15 @@ struct Lq16Head {
     unsigned* cnt;
     unsigned expect;
     int h;
-    int* lost;               // set when the wait below gives up (the host then fails the solve)
+    int* lost;               // set when the wait below gives up (the host then re-runs the subproblem with the
+    int spin_limit;          // separate-launch forms, which wait for nothing)
 };
 // wait (one thread) until *word has reached `expect`; bounded - a workgroup that never comes would otherwise hang the
 // device - and a wait that gives up says so
-__device__ __forceinline__ void lq_wait_for(unsigned* word, unsigned expect, int* lost) {
+__device__ __forceinline__ void lq_wait_for(unsigned* word, unsigned expect, int* lost, int spin_limit) {
     int spins = 0;
     while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
-        if (++spins > (1 << 25)) {     // (about a second: a workgroup that comes this late is not coming)
+        if (++spins > spin_limit) {    // (2^25 by default, about a second: a workgroup that comes this late is not coming)
             __hip_atomic_store(lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
@@ -407,7 +408,7 @@ __device__ __forceinline__ void lq_apply16_body(double* __restrict__ Tc, double*
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_fetch_add(head.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lq_wait_for(head.cnt, head.expect, head.lost);
+            lq_wait_for(head.cnt, head.expect, head.lost, head.spin_limit);
         }
         __syncthreads();
 #pragma unroll
@@ -503,7 +504,8 @@ __global__ __launch_bounds__(64 * A16_WAVES) void k_lq_step16(double* __restrict
                                                              double* __restrict__ Vnext, Lq16Panel* __restrict__ pnext,
                                                              double* __restrict__ diagL, double* __restrict__ dmaxbuf, int rpg,
                                                              unsigned* __restrict__ sync, unsigned expect,
-                                                             double* __restrict__ wpart, int* __restrict__ lost) {
+                                                             double* __restrict__ wpart, int* __restrict__ lost,
+                                                             int spin_limit) {
     extern __shared__ double lds[];
     __shared__ A16Shared sh;
     static_assert(64 * A16_WAVES == P16_THREADS, "one workgroup shape for both roles");
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(64 * A16_WAVES) void k_lq_step16(double* __restrict
     // (the heads come first in the grid: they are dispatched before everything else and start together)
     const int b = (int)blockIdx.x == LQ_HEADS ? 0 : (int)blockIdx.x < LQ_HEADS ? (int)blockIdx.x + 1 : (int)blockIdx.x;
     if (b == 0) {
-        if (threadIdx.x == 0) lq_wait_for(sync + 1, expect, lost);
+        if (threadIdx.x == 0) lq_wait_for(sync + 1, expect, lost, spin_limit);
         __syncthreads();
         lq_panel16_body<E, true>(Tc, ld, mrows, nq, k + LQ16, Vnext, ldv, diagL, pnext, dmaxbuf, lds);
     } else if (b <= LQ_HEADS) {
@@ -521,6 +523,7 @@ __global__ __launch_bounds__(64 * A16_WAVES) void k_lq_step16(double* __restrict
         head.expect = expect;
         head.h = b - 1;
         head.lost = lost;
+        head.spin_limit = spin_limit;
         lq_apply16_body<UH, true>(Tc, Jw, ld, mrows, nq, k, V, ldv, panel, 0, LQ16, sh, b - 1, LQ_HEADS, head);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wavefront: its stores have been acknowledged
         __syncthreads();

@@ -1,11 +1,14 @@
 """C5 - synthetic four-phase knotted launch: 4 phases, 8 states,
 4 controls, 128 LGL nodes per phase, n = 6148 decision variables.  Not a shipped example; it
-exists to put the sweep in the bandwidth-bound regime and to exercise the built-in knot rows
-(``knot_states_smooth = [True, True, True]`` -> 24 continuity rows, quirk Q9).
+exists to put the sweep in the bandwidth-bound regime, to exercise both kinds of knot - the
+built-in continuity rows (``knot_states_smooth`` True, quirk Q9) inside a stage and user-written
+rows with a mass jump at the staging knot, the pattern of reference
+``examples/09_Rocket_Ascent_Polar_TSTO.py:76-132`` - and, since round 4, to be an NLP that SLSQP
+actually solves.
 
-Vehicle: polar ascent with an out-of-plane velocity component and two integrator states.
-States (R, theta, Vr, Vt, Vn, m, Q, Hq); controls (Tr, Tt, Tn, kappa) where kappa in [0, 1]
-scales the drag area (1 + kappa).  Per phase i (its own Cd, A, Isp):
+Vehicle: a two-stage polar ascent, two phases per stage, with an out-of-plane velocity component
+and two integrator states.  States (R, theta, Vr, Vt, Vn, m, Q, Hq); controls (Tr, Tt, Tn, kappa)
+where kappa in [0, 1] scales the drag area (1 + kappa).  Per phase i (its own Cd, A, Isp, Tmax):
 
     rho = 1.225 exp(-h/8500), h = max(R - Re, -100)       V2 = Vr^2 + Vt^2 + Vn^2
     k = 0.5 rho sqrt(V2) Cd_i A_i (1 + kappa)             g = g0 (Re/R)^2
@@ -15,6 +18,21 @@ scales the drag area (1 + kappa).  Per phase i (its own Cd, A, Isp):
     Vndot = Tn/m - k Vn/m - Vr Vn/R
     mdot = -sqrt(Tr^2 + Tt^2 + Tn^2) / g0 / Isp_i
     Qdot = 0.5 rho V2                                     Hqdot = c_q sqrt(rho) V2 sqrt(V2)
+
+Knots: phase 0 -> 1 and 2 -> 3 are smooth (all eight states continuous, built-in rows; the knot
+times are pinned to fixed fractions of the stage's burn - a free knot inside a continuous arc would
+be a direction the NLP does not see); phase 1 -> 2 is the staging: seven states continuous by
+user rows, the mass restarts at the second stage's ignition mass.  Path constraints: thrust
+magnitude, acceleration (MaxG), dynamic pressure (MaxQ), R >= Re, burn durations of both stages
+bounded above.  Cost: the control effort sum w (Tr^2 + Tt^2 + Tn^2) / unit_T^2 as a running cost
+(raw LGL weights, quirk Q10) - a smooth, strictly convex function of the controls.
+
+Round 1-3's form of this problem (one continuous vehicle of 60 t with Isp 280-350 s to a 400 km
+orbit, all knots smooth and free, final mass as the cost) was not a well-posed NLP: its ideal
+delta-v is short of orbit unless the mass runs to its lower bound, the three free knot times of a
+continuous arc are flat directions, and the cost's only gradient entry sits on one variable - SLSQP
+left the guess with steps that overflowed after a handful of iterations (NaN cost from the 5th-8th
+iteration on, in SciPy-faithful restatement and HIP core alike, VERDICT r3 missing #1).
 """
 import numpy as np
 
@@ -25,20 +43,22 @@ class Stack:
     g0 = 9.80665
 
     def __init__(self):
-        self.M0 = 60000.0
-        self.Mfinal = 4000.0
+        # per phase: stage 1 flies phases 0-1, stage 2 phases 2-3
+        self.M0 = [60000.0, 60000.0, 9000.0, 9000.0]          # mass at the stage's ignition
+        self.Mmin = [10000.0, 10000.0, 1000.0, 1000.0]        # burn-out mass of the stack in that phase
+        self.Isp = [290.0, 310.0, 345.0, 345.0]
+        self.Tmax = [60000.0 * self.g0 * 1.5, 60000.0 * self.g0 * 1.5, 9000.0 * self.g0, 9000.0 * self.g0]
         self.Cd = [0.25, 0.22, 0.2, 0.2]
         self.A = [7.0, 7.0, 3.14, 3.14]
-        self.Isp = [280.0, 300.0, 330.0, 350.0]
-        self.Tmax = [self.M0 * self.g0 * 1.4, self.M0 * self.g0 * 0.9,
-                     self.M0 * self.g0 * 0.35, self.M0 * self.g0 * 0.1]
         self.MaxG = 6.0
         self.MaxQ = 45000.0
         self.c_q = 1.7415e-4
-        self.Rtarget = self.Re + 400.0 * 1000
+        self.Rtarget = self.Re + 300.0 * 1000
         self.Vtarget = np.sqrt(self.GMe / self.Rtarget)
         self.unit_Q = 1.0e7
         self.unit_H = 1.0e9
+        self.burn_max = [500.0, 660.0]                          # longest burn of stage 1 / stage 2, seconds
+        self.knot_fraction = [0.4, 270.0 / 660.0]               # where a stage's inner knot sits in its burn
 
     def air_density(self, h):
         h[h < -100.0] = -100.0
@@ -46,6 +66,7 @@ class Stack:
 
 
 N_PHASE = 4
+CONTINUOUS_AT_STAGING = (0, 1, 2, 3, 4, 6, 7)                   # every state but the mass
 
 
 def make_callbacks(api):
@@ -77,18 +98,28 @@ def make_callbacks(api):
 
     def equality(prob, obj):
         u = prob.unit_states[0]
-        first = [(0, obj.Re), (1, 0.0), (2, 0.0), (3, 0.0), (4, 0.0), (5, obj.M0), (6, 0.0), (7, 0.0)]
+        first = [(0, obj.Re), (1, 0.0), (2, 0.0), (3, 0.0), (4, 0.0), (5, obj.M0[0]), (6, 0.0), (7, 0.0)]
         last = [(0, obj.Rtarget), (2, 0.0), (3, obj.Vtarget), (4, 0.0)]
         rows = Condition()
         for state, value in first:
             rows.equal(prob.states(state, 0)[0], value, unit=u[state])
         for state, value in last:
             rows.equal(prob.states(state, N_PHASE - 1)[-1], value, unit=u[state])
+        # the inner knot of each stage at a fixed fraction of the stage's burn
+        t1, t2, t3, t4 = (prob.time_final(i) for i in range(N_PHASE))
+        rows.equal(t1, obj.knot_fraction[0] * t2, unit=prob.unit_time)
+        rows.equal(t3 - t2, obj.knot_fraction[1] * (t4 - t2), unit=prob.unit_time)
+        # staging (knot 1 -> 2): everything but the mass is continuous, the second stage ignites at its own mass
+        for state in CONTINUOUS_AT_STAGING:
+            rows.equal(prob.states(state, 2)[0], prob.states(state, 1)[-1], unit=u[state])
+        rows.equal(prob.states(5, 2)[0], obj.M0[2], unit=u[5])
         return rows()
 
     def inequality(prob, obj):
         rows = Condition()
         rows.lower_bound(prob.states_all_section(0), obj.Re, unit=prob.unit_states[0][0])
+        rows.upper_bound(prob.time_final(1), obj.burn_max[0], unit=prob.unit_time)
+        rows.upper_bound(prob.time_final(3) - prob.time_final(1), obj.burn_max[1], unit=prob.unit_time)
         for i in range(N_PHASE):
             Tr, Tt, Tn = (prob.controls(c, i) for c in range(3))
             rows.upper_bound(np.sqrt(Tr ** 2 + Tt ** 2 + Tn ** 2), obj.Tmax[i],
@@ -107,21 +138,28 @@ def make_callbacks(api):
         return rows()
 
     def cost(prob, obj):
-        return -prob.states(5, N_PHASE - 1)[-1] / prob.unit_states[N_PHASE - 1][5]
+        return 0.0
 
-    return dynamics, equality, inequality, cost
+    def running_cost(prob, obj):
+        u = prob.unit_controls[0][0]
+        Tr, Tt, Tn = (prob.controls_all_section(c) for c in range(3))
+        return (Tr ** 2 + Tt ** 2 + Tn ** 2) / u ** 2
+
+    return dynamics, equality, inequality, cost, running_cost
 
 
 def build(api, nodes=None, max_iteration=5):
     nodes = list(nodes or [128] * N_PHASE)
     assert len(nodes) == N_PHASE
-    prob = api.Problem([0.0, 60.0, 150.0, 300.0, 520.0], nodes, [8] * N_PHASE, [4] * N_PHASE,
-                       max_iteration)
     obj = Stack()
+    t_stage = obj.burn_max[0]
+    t_end = t_stage + obj.burn_max[1]
+    knots = [0.0, obj.knot_fraction[0] * t_stage, t_stage, t_stage + obj.knot_fraction[1] * obj.burn_max[1], t_end]
+    prob = api.Problem(knots, nodes, [8] * N_PHASE, [4] * N_PHASE, max_iteration)
     G = api.Guess
     unit_R = obj.Re
     unit_V = np.sqrt(obj.GMe / obj.Re)
-    unit_m = obj.M0
+    unit_m = obj.M0[0]
     unit_t = unit_R / unit_V
     unit_T = unit_m * unit_R / unit_t ** 2
     for state, unit in enumerate([unit_R, 1, unit_V, unit_V, unit_V, unit_m, obj.unit_Q, obj.unit_H]):
@@ -134,29 +172,31 @@ def build(api, nodes=None, max_iteration=5):
     t = prob.time_all_section
     prob.set_states_all_section(0, G.cubic(t, obj.Re, 0.0, obj.Rtarget, 0.0))
     prob.set_states_all_section(1, G.cubic(t, 0.0, 0.0, np.deg2rad(20.0), 0.0))
-    prob.set_states_all_section(2, G.cubic(t, 0.0, 900.0 * unit_t, 0.0, 0.0))
+    prob.set_states_all_section(2, G.linear(t, 0.0, 0.0))
     prob.set_states_all_section(3, G.linear(t, 0.0, obj.Vtarget))
-    prob.set_states_all_section(4, G.cubic(t, 0.0, 40.0 * unit_t, 0.0, 0.0))
-    prob.set_states_all_section(5, G.cubic(t, obj.M0, -0.6, obj.Mfinal, 0.0))
+    prob.set_states_all_section(4, G.linear(t, 0.0, 0.0))
+    mass = [(60000.0, 40000.0), (40000.0, 14000.0), (9000.0, 5000.0), (5000.0, 2000.0)]
+    prob.set_states_all_section(5, np.hstack([G.linear(prob.time[i], *mass[i]) for i in range(N_PHASE)]))
     prob.set_states_all_section(6, G.linear(t, 0.0, 0.3 * obj.unit_Q))
     prob.set_states_all_section(7, G.linear(t, 0.0, 0.2 * obj.unit_H))
-    for control, share in ((0, 0.8), (1, 0.55), (2, 0.05)):
+    for control, share in ((0, 0.6), (1, 0.6), (2, 0.0)):
         profile = np.hstack([G.cubic(prob.time[i], obj.Tmax[i] * share, 0.0, obj.Tmax[i] * share * 0.5,
                                      0.0) for i in range(N_PHASE)])
         prob.set_controls_all_section(control, profile)
     prob.set_controls_all_section(3, G.linear(t, 0.2, 0.1))
 
     prob.set_states_bounds_all_section(0, obj.Re, None)
-    prob.set_states_bounds_all_section(5, obj.Mfinal * 0.5, obj.M0)
-    for control in range(3):
-        for i in range(N_PHASE):
+    for i in range(N_PHASE):
+        prob.set_states_bounds(5, i, obj.Mmin[i], obj.M0[i])
+        for control in range(3):
             prob.set_controls_bounds(control, i, -obj.Tmax[i], obj.Tmax[i])
     prob.set_controls_bounds_all_section(3, 0.0, 1.0)
 
-    dynamics, equality, inequality, cost = make_callbacks(api)
+    dynamics, equality, inequality, cost, running_cost = make_callbacks(api)
     prob.dynamics = [dynamics] * N_PHASE
-    prob.knot_states_smooth = [True] * (N_PHASE - 1)
+    prob.knot_states_smooth = [True, False, True]
     prob.cost = cost
+    prob.running_cost = running_cost
     prob.equality = equality
     prob.inequality = inequality
     return prob, obj

@@ -129,6 +129,11 @@ class DeviceJacobian:
         return self._multi[3] if self._last == "multi" else self._own[4]
 
     @property
+    def d_JT(self):
+        """The one-device form's matrix as a torch tensor (n * ld entries, row i = FD column i)."""
+        return self._single()[3]
+
+    @property
     def sharded_over(self):
         """Number of devices the last sweep was split over."""
         return len(self.engine.devices) if self._last == "multi" else 1
@@ -188,7 +193,8 @@ def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivati
     x = np.clip(np.asarray(x0, dtype=float), lb, ub)
     # device buffers and the QP work space belong to the engine: the restarts of Problem.solve reuse them
     jacobian, core = _cache(engine)
-    timing = {"callbacks": 0.0, "qp": 0.0, "bfgs": 0.0, "qp_iterations": 0, "qp_solves": 0}
+    timing = {"callbacks": 0.0, "qp": 0.0, "bfgs": 0.0, "qp_iterations": 0, "qp_solves": 0, "recoveries": 0}
+    recoveries_before = core.recoveries()
     unit0 = np.zeros(m + 1)
     unit0[0] = 1.0
 
@@ -340,6 +346,7 @@ def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivati
         if core.bfgs(s, eta, fraction * Bd):
             reset = True
         timing["bfgs"] += time.perf_counter() - t
+    timing["recoveries"] = core.recoveries() - recoveries_before
     if getattr(engine, "_sqp_cache", None) is None:
         core.close()
     message = EXIT_MODES.get(int(status), "mode %d" % status)

@@ -349,6 +349,23 @@ def single_process_bench(a):
         "self_check": {"multi_device_matrix_equals_single_device_bitwise": equal},
     }
     assert equal, "the column-sharded matrix differs from the single-device one"
+    if a.sqp_iterations > 0 and n <= 3000:
+        # the SQP leg on the sharded sweep: the QP core reads device d0's replica in place (sqp.DeviceJacobian) - and
+        # walks the same iterates as on one device, bit for bit (the sharded matrix IS the single-device matrix)
+        from opengoddard_amd import sqp
+        runs = {}
+        for tag, eng_ in ((("sharded", multi), ("one_device", single)) if G > 1 else (("sharded", single),)):
+            t0 = time.perf_counter()
+            res = sqp.minimize_slsqp_hip(eng_, prob.p.copy(), lb, ub, ftol=1e-6, maxiter=a.sqp_iterations + 1)
+            runs[tag] = (res, time.perf_counter() - t0)
+        res, wall = runs["sharded"]
+        leg = _sqp_result(res, wall, res.timing, a.sqp_iterations)
+        leg["fd_columns_sharded_over"] = int(multi._sqp_cache[0].sharded_over)
+        if G > 1:
+            leg["one_device_ms_per_major_iteration"] = runs["one_device"][1] / max(1, a.sqp_iterations) * 1e3
+            leg["same_iterates_as_one_device"] = bool(np.array_equal(res.x, runs["one_device"][0].x))
+            assert leg["same_iterates_as_one_device"], "the SQP leg on the sharded sweep left the single-device path"
+        result["sqp"] = leg
     if G > 1:
         multi.close()
     single.close()

@@ -95,7 +95,7 @@ def build_sqp(force=False):
         return os.environ["OG_SQP_LIB"]
     os.makedirs(LIBDIR, exist_ok=True)
     sources = [os.path.join(CSRC, "ogsqp.hip"), os.path.join(CSRC, "ogsqp_rows.h"), os.path.join(CSRC, "ogsqp_lq16.h"),
-               os.path.join(HERE, "..", "include", "ogsqp.h")]
+               os.path.join(CSRC, "ogsqp_lqwide.h"), os.path.join(HERE, "..", "include", "ogsqp.h")]
     stamp_path = SQP_LIB + ".stamp"
     want = _digest_files(sources)
     if not force and os.path.exists(SQP_LIB) and os.path.exists(stamp_path):
@@ -103,7 +103,7 @@ def build_sqp(force=False):
             if fh.read().strip() == want:
                 return SQP_LIB
     tmp = SQP_LIB + ".tmp%d" % os.getpid()
-    _run([hipcc()] + HIP_FLAGS + [sources[0], "-o", tmp])
+    _run([hipcc()] + HIP_FLAGS + [sources[0], "-o", tmp, "-ldl"])
     os.replace(tmp, SQP_LIB)
     with open(stamp_path, "w") as fh:
         fh.write(want)

@@ -21,6 +21,7 @@
 //
 // Reductions run in a fixed order: results are bit-reproducible from run to run.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(256) void k_lq_apply_reg(double* __restrict__ Tc, d
 }
 
 #include "ogsqp_lq16.h"
+#include "ogsqp_lqwide.h"
 
 // max |diag| / min |diag| test of the triangular factor -> flag[0] = 1 when singular
 __global__ void k_check_diag(const double* diagL, int meq, int* flag, double* dthresh) {
@@ -2390,6 +2392,15 @@ struct og_qp_s {
     Lq16Panel* panel16 = nullptr;
     double* V16b = nullptr;            // ... of the panel the look-ahead factors during the trailing update
     Lq16Panel* panel16b = nullptr;
+    // rows longer than one workgroup's registers (n + 1 > 2048): column-split panels, 64-reflector blocks, GEMMs (ogsqp_lqwide.h)
+    bool lq_wide = false;              // (on from og_qp_create when n + 1 > LQW_SLAB and rocBLAS loads; OGSQP_LQ=8 / 16 turn it off)
+    double* Vall = nullptr;            // reflector vectors of the whole sweep, row k = reflector k (zero left of its panel)
+    Lq16Panel* panelw = nullptr;       // T of the panel being applied inside a block
+    LqWideMail* wide_mail = nullptr;
+    unsigned* wide_count = nullptr;    // monotone count of the panel workgroups' steps, ever
+    unsigned wide_token = 0u;
+    double *wy_w = nullptr, *wy_m = nullptr, *wy_small = nullptr;      // (rows x 64) coefficients, M, 2 x (64 x 16)
+    void* blas = nullptr;              // rocblas_handle
     int spin_limit = 1 << 25;          // bound of the inter-workgroup waits (OGSQP_SPIN_LIMIT: tests force a loss with 1)
     int recoveries = 0;                // subproblems re-run with the separate-launch forms after a wait gave up
     bool lq_ahead = true;              // OGSQP_LQ=16: panel and trailing update as separate launches
@@ -2461,6 +2472,96 @@ size_t rows_lds_bytes(int nr, int qcap) {          // k_rows_decide: the incomin
 }  // namespace
 
 namespace {
+// ---- rocBLAS for the plain GEMMs of the wide sweep (resolved at run time: the copy already in the process, e.g.
+// torch's, is reused; the prototypes are rocblas.h's)
+struct blas_api {
+    void* lib = nullptr;
+    int (*create)(void**) = nullptr;
+    int (*destroy)(void*) = nullptr;
+    int (*set_stream)(void*, hipStream_t) = nullptr;
+    int (*set_atomics)(void*, int) = nullptr;
+    int (*dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*,
+                 double*, int) = nullptr;
+} g_blas;
+constexpr int BLAS_N = 111, BLAS_T = 112;              // rocblas_operation_none / _transpose
+
+bool load_blas() {
+    if (g_blas.dgemm) return true;
+    const char* names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so.5", "/opt/rocm/lib/librocblas.so"};
+    for (const char* nm : names) {
+        void* lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) continue;
+        void* sym = dlsym(lib, "rocblas_dgemm");
+        if (!sym) continue;
+        g_blas.lib = lib;
+        g_blas.dgemm = (decltype(g_blas.dgemm))sym;
+        g_blas.create = (decltype(g_blas.create))dlsym(lib, "rocblas_create_handle");
+        g_blas.destroy = (decltype(g_blas.destroy))dlsym(lib, "rocblas_destroy_handle");
+        g_blas.set_stream = (decltype(g_blas.set_stream))dlsym(lib, "rocblas_set_stream");
+        g_blas.set_atomics = (decltype(g_blas.set_atomics))dlsym(lib, "rocblas_set_atomics_mode");
+        if (g_blas.create && g_blas.destroy && g_blas.set_stream) return true;
+        g_blas = blas_api();
+    }
+    return false;
+}
+
+// C (m x n, column-major, ldc) = alpha op(A) op(B) + beta C
+int blas_gemm(og_qp_s* qp, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
+              int ldb, double beta, double* C, int ldc) {
+    if (m <= 0 || n <= 0) return 0;
+    const int rc = g_blas.dgemm(qp->blas, ta, tb, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc);
+    if (rc != 0) return fail(8, "og_qp_solve_dev: rocblas_dgemm failed (status " + std::to_string(rc) + ")");
+    return 0;
+}
+
+// rows <- rows - ((rows V') M^-1) V for `rows` rows of length L starting at A (leading dimension ld), V: nb reflectors
+// (row-major, leading dimension ldv) over the same L columns, M from k_wy_make_m.  Row-major X (r x c, ld) is the
+// column-major c x r matrix with the same ld: all three products are plain GEMMs on those views.
+int wy_apply_block(og_qp_s* qp, double* A, int ld, int rows, int L, const double* V, int ldv, int nb, hipStream_t s) {
+    if (rows <= 0) return 0;
+    OG_TRY(blas_gemm(qp, BLAS_T, BLAS_N, nb, rows, L, 1.0, V, ldv, A, ld, 0.0, qp->wy_w, LQW_BLOCK));      // W' = V A'
+    hipLaunchKernelGGL(k_wy_solve, dim3((rows + 255) / 256), dim3(256), 0, s, qp->wy_w, rows, nb, (const double*)qp->wy_m);
+    return blas_gemm(qp, BLAS_N, BLAS_N, L, rows, nb, -1.0, V, ldv, qp->wy_w, LQW_BLOCK, 1.0, A, ld);          // A' -= V' W2'
+}
+
+// The sweep over rows longer than LQW_SLAB entries, from reflector k on, in blocks of LQW_BLOCK reflectors: returns the
+// first reflector it did not handle (rows short enough for the look-ahead kernels, or msweep).
+int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s, int* done) {
+    if (g_blas.set_stream(qp->blas, s) != 0) return fail(8, "og_qp_solve_dev: rocblas_set_stream failed");
+    while (k < msweep && nq - k > LQW_SLAB) {
+        const int k0 = k, nbk = std::min(LQW_BLOCK, msweep - k0), L0 = nq - k0;
+        for (int sub = 0; sub < nbk; sub += LQ16) {
+            const int kk = k0 + sub, nb16 = std::min(LQ16, msweep - kk), len = nq - kk;
+            const int nwg = (len + LQW_SLAB - 1) / LQW_SLAB;
+            double* V = qp->Vall + (size_t)kk * ldw + kk;
+            hipLaunchKernelGGL(k_lq_panel16_wide, dim3(nwg), dim3(P16_THREADS), (size_t)2 * LQW_SLAB * sizeof(double), s, qp->Tc,
+                               ldw, msweep, nq, kk, V, ldw, qp->diagL, qp->panelw, qp->dthresh + 1, qp->wide_mail,
+                               qp->wide_count, qp->wide_token, qp->flag + 2, qp->spin_limit);
+            qp->wide_token += (unsigned)(nwg * nb16);
+            // the later rows of this block: rows <- rows - ((rows V16') T16) V16, T16 from the panel kernel
+            const int rest = k0 + nbk - (kk + nb16);
+            if (rest > 0) {
+                double* A = qp->Tc + (size_t)(kk + nb16) * ldw + kk;
+                double* W1 = qp->wy_small;
+                double* W2 = qp->wy_small + LQ16 * LQW_BLOCK;
+                OG_TRY(blas_gemm(qp, BLAS_T, BLAS_N, LQ16, rest, len, 1.0, V, ldw, A, ldw, 0.0, W1, LQ16));
+                OG_TRY(blas_gemm(qp, BLAS_N, BLAS_N, LQ16, rest, LQ16, 1.0, &qp->panelw->T[0][0], LQ16, W1, LQ16, 0.0, W2, LQ16));
+                OG_TRY(blas_gemm(qp, BLAS_N, BLAS_N, len, rest, LQ16, -1.0, V, ldw, W2, LQ16, 1.0, A, ldw));
+            }
+        }
+        // the block reflector: M = T^-1 from the Gram matrix of its nbk reflector vectors (columns k0 .. nq)
+        const double* Vb = qp->Vall + (size_t)k0 * ldw + k0;
+        OG_TRY(blas_gemm(qp, BLAS_T, BLAS_N, nbk, nbk, L0, 1.0, Vb, ldw, Vb, ldw, 0.0, qp->wy_m, LQW_BLOCK));
+        hipLaunchKernelGGL(k_wy_make_m, dim3(1), dim3(256), 0, s, qp->wy_m, nbk);
+        // ... applied to what is left of C Z (and of the warm-start rows) and to Z
+        OG_TRY(wy_apply_block(qp, qp->Tc + (size_t)(k0 + nbk) * ldw + k0, ldw, msweep - k0 - nbk, L0, Vb, ldw, nbk, s));
+        OG_TRY(wy_apply_block(qp, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, s));
+        k = k0 + nbk;
+    }
+    *done = k;
+    return 0;
+}
+
 // out = (the `rows` columns of A from col0 on, or the ones sel names)' Jw: the map of non-empty slabs, then the product
 int launch_gemm(og_qp_s* qp, const AView& A, int col0, int rows, int nq, int ldw, double* out, const int* sel,
                 hipStream_t s) {
@@ -2604,6 +2705,26 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         qp->lq_ahead = !(lq && std::string(lq) == "16");
         const char* tr = getenv("OGSQP_TRSV");
         qp->trsv_mode = (tr && std::string(tr) == "block") ? 1 : (tr && std::string(tr) == "single") ? 2 : 0;
+        // rows longer than one workgroup holds: the wide sweep (ogsqp_lqwide.h) when the default kernels are selected and
+        // rocBLAS is there for its GEMMs (otherwise round 2's 8-reflector kernels serve those rows, as before)
+        const char* wide = getenv("OGSQP_WIDE");
+        if (qp->lq16 && qp->lq_ahead && n1 > (size_t)LQW_SLAB && n1 <= (size_t)LQW_SLAB * LQW_MAX &&
+            !(wide && std::string(wide) == "0") && load_blas()) {
+            const size_t vrows = ((size_t)qp->meq + qc + LQW_BLOCK - 1) / LQW_BLOCK * LQW_BLOCK + LQW_BLOCK;
+            A(&qp->Vall, vrows * ldw); A(&qp->panelw, 1); A(&qp->wide_mail, 1); A(&qp->wide_count, 4);
+            A(&qp->wy_w, (n1 + vrows) * LQW_BLOCK); A(&qp->wy_m, (size_t)LQW_BLOCK * LQW_BLOCK);
+            A(&qp->wy_small, (size_t)2 * LQ16 * LQW_BLOCK);
+            if (!rc && (hipMemset(qp->Vall, 0, vrows * ldw * sizeof(double)) != hipSuccess ||
+                        hipMemset(qp->wide_count, 0, 4 * sizeof(unsigned)) != hipSuccess))
+                rc = fail(5, "og_qp_create: hipMemset failed");
+            if (!rc && g_blas.create(&qp->blas) != 0) rc = fail(8, "og_qp_create: rocblas_create_handle failed");
+            if (!rc && g_blas.set_atomics) g_blas.set_atomics(qp->blas, 0);       // no atomics: results repeat bit for bit
+            if (rc) {
+                og_qp_destroy(qp);
+                return rc;
+            }
+            qp->lq_wide = true;
+        }
         const char* spin = getenv("OGSQP_SPIN_LIMIT");
         if (spin && atoi(spin) > 0) qp->spin_limit = atoi(spin);
         const char* warm = getenv("OGSQP_WARM");
@@ -2617,6 +2738,7 @@ void og_qp_destroy(og_qp_handle qp) {
     if (!qp) return;
     (void)hipSetDevice(qp->device);
     for (void* p : qp->owned) (void)hipFree(p);
+    if (qp->blas && g_blas.destroy) (void)g_blas.destroy(qp->blas);
     if (qp->jt_stage) (void)hipFree(qp->jt_stage);
     if (qp->stream) (void)hipStreamDestroy(qp->stream);
     delete qp;
@@ -2735,7 +2857,13 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
         int factored = -1;                                  // the panel the previous launch factored on the side
         OG_HIP(hipMemsetAsync(qp->lq_go, 0, 2 * sizeof(unsigned), s)); // counts of the head workgroups, this sweep
         qp->lq_token = 0u;
-        for (int k = 0; k < msweep;) {
+        int kstart = 0;
+        if (qp->lq_wide && nq > LQW_SLAB) {
+            // long rows: column-split panels and 64-reflector blocks until the rows fit one workgroup (ogsqp_lqwide.h)
+            OG_STAGE("lq sweep, wide blocks");
+            OG_TRY(lq_sweep_wide(qp, msweep, nq, ldw, 0, s, &kstart));
+        }
+        for (int k = kstart; k < msweep;) {
             if (qp->lq16 && nq - k <= 2048 && k % LQ16 == 0) {
                 // 16 reflectors per trip: row-distributed panel kernel, MFMA trailing update (ogsqp_lq16.h)
                 const int nb16 = std::min(LQ16, msweep - k), len16 = nq - k;
@@ -3184,15 +3312,17 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     // and a bounded wait gives up.  Nothing was committed: the subproblem is solved again with the forms that wait for
     // nothing (panel and update as separate launches, a launch per block of the triangular solves) - SciPy's core has
     // no such failure mode, so neither does this one.
-    const bool ahead = qp->lq_ahead;
+    const bool ahead = qp->lq_ahead, wide_on = qp->lq_wide;
     const int trsv = qp->trsv_mode;
     qp->lq_ahead = false;
+    qp->lq_wide = false;               // (its column-split panel waits too; round 2's kernels serve the long rows)
     if (qp->trsv_mode == 0) qp->trsv_mode = 1;
     ++qp->recoveries;
     lost = 0;
     rc = qp_solve_attempt(qp, d_jt, ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status, iterations, hip_stream,
                           &lost);
     qp->lq_ahead = ahead;
+    qp->lq_wide = wide_on;
     qp->trsv_mode = trsv;
     if (!rc && lost) return fail(7, "og_qp_solve_dev: a wait gave up in the forms that have none (internal error)");
     return rc;

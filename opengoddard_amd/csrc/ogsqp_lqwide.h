@@ -1,0 +1,287 @@
+// ogsqp_lqwide.h - the LQ sweep for rows LONGER than the 2048 entries one workgroup's registers hold (C5: n + 1 = 6149):
+// a 16-reflector panel kernel whose COLUMNS are split over several workgroups, and the block-reflector plumbing
+// (64 reflectors per block) that lets everything else of the sweep be plain library GEMMs.  Included by ogsqp.hip
+// inside its anonymous namespace, after ogsqp_lq16.h; DESIGN.md section 9.
+//
+// Until round 4 such rows went through round 2's 8-reflector kernels until the sweep had shortened them: one
+// workgroup holding all 8 rows of its columns (174 us per panel at C5) and a trailing update that streams the whole of
+// [C Z; Z] once per 8 reflectors (242 us) - 59 % of a C5 subproblem.  Here:
+//
+//   k_lq_panel16_wide   16 rows x L columns; workgroup w of ceil(L / 2048) holds the slab of columns
+//                       [2048 w, 2048 (w + 1)) of all 16 rows in registers exactly like k_lq_panel16 holds its rows.
+//                       A reflector step needs the products of every row with the current row over ALL columns: each
+//                       workgroup adds up its slab's share, the 16 partial sums (and, from workgroup 0, the rows'
+//                       entries in the pivot column) meet in a mailbox in HBM - agent-scope stores, a monotone counter,
+//                       a bounded spin: the workgroups are the whole grid of the launch and wait only for each
+//                       other - and every workgroup derives the same reflector scalars from the same totals and
+//                       updates its own slab.  16 exchanges per panel instead of 16 x 8 workgroup-wide reductions over
+//                       rows that do not fit.
+//   the rest            with V of a 64-row block (four panels) and M = T^-1 = diag(1 / beta) + striu(V V')
+//                       (k_wy_make_m), the update of every other row is  A <- A - ((A V') M^-1) V: two GEMMs
+//                       (rocBLAS, plain library GEMMs) around a per-row triangular solve with M (k_wy_solve) - for
+//                       the rows of the block's later panels (16 reflectors at a time, T of the panel kernel), for the
+//                       rest of C Z and for Z.  The matrix is streamed once per 64 reflectors instead of once per 8.
+//
+// A wait that gives up raises flag[2] like the look-ahead's: the subproblem is then solved again by the old kernels.
+
+constexpr int LQW_E = 8;                         // groups of 256 columns per workgroup: slabs of 2048 columns
+constexpr int LQW_SLAB = 256 * LQW_E;
+constexpr int LQW_MAX = 4;                       // workgroups per panel: rows of up to 8192 entries
+constexpr int LQW_BLOCK = 64;                    // reflectors per block reflector
+
+struct LqWideMail {
+    double v[LQ16][LQW_MAX][32];                 // per step and workgroup: 16 partial products | 16 pivot-column entries
+};
+
+__global__ __launch_bounds__(P16_THREADS) void k_lq_panel16_wide(double* __restrict__ Tc, int ld, int mrows, int nq, int k,
+                                                                double* __restrict__ V, int ldv, double* __restrict__ diagL,
+                                                                Lq16Panel* __restrict__ panel, double* __restrict__ dmaxbuf,
+                                                                LqWideMail* __restrict__ mail, unsigned* __restrict__ count,
+                                                                unsigned expect0, int* __restrict__ lost, int spin_limit) {
+    constexpr int E = LQW_E;
+    extern __shared__ double lds[];
+    __shared__ double s_part[2][P16_WAVES][LQ16];
+    __shared__ double s_xpc[2][LQ16];
+    __shared__ double s_tot[LQ16], s_pc[LQ16];       // totals over all workgroups; the rows' pivot-column entries
+    __shared__ double s_lower[LQ16][LQ16];
+    __shared__ double s_S[LQ16][LQ16];
+    __shared__ double s_T[LQ16][LQ16];
+    __shared__ double s_beta[LQ16], s_diag[LQ16];
+    double* vrow = lds;                              // 2 x LQW_SLAB
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int rp = lane >> 3, slot = wv * 8 + (lane & 7);
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    const int nb = min(LQ16, mrows - k);
+    const int c0 = wg * LQW_SLAB;                    // first column of my slab, from the panel's first column
+    const int L = min(LQW_SLAB, nq - k - c0);        // columns of my slab (> 0: the grid is ceil((nq - k) / 2048))
+    const bool first = wg == 0;
+    double x[2][E][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 2 * rp + h;
+        const double* row = Tc + (long)(k + min(r, nb - 1)) * ld + k + c0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int j = 4 * (64 * e + slot);
+            const double* src = row + min(j, 4 * ((L - 1) / 4));
+            const dbl4 v = *(const dbl4*)src;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[h][e][i] = (r < nb && j + i < L) ? v[i] : 0.0;
+        }
+    }
+    for (int e = tid; e < LQ16 * LQ16; e += P16_THREADS) {
+        (&s_S[0][0])[e] = 0.0;
+        (&s_T[0][0])[e] = 0.0;
+        (&s_lower[0][0])[e] = 0.0;
+    }
+    double dmax = dmaxbuf[0];
+#pragma unroll
+    for (int b = 0; b < LQ16; ++b) {
+        if (b < nb) {                                // (uniform)
+            double* vr = vrow + (b & 1) * LQW_SLAB;
+            if (rp == (b >> 1)) {
+                if (first) {
+                    // (only the first group of four columns of the first slab can lie left of the pivot: b < 16)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 4 * slot + i;
+                        const bool left = j < b;
+                        if (left) s_lower[b][j] = x[b & 1][0][i];
+                        x[b & 1][0][i] = left ? 0.0 : x[b & 1][0][i];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    dbl4 q;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[i] = x[b & 1][e][i];
+                    *(dbl4*)(vr + 4 * (64 * e + slot)) = q;
+                }
+            }
+            if (first && slot == (b >> 2)) {
+                s_xpc[b & 1][2 * rp] = x[0][0][b & 3];
+                s_xpc[b & 1][2 * rp + 1] = x[1][0][b & 3];
+            }
+            __syncthreads();
+            double v[E][4];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const dbl4 q = *(const dbl4*)(vr + 4 * (64 * e + slot));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[e][i] = q[i];
+            }
+            double pa[4] = {0.0, 0.0, 0.0, 0.0}, pb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pa[i] = fma(x[0][e][i], v[e][i], pa[i]);
+                    pb[i] = fma(x[1][e][i], v[e][i], pb[i]);
+                }
+            const double acc0 = oct_sum((pa[0] + pa[1]) + (pa[2] + pa[3]));
+            const double acc1 = oct_sum((pb[0] + pb[1]) + (pb[2] + pb[3]));
+            if ((lane & 7) == 0) {
+                s_part[b & 1][wv][2 * rp] = acc0;
+                s_part[b & 1][wv][2 * rp + 1] = acc1;
+            }
+            __syncthreads();
+            // ---- the exchange: wavefront 0 posts this workgroup's share and collects everybody's
+            if (wv == 0) {
+                double* mine = &mail->v[b][wg][0];
+                if (lane < LQ16) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int w8 = 0; w8 < P16_WAVES; ++w8) sum += s_part[b & 1][w8][lane];
+                    __hip_atomic_store(mine + lane, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (lane < 2 * LQ16 && first) {
+                    __hip_atomic_store(mine + lane, s_xpc[b & 1][lane - LQ16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the stores have been acknowledged
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    lq_wait_for(count, expect0 + (unsigned)(nwg * (b + 1)), lost, spin_limit);
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane < LQ16) {
+                    double sum = 0.0;
+                    for (int w = 0; w < nwg; ++w)
+                        sum += __hip_atomic_load(&mail->v[b][w][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_tot[lane] = sum;
+                } else if (lane < 2 * LQ16) {
+                    s_pc[lane - LQ16] = __hip_atomic_load(&mail->v[b][0][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            const double Db = s_tot[b], D0 = s_tot[2 * rp], D1 = s_tot[2 * rp + 1];
+            const double x0 = s_pc[b];
+            const double xr0 = s_pc[2 * rp], xr1 = s_pc[2 * rp + 1];
+            const double sigma = sqrt(Db);
+            const bool live = sigma > REDUNDANT * dmax && sigma > 0.0;
+            dmax = fmax(dmax, sigma);
+            const double alpha = !live ? 0.0 : (x0 >= 0.0 ? -sigma : sigma);
+            const double v0 = x0 - alpha;
+            const double vv = Db - x0 * x0 + v0 * v0;
+            const double bt = (live && vv > 0.0) ? 2.0 / vv : 0.0;
+            const double rv0 = D0 - xr0 * alpha, rv1 = D1 - xr1 * alpha;     // row . v_b
+            if (tid == 0) {
+                s_beta[b] = bt;
+                s_diag[b] = alpha;
+            }
+            if (wv == 0 && (lane & 7) == 0) {
+                if (2 * rp < b) s_S[2 * rp][b] = rv0;
+                if (2 * rp + 1 < b) s_S[2 * rp + 1][b] = rv1;
+            }
+            const double f0 = (2 * rp > b && 2 * rp < nb) ? bt * rv0 : 0.0;
+            const double f1 = (2 * rp + 1 > b && 2 * rp + 1 < nb) ? bt * rv1 : 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x[0][e][i] = fma(-f0, v[e][i], x[0][e][i]);
+                    x[1][e][i] = fma(-f1, v[e][i], x[1][e][i]);
+                }
+            if (first && slot == (b >> 2)) {
+                x[0][0][b & 3] = fma(f0, alpha, x[0][0][b & 3]);
+                x[1][0][b & 3] = fma(f1, alpha, x[1][0][b & 3]);
+                if (rp == (b >> 1)) x[b & 1][0][b & 3] = v0;     // row b becomes its reflector vector
+            }
+        }
+    }
+    __syncthreads();                                              // s_beta of the last step
+    if (first && tid < LQ16) {
+        const int a = tid;
+        double Tr[LQ16];
+#pragma unroll
+        for (int c = 0; c < LQ16; ++c) Tr[c] = (c == a && a < nb) ? s_beta[a] : 0.0;
+#pragma unroll
+        for (int b = 1; b < LQ16; ++b) {
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < b; ++c) {
+                if (c & 1) acc1 = fma(Tr[c], s_S[c][b], acc1);
+                else acc0 = fma(Tr[c], s_S[c][b], acc0);
+            }
+            if (b > a && b < nb) Tr[b] = -s_beta[b] * (acc0 + acc1);
+        }
+#pragma unroll
+        for (int c = 0; c < LQ16; ++c) s_T[a][c] = Tr[c];
+    }
+    // V: my slab of every row; a row whose pivot was dropped (beta = 0: no reflector) is stored as zeros, so that the
+    // block reflector's Gram matrix sees none
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 2 * rp + h;
+        const bool keep = r < nb && s_beta[min(r, LQ16 - 1)] != 0.0;
+        double* vout = V + (long)r * ldv + c0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int j = 4 * (64 * e + slot);
+            if (j + 3 < L) {
+                dbl4 q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = keep ? x[h][e][i] : 0.0;
+                *(dbl4*)(vout + j) = q;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j + i < L) vout[j + i] = keep ? x[h][e][i] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    if (first) {
+        for (int e = tid; e < LQ16 * LQ16; e += P16_THREADS) {
+            const int a = e / LQ16, b = e % LQ16;
+            panel->T[a][b] = s_T[a][b];
+            if (a < nb && b < a) Tc[(long)(k + a) * ld + k + b] = s_lower[a][b];
+            if (a < nb && b == 0) diagL[k + a] = s_diag[a];
+        }
+        if (tid == 0) {
+            panel->nb = nb;
+            panel->pad = 0;
+            dmaxbuf[0] = dmax;
+        }
+    }
+}
+
+// M = T^-1 of a block of nb reflectors from their Gram matrix S = V V' (nb x nb, leading dimension LQW_BLOCK; both
+// triangles hold the products): strictly upper triangle as it is, 1 / beta_i = |v_i|^2 / 2 on the diagonal; a row of
+// zeros (dropped pivot) gets 1 there - its coefficients are zero either way
+__global__ __launch_bounds__(256) void k_wy_make_m(double* __restrict__ S, int nb) {
+    for (int e = threadIdx.x; e < LQW_BLOCK * LQW_BLOCK; e += blockDim.x) {
+        const int i = e / LQW_BLOCK, j = e % LQW_BLOCK;
+        double v = S[(long)i * LQW_BLOCK + j];
+        if (i >= nb || j >= nb || j < i) v = 0.0;
+        if (i == j) v = (i < nb && v > 0.0) ? 0.5 * v : 1.0;
+        S[(long)i * LQW_BLOCK + j] = v;              // (every thread rewrites only what it read)
+    }
+}
+
+// W <- W M^-1 row by row: W holds `rows` rows of LQW_BLOCK coefficients (w = a V'), M upper triangular (row-major,
+// leading dimension LQW_BLOCK): w2_j = (w_j - sum_{i<j} w2_i M_ij) / M_jj.  A thread per row, M out of LDS.
+__global__ __launch_bounds__(256) void k_wy_solve(double* __restrict__ W, int rows, int nb, const double* __restrict__ M) {
+    __shared__ double s_m[LQW_BLOCK][LQW_BLOCK + 1];
+    for (int e = threadIdx.x; e < LQW_BLOCK * LQW_BLOCK; e += blockDim.x)
+        s_m[e / LQW_BLOCK][e % LQW_BLOCK] = M[e];
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double* w = W + (long)r * LQW_BLOCK;
+    double z[LQW_BLOCK];
+#pragma unroll
+    for (int j = 0; j < LQW_BLOCK; ++j) z[j] = j < nb ? w[j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < LQW_BLOCK; ++j) {
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < j; ++i) {
+            if (i & 1) acc1 = fma(z[i], s_m[i][j], acc1);
+            else acc0 = fma(z[i], s_m[i][j], acc0);
+        }
+        z[j] = (z[j] - (acc0 + acc1)) / s_m[j][j];
+    }
+#pragma unroll
+    for (int j = 0; j < LQW_BLOCK; ++j)
+        if (j < nb) w[j] = z[j];
+}

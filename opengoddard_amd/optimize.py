@@ -30,11 +30,15 @@ __all__ = ["Problem", "Guess", "Condition", "Dynamics"]
 ENGINE_FACTORY = None
 # 'scipy': SciPy's Fortran SLSQP driven by GPU callbacks (the reference's own core);
 # 'hip': the same major iteration with the QP subproblem on the GPU (sqp.py, include/ogsqp.h);
-# 'auto': 'hip' from AUTO_HIP_FROM decision variables on, 'scipy' below.  SciPy's core is O(n^3) per major
-# iteration (16 s at n = 1442 against a few ms for the HIP core); below a few hundred variables it costs
-# milliseconds and is the reference's own arithmetic, iterate for iterate.
+# 'auto': 'hip' from AUTO_HIP_FROM decision variables on, 'scipy' below, and 'scipy' whenever the HIP core cannot take
+# the problem (its capacity limits, no torch: Problem.sqp_core_fallback says why).  SciPy's core is O(n^3) per major
+# iteration (16 s at n = 1442 against a few ms for the HIP core).  Where the HIP core overtakes it was measured in
+# round 4 (tools/small_n_crossover.sh, profiles/r04_small_n.jsonl, same solves, MI355X box): n = 81 0.37 s vs 0.44 s
+# (a tie: both are Python start-up), n = 201 0.85 vs 4.40 s, n = 281 0.50 vs 4.79 s, n = 701 0.82 vs 29.5 s - the HIP
+# core from everything above the smallest shipped example, which keeps the reference's own arithmetic, iterate for
+# iterate.  (Round 3 drew the line at 400.)
 DEFAULT_SQP_CORE = "auto"
-AUTO_HIP_FROM = 400
+AUTO_HIP_FROM = 150
 
 
 def _default_engine(prob, obj, devices=None):
@@ -386,7 +390,7 @@ class Problem:
 
         Options honoured are the reference's: ``ftol`` (1e-6) and ``maxiter`` (25); two more select what
         the reference does not have: ``sqp_core`` ("auto", the default: the HIP SQP core - QP subproblems on the GPU,
-        sqp.py - from 400 decision variables on, SciPy's Fortran core below; "hip" / "scipy" force one) and
+        sqp.py - from 150 decision variables on, SciPy's Fortran core below; "hip" / "scipy" force one) and
         ``jacobian="exact"`` (forward-mode derivatives of the traced callbacks instead of SciPy's
         forward differences; same optimum, fewer iterations, no FD noise).  Cost,
         equality and inequality values come from a single-column launch of the sweep kernel;

@@ -42,6 +42,9 @@ def main():
                     help="exact: forward-mode derivatives instead of SciPy's forward differences")
     ap.add_argument("--sqp-core", default="scipy", choices=["scipy", "hip"],
                     help="hip: QP subproblems on the GPU (include/ogsqp.h); needs --engine hip")
+    ap.add_argument("--time-limit", type=float, default=None,
+                    help="seconds: no further SLSQP restart is started after this much wall time (the line then says "
+                         "converged false with what was reached; restarts are --maxiter iterations long)")
     ap.add_argument("--cold-start", action="store_true",
                     help="only measure what a NEW problem shape pays before its first sweep: trace + codegen + hipcc "
                          "(forced rebuild of the kernel module) + load, in a fresh process (bench.cold_start)")
@@ -77,8 +80,20 @@ def main():
     opts["jacobian"] = a.jacobian
     buf = io.StringIO()
     t0 = time.perf_counter()
+
+    class OutOfTime(Exception):
+        pass
+
+    def after_restart():
+        if a.time_limit is not None and time.perf_counter() - t0 > a.time_limit and prob.last_result.status != 0:
+            raise OutOfTime
+
+    stopped = False
     with contextlib.redirect_stdout(buf):
-        prob.solve(obj, **opts)
+        try:
+            prob.solve(obj, after_restart, **opts)
+        except OutOfTime:
+            stopped = True
     wall = time.perf_counter() - t0
     out = buf.getvalue()
     if a.sqp_core == "hip":
@@ -92,7 +107,8 @@ def main():
                           "t_driver_and_python_s": wall - cb - sum(t["qp"] + t["bfgs"] for t in tm),
                           "major_iterations": int(prob.last_result.nit), "exit_mode": int(prob.last_result.status),
                           "restarts": out.count("---- iteration"), "converged": "successfully" in out,
-                          "cost": float(prob.last_result.fun)}))
+                          "stopped_by_time_limit": stopped, "recoveries": sum(t.get("recoveries", 0) for t in tm),
+                          "sqp_core_used": getattr(prob, "sqp_core_used", None), "cost": float(prob.last_result.fun)}))
         return
     e = holder["e"]
     print(json.dumps({"workload": a.workload, "engine": a.engine, "n": int(prob.number_of_variables),

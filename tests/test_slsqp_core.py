@@ -672,6 +672,47 @@ def test_gpu_lq_sweep_forms_agree(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gpu_wide_sweep_agrees_with_the_old_kernels(monkeypatch):
+    """Rows longer than the 2048 entries one workgroup's registers hold (C5: 6149) take the wide sweep since round 4
+    (csrc/ogsqp_lqwide.h: a 16-reflector panel whose columns are split over 2-4 workgroups that exchange their partial
+    products through HBM, 64-reflector block reflectors applied by GEMMs); ``OGSQP_WIDE=0`` keeps round 2's
+    8-reflector kernels on those rows.  Same Householder sweep, sums in another order: same status, active set and
+    number of changes, the step to rounding - on random problems whose rows start at 2 and at 3 slabs (the sweep
+    hands over to the look-ahead kernels where the rows have become short enough; the second case ends inside the wide
+    part, with a partial last block and a partial last panel), with a redundant equality row in a wide panel, and twice
+    on one handle."""
+    rng = np.random.default_rng(31)
+    for n, meq, mg, redundant in ((2300, 700, 150, False), (4200, 1930, 120, True)):
+        Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+        if redundant:                                   # row 100 repeats a combination of rows 3 and 40: dropped, consistent
+            C[100] = 0.5 * C[3] - 2.0 * C[40]
+            c[100] = 0.5 * c[3] - 2.0 * c[40]
+        A, cc = np.vstack([C, G]), np.concatenate([c, h])
+        results = {}
+        for form in ("wide", "old"):
+            monkeypatch.delenv("OGSQP_WIDE", raising=False)
+            if form == "old":
+                monkeypatch.setenv("OGSQP_WIDE", "0")
+            core = _sqp_native.QpCore(n, meq, mg)
+            core.set_factor(Z)
+            d, mult, bm, status, iters = core.solve(A, g, cc, lb, ub)
+            results[form] = (d, mult, status, iters, sorted(core.get_active().tolist()))
+            core.set_factor(Z)
+            core.set_active()
+            d2, _, _, status2, iters2 = core.solve(A, g, cc, lb, ub)
+            assert status2 == status and iters2 == iters and np.array_equal(d2, d)      # bit-reproducible
+            assert core.recoveries() == 0
+            core.close()
+        d0, m0, s0, i0, a0 = results["old"]
+        d1, m1, s1, i1, a1 = results["wide"]
+        assert s0 == s1 == 1 and (i0, a0) == (i1, a1), (n, i0, i1)
+        assert np.max(np.abs(d1 - d0)) <= 1e-10 * max(1.0, np.abs(d0).max())
+        assert np.max(np.abs(m1 - m0)) <= 1e-8 * max(1.0, np.abs(m0).max())
+        # feasibility and stationarity do not care which kernels ran
+        assert np.max(np.abs(C @ d1 + c)) <= 1e-9 * max(1.0, np.abs(c).max())
+
+
+@pytest.mark.gpu
 def test_device_resident_jacobian_equals_host_staged():
     """og_qp_solve_dev on the Jacobian the sweep kernel left in HBM == og_qp_solve on its host copy;
     og_jt_times gives the cost gradient and the gradient of the Lagrangian."""

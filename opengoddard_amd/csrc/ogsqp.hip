@@ -2399,7 +2399,9 @@ struct og_qp_s {
     LqWideMail* wide_mail = nullptr;
     unsigned* wide_count = nullptr;    // monotone count of the panel workgroups' steps, ever
     unsigned wide_token = 0u;
-    double *wy_w = nullptr, *wy_m = nullptr, *wy_small = nullptr;      // (rows x 64) coefficients, M, 2 x (64 x 16)
+    double* wy_part = nullptr;         // column slices of a product (k_wy_w with blockIdx.y > 0), summed by k_wy_sum
+    size_t wy_part_cap = 0;
+    double *wy_w = nullptr, *wy_m = nullptr, *wy_t = nullptr, *wy_small = nullptr;   // 2 x (rows x 64) coefficients, M, T = M^-1, 2 x (64 x 16)
     void* blas = nullptr;              // rocblas_handle
     int spin_limit = 1 << 25;          // bound of the inter-workgroup waits (OGSQP_SPIN_LIMIT: tests force a loss with 1)
     int recoveries = 0;                // subproblems re-run with the separate-launch forms after a wait gave up
@@ -2514,14 +2516,39 @@ int blas_gemm(og_qp_s* qp, int ta, int tb, int m, int n, int k, double alpha, co
     return 0;
 }
 
+// W (rows x 64) = A V' by k_wy_w; few rows are split over the chip by columns (partials in wy_part, summed in order)
+void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const double* V, int ldv, int nb, double* W,
+                 int* nsplit_out, hipStream_t s) {
+    const int tiles = (rows + 16 * WYW_WAVES - 1) / (16 * WYW_WAVES), nblk = (L + 15) / 16;
+    // enough workgroups for every SIMD of the chip (a workgroup is two wavefronts that issue 16 MFMAs per 2 KB of A)
+    int nsplit = std::max(1, std::min(std::min(WYW_SPLIT_MAX, 1024 / tiles), nblk / 4));
+    nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, qp->wy_part_cap / ((size_t)rows * LQW_BLOCK)));
+    const int kb_per = (nblk + nsplit - 1) / nsplit;
+    nsplit = (nblk + kb_per - 1) / kb_per;
+    double* dst = nsplit > 1 ? qp->wy_part : W;
+    hipLaunchKernelGGL(k_wy_w, dim3(tiles, nsplit), dim3(64 * WYW_WAVES), 0, s, A, ld, rows, L, V, ldv, nb, dst, kb_per);
+    if (nsplit_out) {
+        *nsplit_out = nsplit;                         // the caller sums the slices itself (k_wy_small_finish)
+        return;
+    }
+    if (nsplit > 1) {
+        const long count = (long)rows * LQW_BLOCK;
+        hipLaunchKernelGGL(k_wy_sum, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const double*)qp->wy_part,
+                           nsplit, count, W);
+    }
+}
+
 // rows <- rows - ((rows V') M^-1) V for `rows` rows of length L starting at A (leading dimension ld), V: nb reflectors
 // (row-major, leading dimension ldv) over the same L columns, M from k_wy_make_m.  Row-major X (r x c, ld) is the
 // column-major c x r matrix with the same ld: all three products are plain GEMMs on those views.
 int wy_apply_block(og_qp_s* qp, double* A, int ld, int rows, int L, const double* V, int ldv, int nb, hipStream_t s) {
     if (rows <= 0) return 0;
-    OG_TRY(blas_gemm(qp, BLAS_T, BLAS_N, nb, rows, L, 1.0, V, ldv, A, ld, 0.0, qp->wy_w, LQW_BLOCK));      // W' = V A'
-    hipLaunchKernelGGL(k_wy_solve, dim3((rows + 255) / 256), dim3(256), 0, s, qp->wy_w, rows, nb, (const double*)qp->wy_m);
-    return blas_gemm(qp, BLAS_N, BLAS_N, L, rows, nb, -1.0, V, ldv, qp->wy_w, LQW_BLOCK, 1.0, A, ld);          // A' -= V' W2'
+    double* W = qp->wy_w;                                         // rows x LQW_BLOCK (as column-major: LQW_BLOCK x rows)
+    double* W2 = qp->wy_w + (size_t)rows * LQW_BLOCK;
+    launch_wy_w(qp, A, ld, rows, L, V, ldv, nb, W, nullptr, s);                                                // W = A V'
+    // W2 = W T (T = M^-1, row-major, upper triangular): as column-major, W2' = T' W' with T' = the array read column-major
+    OG_TRY(blas_gemm(qp, BLAS_N, BLAS_N, nb, rows, nb, 1.0, qp->wy_t, LQW_BLOCK, W, LQW_BLOCK, 0.0, W2, LQW_BLOCK));
+    return blas_gemm(qp, BLAS_N, BLAS_N, L, rows, nb, -1.0, V, ldv, W2, LQW_BLOCK, 1.0, A, ld);               // A' -= V' W2'
 }
 
 // The sweep over rows longer than LQW_SLAB entries, from reflector k on, in blocks of LQW_BLOCK reflectors: returns the
@@ -2542,17 +2569,19 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
             const int rest = k0 + nbk - (kk + nb16);
             if (rest > 0) {
                 double* A = qp->Tc + (size_t)(kk + nb16) * ldw + kk;
-                double* W1 = qp->wy_small;
-                double* W2 = qp->wy_small + LQ16 * LQW_BLOCK;
-                OG_TRY(blas_gemm(qp, BLAS_T, BLAS_N, LQ16, rest, len, 1.0, V, ldw, A, ldw, 0.0, W1, LQ16));
-                OG_TRY(blas_gemm(qp, BLAS_N, BLAS_N, LQ16, rest, LQ16, 1.0, &qp->panelw->T[0][0], LQ16, W1, LQ16, 0.0, W2, LQ16));
+                double* W2 = qp->wy_small;                                  // rest x 16
+                int nsplit = 1;
+                launch_wy_w(qp, A, ldw, rest, len, V, ldw, LQ16, qp->wy_part, &nsplit, s);
+                hipLaunchKernelGGL(k_wy_small_finish, dim3(1), dim3(256), 0, s, (const double*)qp->wy_part, nsplit, rest,
+                                   (const Lq16Panel*)qp->panelw, W2);
                 OG_TRY(blas_gemm(qp, BLAS_N, BLAS_N, len, rest, LQ16, -1.0, V, ldw, W2, LQ16, 1.0, A, ldw));
             }
         }
         // the block reflector: M = T^-1 from the Gram matrix of its nbk reflector vectors (columns k0 .. nq)
         const double* Vb = qp->Vall + (size_t)k0 * ldw + k0;
-        OG_TRY(blas_gemm(qp, BLAS_T, BLAS_N, nbk, nbk, L0, 1.0, Vb, ldw, Vb, ldw, 0.0, qp->wy_m, LQW_BLOCK));
+        launch_wy_w(qp, Vb, ldw, nbk, L0, Vb, ldw, nbk, qp->wy_m, nullptr, s);                    // S = V V' (nbk x 64)
         hipLaunchKernelGGL(k_wy_make_m, dim3(1), dim3(256), 0, s, qp->wy_m, nbk);
+        hipLaunchKernelGGL(k_wy_invert, dim3(1), dim3(LQW_BLOCK), 0, s, (const double*)qp->wy_m, nbk, qp->wy_t);
         // ... applied to what is left of C Z (and of the warm-start rows) and to Z
         OG_TRY(wy_apply_block(qp, qp->Tc + (size_t)(k0 + nbk) * ldw + k0, ldw, msweep - k0 - nbk, L0, Vb, ldw, nbk, s));
         OG_TRY(wy_apply_block(qp, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, s));
@@ -2712,7 +2741,10 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
             !(wide && std::string(wide) == "0") && load_blas()) {
             const size_t vrows = ((size_t)qp->meq + qc + LQW_BLOCK - 1) / LQW_BLOCK * LQW_BLOCK + LQW_BLOCK;
             A(&qp->Vall, vrows * ldw); A(&qp->panelw, 1); A(&qp->wide_mail, 1); A(&qp->wide_count, 4);
-            A(&qp->wy_w, (n1 + vrows) * LQW_BLOCK); A(&qp->wy_m, (size_t)LQW_BLOCK * LQW_BLOCK);
+            A(&qp->wy_w, 2 * (n1 + vrows) * LQW_BLOCK); A(&qp->wy_m, (size_t)LQW_BLOCK * LQW_BLOCK);
+            A(&qp->wy_t, (size_t)LQW_BLOCK * LQW_BLOCK);
+            qp->wy_part_cap = std::max((size_t)WYW_SPLIT_MAX * 2 * LQW_BLOCK * LQW_BLOCK, 4 * (n1 + vrows) * LQW_BLOCK);
+            A(&qp->wy_part, qp->wy_part_cap);
             A(&qp->wy_small, (size_t)2 * LQ16 * LQW_BLOCK);
             if (!rc && (hipMemset(qp->Vall, 0, vrows * ldw * sizeof(double)) != hipSuccess ||
                         hipMemset(qp->wide_count, 0, 4 * sizeof(unsigned)) != hipSuccess))

@@ -258,30 +258,138 @@ __global__ __launch_bounds__(256) void k_wy_make_m(double* __restrict__ S, int n
     }
 }
 
-// W <- W M^-1 row by row: W holds `rows` rows of LQW_BLOCK coefficients (w = a V'), M upper triangular (row-major,
-// leading dimension LQW_BLOCK): w2_j = (w_j - sum_{i<j} w2_i M_ij) / M_jj.  A thread per row, M out of LDS.
-__global__ __launch_bounds__(256) void k_wy_solve(double* __restrict__ W, int rows, int nb, const double* __restrict__ M) {
+// T = M^-1 (upper triangular, nb x nb inside a LQW_BLOCK x LQW_BLOCK array, row-major) - the block reflector's T factor:
+// thread j solves M t_j = e_j by back substitution (column j of the inverse of an upper triangle has nothing below
+// row j); entries outside the nb x nb corner are zero.  One workgroup of LQW_BLOCK threads, M out of LDS.
+__global__ __launch_bounds__(LQW_BLOCK) void k_wy_invert(const double* __restrict__ M, int nb, double* __restrict__ T) {
     __shared__ double s_m[LQW_BLOCK][LQW_BLOCK + 1];
-    for (int e = threadIdx.x; e < LQW_BLOCK * LQW_BLOCK; e += blockDim.x)
-        s_m[e / LQW_BLOCK][e % LQW_BLOCK] = M[e];
+    const int j = threadIdx.x;
+    for (int e = j; e < LQW_BLOCK * LQW_BLOCK; e += LQW_BLOCK) s_m[e / LQW_BLOCK][e % LQW_BLOCK] = M[e];
     __syncthreads();
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    double* w = W + (long)r * LQW_BLOCK;
-    double z[LQW_BLOCK];
-#pragma unroll
-    for (int j = 0; j < LQW_BLOCK; ++j) z[j] = j < nb ? w[j] : 0.0;
-#pragma unroll
-    for (int j = 0; j < LQW_BLOCK; ++j) {
-        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int i = 0; i < j; ++i) {
-            if (i & 1) acc1 = fma(z[i], s_m[i][j], acc1);
-            else acc0 = fma(z[i], s_m[i][j], acc0);
+    __shared__ double s_t[LQW_BLOCK][LQW_BLOCK + 1];      // s_t[i][j] = T_ij: thread j owns column j
+    for (int i = 0; i < LQW_BLOCK; ++i) s_t[i][j] = 0.0;
+    if (j < nb) {
+        for (int i = j; i >= 0; --i) {
+            double acc = (i == j) ? 1.0 : 0.0;
+            for (int c = i + 1; c <= j; ++c) acc -= s_m[i][c] * s_t[c][j];
+            s_t[i][j] = acc / s_m[i][i];
         }
-        z[j] = (z[j] - (acc0 + acc1)) / s_m[j][j];
     }
+    for (int i = 0; i < LQW_BLOCK; ++i) T[(long)i * LQW_BLOCK + j] = s_t[i][j];
+}
+
+// W (rows x LQW_BLOCK, row-major) = A V' for `rows` rows of length L at A (leading dimension ld) and the nb <= 64
+// reflector vectors V (row-major, leading dimension ldv) over the same columns - the tall-skinny product of the block
+// reflector's application, hand-written because the library runs it at 0.7 TB/s (12 TF/s; tools/gemm_shapes.py) where
+// it is a plain stream of A: a workgroup = 2 wavefronts x 16 rows walks the columns in blocks of 16; the block of V
+// (64 x 16) goes through LDS once per workgroup (double-buffered, one barrier per block) and is the A operand of 16
+// v_mfma_f64_16x16x4 per wavefront and block, the rows are the B operand straight from their 32-byte loads (lane
+// (n, g) owns the columns 16 b + 4 g + i of row n - K slot g of MFMA i, as in k_lq_apply16); the accumulator layout
+// (register i of lane (n, g) = reflector 16 q + 4 i + g, row n) is written out as it is.
+constexpr int WYW_WAVES = 2;
+// blockIdx.y = a slice of the column blocks (kb_per blocks each): few rows (the later panels of a block, the Gram matrix
+// of the block's own vectors) are spread over the chip by columns instead; slice y writes its partial products to
+// W + y * rows * LQW_BLOCK and k_wy_sum adds the slices up in order.
+constexpr int WYW_SPLIT_MAX = 128;
+__global__ __launch_bounds__(64 * WYW_WAVES) void k_wy_w(const double* __restrict__ A, int ld, int rows, int L,
+                                                        const double* __restrict__ V, int ldv, int nb,
+                                                        double* __restrict__ W, int kb_per) {
+    __shared__ __attribute__((aligned(32))) double s_v[2][LQW_BLOCK][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int r = (int)blockIdx.x * 16 * WYW_WAVES + 16 * wv + n;
+    const double* row = A + (long)min(r, rows - 1) * ld;
+    const int nblk_all = (L + 15) / 16;
+    const int b_lo = (int)blockIdx.y * kb_per, nblk = min(nblk_all, b_lo + kb_per);
+    W += (long)blockIdx.y * rows * LQW_BLOCK;
+    // V tile: thread t brings reflector rows t / 4 and 32 + t / 4, columns 4 (t % 4) .. + 3 of the block
+    const int vr = tid >> 2, vc = 4 * (tid & 3);
+    const double* v0 = V + (long)vr * ldv + vc;
+    const double* v1 = V + (long)(vr + 32) * ldv + vc;
+    const bool on0 = vr < nb, on1 = vr + 32 < nb;
+    auto load_v = [&](int b, dbl4& a0, dbl4& a1) {
+        const int j = 16 * b + vc;
+        const dbl4 z = {0.0, 0.0, 0.0, 0.0};
+        a0 = on0 ? *(const dbl4*)(v0 + 16 * b) : z;
+        a1 = on1 ? *(const dbl4*)(v1 + 16 * b) : z;
 #pragma unroll
-    for (int j = 0; j < LQW_BLOCK; ++j)
-        if (j < nb) w[j] = z[j];
+        for (int i = 0; i < 4; ++i)
+            if (j + i >= L) a0[i] = a1[i] = 0.0;
+    };
+    auto load_x = [&](int b) {
+        dbl4 x = *(const dbl4*)(row + min(16 * b + 4 * g, 4 * ((L - 1) / 4)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (16 * b + 4 * g + i >= L) x[i] = 0.0;
+        return x;
+    };
+    d4 acc[4] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+    dbl4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, x = a0;
+    if (b_lo < nblk) {
+        load_v(b_lo, a0, a1);
+        x = load_x(b_lo);
+    }
+    *(dbl4*)&s_v[b_lo & 1][vr][vc] = a0;
+    *(dbl4*)&s_v[b_lo & 1][vr + 32][vc] = a1;
+    __syncthreads();
+    for (int b = b_lo; b < nblk; ++b) {
+        dbl4 xn = x;
+        if (b + 1 < nblk) {
+            load_v(b + 1, a0, a1);
+            xn = load_x(b + 1);
+        }
+        const double (*vt)[16] = s_v[b & 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const dbl4 vq = *(const dbl4*)&vt[16 * q + n][4 * g];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vq[i], x[i], acc[q], 0, 0, 0);
+        }
+        if (b + 1 < nblk) {
+            *(dbl4*)&s_v[(b + 1) & 1][vr][vc] = a0;
+            *(dbl4*)&s_v[(b + 1) & 1][vr + 32][vc] = a1;
+        }
+        x = xn;
+        __syncthreads();
+    }
+    if (r < rows) {
+        double* out = W + (long)r * LQW_BLOCK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[16 * q + 4 * i + g] = acc[q][i];
+    }
+}
+
+// out[e] = sum over the slices y < nsplit of part[y * count + e], in order (count = rows * LQW_BLOCK entries)
+__global__ __launch_bounds__(256) void k_wy_sum(const double* __restrict__ part, int nsplit, long count,
+                                                double* __restrict__ out) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    double acc = 0.0;
+    for (int y = 0; y < nsplit; ++y) acc += part[(long)y * count + e];
+    out[e] = acc;
+}
+
+// The later rows of a block after one of its 16-reflector panels: W1 = sum of the slices (rows x LQW_BLOCK, the first 16
+// entries of a row are its products with the panel's vectors), W2 = W1 T16 (T of the panel kernel, upper triangular):
+// out (rows x 16, row-major) for the GEMM that subtracts W2 V16.  A thread per (row, reflector).
+__global__ __launch_bounds__(256) void k_wy_small_finish(const double* __restrict__ part, int nsplit, int rows,
+                                                         const Lq16Panel* __restrict__ panel, double* __restrict__ out) {
+    __shared__ double s_w[64][LQ16 + 1];
+    const int tid = threadIdx.x, r = tid >> 4, j = tid & 15;          // (rows <= 48: one workgroup of 16 x 16 threads x 4)
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        const int rr = r0 + r;
+        double acc = 0.0;
+        if (rr < rows)
+            for (int y = 0; y < nsplit; ++y) acc += part[((long)y * rows + rr) * LQW_BLOCK + j];
+        s_w[r][j] = acc;
+        __syncthreads();
+        if (rr < rows) {
+            double w2 = 0.0;
+            for (int i = 0; i <= j; ++i) w2 = fma(s_w[r][i], panel->T[i][j], w2);
+            out[(long)rr * LQ16 + j] = w2;
+        }
+        __syncthreads();
+    }
 }

@@ -214,7 +214,7 @@ def sqp_first_qp_parity(eng, prob, lb, ub):
             "checker": "oracle/slsqp_np.py qp_solve (LAPACK LQ), %.1f s of CPU" % (time.perf_counter() - t0)}
 
 
-def sqp_leg(eng, prob, iterations, reference_iterations=0):
+def sqp_leg(eng, prob, iterations, reference_iterations=0, check_first_qp=True):
     """Second BASELINE metric, "wall-clock to SLSQP convergence", on a bounded sample: the first
     ``iterations`` major iterations of ``Problem.solve`` with the QP subproblems on the GPU
     (``sqp_core="hip"``), split into callbacks / QP / BFGS.  The same iterations with SciPy's Fortran
@@ -229,10 +229,15 @@ def sqp_leg(eng, prob, iterations, reference_iterations=0):
     wall = time.perf_counter() - t0
     t = res.timing
     out = _sqp_result(res, wall, t, iterations)
-    try:
-        out.update(sqp_first_qp_parity(eng, prob, lb, ub))
-    except AssertionError as exc:
-        out.update({"parity_checked": False, "parity_failure": str(exc)})
+    if check_first_qp:
+        try:
+            out.update(sqp_first_qp_parity(eng, prob, lb, ub))
+        except AssertionError as exc:
+            out.update({"parity_checked": False, "parity_failure": str(exc)})
+    else:
+        out.update({"parity_checked": None, "parity_note": "the CPU checker of the first subproblem takes minutes at this size: "
+                    "tests/test_slsqp_core.py::test_gpu_first_subproblem_of_the_baseline_configurations runs it"})
+    out["recoveries"] = int(t.get("recoveries", 0))
     if reference_iterations > 0:
         out["scipy_core"] = scipy_core_sample(eng, prob, lb, ub, reference_iterations)
         out["speedup_per_major_iteration"] = (out["scipy_core"]["ms_per_major_iteration"] /
@@ -386,7 +391,7 @@ def main():
                          "workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sqp-iterations", type=int, default=10,
-                    help="major iterations of the SQP leg (0 = skip); skipped above n = 3000")
+                    help="major iterations of the SQP leg (0 = skip)")
     ap.add_argument("--sqp-reference-iterations", type=int, default=2,
                     help="major iterations of the same solve with SciPy's Fortran core, timed next to the SQP "
                          "leg (0 = skip; about 8 s each at n = 1442); skipped above n = 1600")
@@ -724,9 +729,11 @@ def main():
         result["cold_start_s"] = cold_start(a.workload, a.nodes)
         # (import -> traced -> compiled -> handle -> F and the whole Jacobian of the first point on the host)
         result["first_solve_s"] = result["cold_start_s"].get("total_s")
-    if world == 1 and rank == 0 and a.sqp_iterations > 0 and n <= 3000 and not a.quick:
+    if world == 1 and rank == 0 and a.sqp_iterations > 0 and n + 1 <= 8192 and not a.quick:
+        # (round 4: C5 too - its subproblems take 0.07-0.15 s since the wide LQ sweep; the CPU checker of the first
+        # subproblem needs minutes there and runs in tests/test_slsqp_core.py instead)
         result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations,
-                                a.sqp_reference_iterations if n <= 1600 else 0)
+                                a.sqp_reference_iterations if n <= 1600 else 0, check_first_qp=n <= 3000)
     if collective:
         # every rank's replicas hold the whole matrix: compare rank 0's with every other rank's (checksums)
         sums = torch.stack([sh.replica.sum(dtype=torch.float64) for sh in sweeps]).to(pg_dev)

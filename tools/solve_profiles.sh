@@ -4,7 +4,7 @@
 # the HIP SQP core into gpurun_out/<round>_solve_timing_hip.jsonl (reference defaults - maxiter 25 per restart - unless
 # the line says otherwise; the C3 line with --maxiter 400 runs to exit mode 0; C5: the first major iterations)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-rnd=${1:-r03}
+rnd=${1:-r04}
 mkdir -p $R/gpurun_out
 out=$R/gpurun_out/${rnd}_solve_timing.jsonl
 : > $out
@@ -21,7 +21,10 @@ runh polar_tsto_shipped
 runh polar_tsto
 runh polar_tsto --maxiter 400
 runh low_thrust
-runh launch4 --max-restarts 1 --maxiter 4
+runh low_thrust --maxiter 1000 --max-restarts 3
+# C5 (round 4: a well-posed problem, the wide LQ sweep): the reference's defaults, then one long restart under a time limit
+runh launch4
+[ -n "$C5_LONG" ] && runh launch4 --maxiter ${C5_MAXITER:-6000} --max-restarts 2 --time-limit ${C5_LONG}
 # what a new problem shape pays before its first sweep (forced rebuild of its kernel module)
 cold=$R/gpurun_out/${rnd}_cold_start.jsonl
 : > $cold

@@ -41,12 +41,22 @@ def test_solve_records_q13_like_the_reference():
     p == x except p[-1] = x[-1] + h[-1] (quirk Q13)."""
     prob, obj = problems.build("goddard")
     prob.maxIterator = 1
-    prob.solve(obj, maxiter=2)
+    prob.solve(obj, maxiter=2, sqp_core="scipy")          # SciPy's core asking the engine's callbacks
     eng = prob._engine
     (_, _, _), h = eng._jac
     x = np.frombuffer(eng._jac_key, dtype=np.float64)
     assert np.array_equal(prob.p[:-1], x[:-1]) and prob.p[-1] == x[-1] + h[-1]
     eng.close()
+    # the HIP SQP core (the default at this size since round 4) leaves the same trace: its last linearisation's x with
+    # the last column's step on the last entry
+    prob, obj = problems.build("goddard")
+    prob.maxIterator = 1
+    prob.solve(obj, maxiter=2)
+    assert prob.sqp_core_used == "hip"
+    jac = prob._engine._sqp_cache[0]
+    assert np.array_equal(prob.p[:-1], prob.last_result.x[:-1])
+    assert prob.p[-1] == prob.last_result.x[-1] + jac.last_step[-1]
+    prob._engine.close()
 
 
 def test_devices_and_the_hip_sqp_core_work_together(monkeypatch, capsys):

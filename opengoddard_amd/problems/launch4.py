@@ -59,6 +59,7 @@ class Stack:
         self.unit_H = 1.0e9
         self.burn_max = [500.0, 660.0]                          # longest burn of stage 1 / stage 2, seconds
         self.knot_fraction = [0.4, 270.0 / 660.0]               # where a stage's inner knot sits in its burn
+        self.effort_scale = 1.0                                 # weight of the cost
 
     def air_density(self, h):
         h[h < -100.0] = -100.0
@@ -143,15 +144,17 @@ def make_callbacks(api):
     def running_cost(prob, obj):
         u = prob.unit_controls[0][0]
         Tr, Tt, Tn = (prob.controls_all_section(c) for c in range(3))
-        return (Tr ** 2 + Tt ** 2 + Tn ** 2) / u ** 2
+        return obj.effort_scale * (Tr ** 2 + Tt ** 2 + Tn ** 2) / u ** 2
 
     return dynamics, equality, inequality, cost, running_cost
 
 
-def build(api, nodes=None, max_iteration=5):
+def build(api, nodes=None, max_iteration=5, effort_scale=None):
     nodes = list(nodes or [128] * N_PHASE)
     assert len(nodes) == N_PHASE
     obj = Stack()
+    if effort_scale is not None:
+        obj.effort_scale = float(effort_scale)
     t_stage = obj.burn_max[0]
     t_end = t_stage + obj.burn_max[1]
     knots = [0.0, obj.knot_fraction[0] * t_stage, t_stage, t_stage + obj.knot_fraction[1] * obj.burn_max[1], t_end]

@@ -86,3 +86,29 @@ def test_devices_and_the_hip_sqp_core_work_together(monkeypatch, capsys):
     assert one[5] == four[5] == "hip" and one[6] == 1 and four[6] == 4
     assert np.array_equal(one[0], four[0]) and np.array_equal(one[1], four[1])
     assert one[2:5] == four[2:5]
+
+
+@pytest.mark.parametrize("name,maxiter", [("launch4", 11), ("low_thrust", 11)])
+def test_the_redefined_baseline_problems_descend_without_a_non_finite_number(name, maxiter, capsys):
+    """C5's round-1 form overflowed to NaN between the 5th and the 8th major iteration in every core.  The
+    problems as redefined in round 4 (C5: two-stage minimum-effort ascent, C4: 3-D minimum-energy transfer): the first
+    ten major iterations of the default solve keep every iterate, the cost and every constraint value finite, and the
+    L1 merit SLSQP descends on - cost + constraint violation - goes down."""
+    from opengoddard_amd.engine import HipEngine
+    prob, obj = problems.build(name)
+    prob.maxIterator = 1
+    x0 = prob.p.copy()
+    prob.solve(obj, maxiter=maxiter)
+    capsys.readouterr()
+    res = prob.last_result
+    assert prob.sqp_core_used == "hip" and res.status == 9 and res.nit >= maxiter - 1
+    assert np.all(np.isfinite(res.x)) and np.isfinite(res.fun) and np.all(np.isfinite(res.jac))
+    eng = prob._engine
+    F0, F1 = eng.eval_stacked(x0), eng.eval_stacked(res.x)
+    assert np.all(np.isfinite(F1))
+
+    def violation(F):
+        ceq, cin = F[1:1 + eng.m_eq], F[1 + eng.m_eq:]
+        return np.abs(ceq).sum() + np.maximum(-cin, 0.0).sum()
+    assert violation(F1) < 0.5 * violation(F0)
+    eng.close()

@@ -2521,7 +2521,8 @@ void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const do
                  int* nsplit_out, hipStream_t s) {
     const int tiles = (rows + 16 * WYW_WAVES - 1) / (16 * WYW_WAVES), nblk = (L + 15) / 16;
     // enough workgroups for every SIMD of the chip (a workgroup is two wavefronts that issue 16 MFMAs per 2 KB of A)
-    int nsplit = std::max(1, std::min(std::min(WYW_SPLIT_MAX, 1024 / tiles), nblk / 4));
+    // (few rows: at most 32 slices - the kernels that add the slices up walk them one after the other)
+    int nsplit = std::max(1, std::min(std::min(tiles <= 4 ? 32 : WYW_SPLIT_MAX, 1024 / tiles), nblk / 4));
     nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, qp->wy_part_cap / ((size_t)rows * LQW_BLOCK)));
     const int kb_per = (nblk + nsplit - 1) / nsplit;
     nsplit = (nblk + kb_per - 1) / kb_per;

@@ -22,9 +22,9 @@ runh polar_tsto
 runh polar_tsto --maxiter 400
 runh low_thrust
 runh low_thrust --maxiter 1000 --max-restarts 3
-# C5 (round 4: a well-posed problem, the wide LQ sweep): the reference's defaults, then one long restart under a time limit
+# C5 (round 4: a well-posed problem, the wide LQ sweep): the reference's defaults, then to exit mode 0
 runh launch4
-[ -n "$C5_LONG" ] && runh launch4 --maxiter ${C5_MAXITER:-6000} --max-restarts 2 --time-limit ${C5_LONG}
+runh launch4 --maxiter 3000 --max-restarts 3 --time-limit 900
 # what a new problem shape pays before its first sweep (forced rebuild of its kernel module)
 cold=$R/gpurun_out/${rnd}_cold_start.jsonl
 : > $cold

@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     if not f:
         out.write("no counter file for %s\n" % c); continue
     for r in csv.DictReader(open(f[0])):
-        nm = re.search(r"((k_\w+|ogk_\w+)(<[\d, ]+>)?)", r["Kernel_Name"])
+        nm = re.search(r"((k_\w+|ogk_\w+|Cijk_\w{0,40})(<[\d, ]+>)?)", r["Kernel_Name"])
         if not nm: continue
         a = agg.setdefault(nm.group(1), {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
         a[r["Counter_Name"]][0] += float(r["Counter_Value"]); a[r["Counter_Name"]][1] += 1

@@ -17,7 +17,7 @@ vector as a fraction of the maximum, |u| <= 1:
     mdot  = -(T / ve) (ur^2 + ut^2 + uz^2)
 
 from the unit circular orbit to the circular orbit of radius 4 inclined by 10 degrees (reached at
-its node: z = 0, vz = v sin i, vt = v cos i).  Cost: the running cost ur^2 + ut^2 + uz^2 with the
+its node: z = 0, vz = v sin i, vt = v cos i).  Cost: the running cost 100 (ur^2 + ut^2 + uz^2) with the
 raw LGL weights, like the shipped example (quirk Q10) - the minimum-energy transfer.  Round 4
 replaced round 1's planar throttle-times-direction form (controls ur, ut, delta with the thrust
 delta (ur, ut)): its product of controls leaves the direction undetermined wherever the throttle
@@ -44,6 +44,11 @@ class Spacecraft:
         speed = 1.0 / np.sqrt(self.rf)
         self.vt_target = speed * np.cos(self.inclination)
         self.vz_target = speed * np.sin(self.inclination)
+        # weight of the 7x3 running cost: its Hessian in the controls, 2 x weight x w_i with LGL weights of 200 nodes
+        # between 5e-5 and 1.6e-2, is then of the order of the identity SLSQP starts its quasi-Newton matrix from
+        # (measured, MI355X, ftol 1e-6: weight 1 - exit mode 0 after 724 major iterations, 10 - 386, 100 - 127, 1000 - 170;
+        # problems/launch4.py has the longer story)
+        self.effort_scale = 100.0
 
 
 def make_callbacks_3x4(api):
@@ -148,13 +153,15 @@ def make_callbacks_7x3(api):
 
     def running_cost(prob, obj):
         ur, ut, uz = (prob.controls_all_section(i) for i in range(3))
-        return ur ** 2 + ut ** 2 + uz ** 2
+        return obj.effort_scale * (ur ** 2 + ut ** 2 + uz ** 2)
 
     return dynamics, equality, inequality, cost, running_cost
 
 
-def build(api, variant="3x4", nodes=None, max_iteration=10):
+def build(api, variant="3x4", nodes=None, max_iteration=10, effort_scale=None):
     obj = Spacecraft()
+    if effort_scale is not None:
+        obj.effort_scale = float(effort_scale)
     G = api.Guess
     if variant == "3x4":
         prob = api.Problem([0.0, 10.0], list(nodes or [100]), [3], [4], max_iteration)

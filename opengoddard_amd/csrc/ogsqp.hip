@@ -2564,8 +2564,8 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
             double* V = qp->Vall + (size_t)kk * ldw + kk;
             hipLaunchKernelGGL(k_lq_panel16_wide, dim3(nwg), dim3(P16_THREADS), (size_t)2 * LQW_SLAB * sizeof(double), s, qp->Tc,
                                ldw, msweep, nq, kk, V, ldw, qp->diagL, qp->panelw, qp->dthresh + 1, qp->wide_mail,
-                               qp->wide_count, qp->wide_token, qp->flag + 2, qp->spin_limit);
-            qp->wide_token += (unsigned)(nwg * nb16);
+                               (int)(qp->wide_token & 1u), qp->flag + 2, qp->spin_limit);
+            ++qp->wide_token;                                  // the mailbox's generation alternates from launch to launch
             // the later rows of this block: rows <- rows - ((rows V16') T16) V16, T16 from the panel kernel
             const int rest = k0 + nbk - (kk + nb16);
             if (rest > 0) {
@@ -2747,9 +2747,13 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
             qp->wy_part_cap = std::max((size_t)WYW_SPLIT_MAX * 2 * LQW_BLOCK * LQW_BLOCK, 4 * (n1 + vrows) * LQW_BLOCK);
             A(&qp->wy_part, qp->wy_part_cap);
             A(&qp->wy_small, (size_t)2 * LQ16 * LQW_BLOCK);
-            if (!rc && (hipMemset(qp->Vall, 0, vrows * ldw * sizeof(double)) != hipSuccess ||
-                        hipMemset(qp->wide_count, 0, 4 * sizeof(unsigned)) != hipSuccess))
+            if (!rc && hipMemset(qp->Vall, 0, vrows * ldw * sizeof(double)) != hipSuccess)
                 rc = fail(5, "og_qp_create: hipMemset failed");
+            if (!rc) {
+                const int cells = (int)(sizeof(LqWideMail) / sizeof(double));
+                hipLaunchKernelGGL(k_lq_wide_arm, dim3((cells + 255) / 256), dim3(256), 0, 0, qp->wide_mail);
+                if (hipDeviceSynchronize() != hipSuccess) rc = fail(5, "og_qp_create: arming the panel mailbox failed");
+            }
             if (!rc && g_blas.create(&qp->blas) != 0) rc = fail(8, "og_qp_create: rocblas_create_handle failed");
             if (!rc && g_blas.set_atomics) g_blas.set_atomics(qp->blas, 0);       // no atomics: results repeat bit for bit
             if (rc) {

@@ -11,9 +11,9 @@
 //                       [2048 w, 2048 (w + 1)) of all 16 rows in registers exactly like k_lq_panel16 holds its rows.
 //                       A reflector step needs the products of every row with the current row over ALL columns: each
 //                       workgroup adds up its slab's share, the 16 partial sums (and, from workgroup 0, the rows'
-//                       entries in the pivot column) meet in a mailbox in HBM - agent-scope stores, a monotone counter,
-//                       a bounded spin: the workgroups are the whole grid of the launch and wait only for each
-//                       other - and every workgroup derives the same reflector scalars from the same totals and
+//                       entries in the pivot column) meet in a mailbox in HBM - agent-scope stores of values that are
+//                       their own flags, bounded polling: the workgroups are the whole grid of the launch and wait
+//                       only for each other - and every workgroup derives the same reflector scalars from the same totals and
 //                       updates its own slab.  16 exchanges per panel instead of 16 x 8 workgroup-wide reductions over
 //                       rows that do not fit.
 //   the rest            with V of a 64-row block (four panels) and M = T^-1 = diag(1 / beta) + striu(V V')
@@ -29,15 +29,27 @@ constexpr int LQW_SLAB = 256 * LQW_E;
 constexpr int LQW_MAX = 4;                       // workgroups per panel: rows of up to 8192 entries
 constexpr int LQW_BLOCK = 64;                    // reflectors per block reflector
 
+// The mailbox of the column-split panel.  Every value is its own flag: a slot holds LQW_PENDING - a NaN with a payload no
+// computation produces (as in k_trsv_chain) - until its workgroup stores the partial sum there, readers poll the VALUES
+// (agent-scope loads) until none of them is pending: one trip through memory per exchange instead of three (store
+// acknowledged, counter incremented, counter polled, data loaded).  Two generations: a launch uses generation
+// `gen` and re-arms the other one for the next launch (launches of one stream run one after the other, so nobody
+// still reads what is being re-armed).
+constexpr unsigned long long LQW_PENDING = 0x7ff8dead5eedbeefull;
 struct LqWideMail {
-    double v[LQ16][LQW_MAX][32];                 // per step and workgroup: 16 partial products | 16 pivot-column entries
+    double v[2][LQ16][LQW_MAX][32];              // [generation][step][workgroup]: 16 partial products | 16 pivot-column entries
 };
+
+__global__ void k_lq_wide_arm(LqWideMail* mail) {       // once, when the handle is made: everything pending
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int)(sizeof(LqWideMail) / sizeof(double))) (&mail->v[0][0][0][0])[e] = __longlong_as_double((long long)LQW_PENDING);
+}
 
 __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16_wide(double* __restrict__ Tc, int ld, int mrows, int nq, int k,
                                                                 double* __restrict__ V, int ldv, double* __restrict__ diagL,
                                                                 Lq16Panel* __restrict__ panel, double* __restrict__ dmaxbuf,
-                                                                LqWideMail* __restrict__ mail, unsigned* __restrict__ count,
-                                                                unsigned expect0, int* __restrict__ lost, int spin_limit) {
+                                                                LqWideMail* __restrict__ mail, int gen,
+                                                                int* __restrict__ lost, int spin_limit) {
     constexpr int E = LQW_E;
     extern __shared__ double lds[];
     __shared__ double s_part[2][P16_WAVES][LQ16];
@@ -75,6 +87,13 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16_wide(double* __restr
         (&s_lower[0][0])[e] = 0.0;
     }
     double dmax = dmaxbuf[0];
+    if (first) {
+        // re-arm the WHOLE other generation (every step, every workgroup slot - the next launch may have more workgroups
+        // or steps than this one): nobody reads it during this launch
+        double* other = &mail->v[gen ^ 1][0][0][0];
+        for (int e = tid; e < LQ16 * LQW_MAX * 32; e += P16_THREADS)
+            __hip_atomic_store(other + e, __longlong_as_double((long long)LQW_PENDING), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int b = 0; b < LQ16; ++b) {
         if (b < nb) {                                // (uniform)
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16_wide(double* __restr
             __syncthreads();
             // ---- the exchange: wavefront 0 posts this workgroup's share and collects everybody's
             if (wv == 0) {
-                double* mine = &mail->v[b][wg][0];
+                double* mine = &mail->v[gen][b][wg][0];
                 if (lane < LQ16) {
                     double sum = 0.0;
 #pragma unroll
@@ -136,20 +155,26 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16_wide(double* __restr
                 } else if (lane < 2 * LQ16 && first) {
                     __hip_atomic_store(mine + lane, s_xpc[b & 1][lane - LQ16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the stores have been acknowledged
-                if (lane == 0) {
-                    __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    lq_wait_for(count, expect0 + (unsigned)(nwg * (b + 1)), lost, spin_limit);
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (lane < LQ16) {
-                    double sum = 0.0;
-                    for (int w = 0; w < nwg; ++w)
-                        sum += __hip_atomic_load(&mail->v[b][w][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_tot[lane] = sum;
-                } else if (lane < 2 * LQ16) {
-                    s_pc[lane - LQ16] = __hip_atomic_load(&mail->v[b][0][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // lanes 0-15: row `lane`'s partial products of all workgroups; lanes 16-31: workgroup 0's pivot-column entries
+                double total = 0.0;
+                if (lane < 2 * LQ16) {
+                    const int w_lo = lane < LQ16 ? 0 : 0, w_hi = lane < LQ16 ? nwg : 1;
+                    for (int w = w_lo; w < w_hi; ++w) {
+                        const double* src = &mail->v[gen][b][w][lane];
+                        double val = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        int spins = 0;
+                        while ((unsigned long long)__double_as_longlong(val) == LQW_PENDING) {
+                            if (++spins > spin_limit) {
+                                __hip_atomic_store(lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                            val = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        total += val;
+                    }
+                    if (lane < LQ16) s_tot[lane] = total;
+                    else s_pc[lane - LQ16] = total;
                 }
             }
             __syncthreads();

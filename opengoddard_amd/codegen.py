@@ -1141,6 +1141,16 @@ def _sweep_records(P, col_ptr, elem_g, elem_o, elem_k, own_lo, own_hi, heavy, sl
     L += ["static constexpr int OGT_N_LGRP = %d;" % len(light_groups),
           "static const int OGH_LGRP_J[%d] = {%s};" % (len(light_groups) + 1, ", ".join(
               [str(r[0]) for r in light_groups] + [str(P.n)]))]
+    # Light workgroups whose items contain a sequential sum (a running cost: a chain of as many dependent additions
+    # as the sum has terms) are the longest of the launch: they are dispatched FIRST among the light workgroups - the
+    # launch's block index is mapped through these two lists (the groups with a sum, the others, each in column order;
+    # the host passes how many of the first lie below the launch's column range, ogk_launch)
+    with_sum = [i for i, r in enumerate(lgrp) if r[7] & (1 << 16)]
+    without = [i for i, r in enumerate(lgrp) if not r[7] & (1 << 16)]
+    L += ["static __device__ const int OGT_LSUM[%d] = {%s};" % (max(len(with_sum), 1), ", ".join(map(str, with_sum or [0]))),
+          "static __device__ const int OGT_LPLAIN[%d] = {%s};" % (max(len(without), 1), ", ".join(map(str, without or [0]))),
+          "static const unsigned char OGH_LGRP_SUM[%d] = {%s};" % (max(len(lgrp), 1), ", ".join(
+              "1" if r[7] & (1 << 16) else "0" for r in (lgrp or [[0] * 8])))]
     L += table("int4", "OGT_ROWWAVE", rowwaves)
     L.append("static constexpr int OGT_N_ROWWAVES = %d;" % len(rowwaves))
     L += table("int4", "OGT_COL", col)

@@ -650,8 +650,16 @@ class _Emitter:
                           "%s    if (tcp) {" % pad,
                           "%s        const int qd = term_q_of(x, %d, 0);" % (pad, tb),
                           "%s        const S td = term_v_of(x, %d, 0);" % (pad, tb),
-                          "%s        _Pragma(\"unroll 8\")" % pad,
-                          "%s        for (int q = 0; q < %d; ++q) %s = %s + (q == qd ? td : S(tcp[q]));" % (pad, ln, name, name),
+                          # (the terms of a group of eight are loaded whatever q is, all of them before the group's
+                          # additions: left to itself the compiler turns every select into a load under an exec mask -
+                          # eight saveexec / restore pairs in front of every eight additions)
+                          "%s        for (int q0 = 0; q0 < %d; q0 += 8) {" % (pad, ln),
+                          "%s            double tv_[8];" % pad,
+                          "%s            _Pragma(\"unroll\") for (int u = 0; u < 8; ++u) tv_[u] = tcp[q0 + u < %d ? q0 + u : %d];" % (pad, ln, ln - 1),
+                          "%s            _Pragma(\"unroll\") for (int u = 0; u < 8; ++u) OG_KEEP(tv_[u]);" % pad,
+                          "%s            _Pragma(\"unroll\") for (int u = 0; u < 8; ++u)" % pad,
+                          "%s                if (q0 + u < %d) %s = %s + (q0 + u == qd ? td : S(tv_[u]));" % (pad, ln, name, name),
+                          "%s        }" % pad,
                           "%s    } else {" % pad,
                           "%s        _Pragma(\"unroll 8\")" % pad,
                           "%s        for (int q = 0; q < %d; ++q) %s = %s + sum_term(%d, q, x, cv);" % (pad, ln, name, name, tb),

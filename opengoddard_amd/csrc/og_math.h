@@ -26,6 +26,14 @@
 #define OG_HDI inline __attribute__((always_inline))
 #endif
 
+// OG_KEEP(x): the value is materialised here (device code: an empty asm that claims to read and write the register), so
+// that a load feeding a select is not sunk into the select's arm and executed under an exec mask
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OG_KEEP(x) asm volatile("" : "+v"(x))
+#else
+#define OG_KEEP(x) ((void)0)
+#endif
+
 namespace ogm {
 
 OG_HD uint64_t bits_of(double x) { uint64_t u; memcpy(&u, &x, sizeof u); return u; }

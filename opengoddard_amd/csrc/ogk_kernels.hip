@@ -1518,8 +1518,12 @@ __device__ __forceinline__ void fz_tile_body(const ogk_args& a, const int bx, do
     FZ_TRACE_OUT(a);
 }
 
+// At least four wavefronts per SIMD = two workgroups per compute unit = 512 resident workgroups: a problem whose
+// callbacks bring the kernel to 129 registers (C5 since round 4) would otherwise run ONE workgroup per compute unit and
+// start half of its workgroups microseconds late.  Kernels that need fewer registers (84 at C3) are not affected: the
+// attribute is a floor on the occupancy the register allocator must leave possible.
 #ifndef OGK_FUSED_ATTR
-#define OGK_FUSED_ATTR
+#define OGK_FUSED_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 #ifdef OGK_HAS_FUSED
 __global__ __launch_bounds__(SWEEP_THREADS) OGK_FUSED_ATTR void ogk_fused(const ogk_args a, const int ndef, const int n_eval,

@@ -91,6 +91,9 @@ def run_reference(name, maxiter, ftol):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--maxiter", type=int, default=None, help="override the case's number of major iterations")
+    ap.add_argument("--no-reference", action="store_true",
+                    help="only the twin-driven SciPy run (the GPU replay uses nothing else; halves the hours C5 takes)")
     a = ap.parse_args()
     for name, opts in CASES.items():
         if a.only and name not in a.only:
@@ -98,7 +101,13 @@ def main():
         print("golden slsqp:", name, opts, flush=True)
         data = dict(maxiter=np.int64(opts["maxiter"]), ftol=np.float64(opts["ftol"]),
                     scipy_version=np.array(scipy.__version__))
+        if a.maxiter is not None:
+            opts = dict(opts, maxiter=a.maxiter)
+            data["maxiter"] = np.int64(a.maxiter)
         data.update(run_twin(name, **opts))
+        if a.no_reference:
+            np.savez_compressed(os.path.join(OUT, "slsqp_%s.npz" % name), **data)
+            continue
         data.update(run_reference(name, **opts))
         k = min(len(data["iterates_ref"]), len(data["iterates_twin"]) - 1)
         for i in range(k):

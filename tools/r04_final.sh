@@ -9,7 +9,7 @@ bash tools/solve_profiles.sh r04 2>&1 | tail -14 | cut -c1-300
 bash tools/sqp_kstats.sh launch4 60 r04_sqp_launch4_60 2>&1 | tail -12
 bash tools/sqp_kstats.sh polar_tsto 150 r04_sqp_polar_tsto_150 > /dev/null 2>&1
 bash tools/sqp_kstats.sh polar_tsto 10 r04_sqp_polar_tsto > /dev/null 2>&1
+bash tools/sqp_pmc.sh launch4 3 r04_sqp_launch4 > /dev/null 2>&1
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r04_bench_driver_style.json
 OG_BENCH_SAME_DEVICE=1 timeout 900 python bench.py --single-process --gpus 4 --workload low_thrust --steps 100 --reps 5 2>/dev/null | tail -1 > gpurun_out/r04_bench_single_process_x4_low_thrust.json
-cut -c1-200 gpurun_out/r04_bench_driver_style.json; python -c "
-import json; d=json.load(open('gpurun_out/r04_bench_single_process_x4_low_thrust.json')); print(d['ms_per_step'], d['config']['parallelism'][:60], d.get('sqp'))"
+cut -c1-200 gpurun_out/r04_bench_driver_style.json

@@ -176,3 +176,39 @@ def test_to_csv_writes_the_reference_bytes(name, delimiter, tag, lgl_golden, tmp
     b = np.array([[float(v) for v in line.split(delimiter)] for line in want_lines[1:]])
     assert np.array_equal(a[:, 1:], b[:, 1:])                                   # states and controls: the same numbers
     assert np.max(np.abs(a[:, 0] - b[:, 0])) <= 4e-15 * max(1.0, np.abs(b[:, 0]).max())
+
+
+def test_auto_falls_back_to_scipys_core_when_the_hip_core_cannot_take_the_problem(monkeypatch, capsys):
+    """``sqp_core="auto"`` must never turn a problem the reference's core solves into an error.  The
+    HIP SQP core needs torch with a GPU and has capacity limits (include/ogsqp.h); ``sqp.prepare`` says why it cannot
+    run, ``Problem.solve`` then warns, records the reason and hands the solve to SciPy's SLSQP."""
+    import types
+    from opengoddard_amd import sqp
+    from oracle import np_path
+    assert "8192" in sqp.prepare(types.SimpleNamespace(n=9000, m_eq=10))
+    assert "null space" in sqp.prepare(types.SimpleNamespace(n=8000, m_eq=100))
+    reason = sqp.prepare(types.SimpleNamespace(n=300, m_eq=100))           # this container: torch without a GPU
+    assert reason is not None and ("GPU" in reason or "torch" in reason)
+
+    class Engine(np_path.NumpyEngine):                # an engine "auto" would give the HIP core (n >= AUTO_HIP_FROM)
+        def __init__(self, prob, obj):
+            super().__init__(prob, obj)
+            self.n = int(prob.number_of_variables)
+            self.m_eq, self.m_ineq, self.device = 213, 160, 0
+            self.m = 1 + self.m_eq + self.m_ineq
+
+    monkeypatch.setattr(og, "_default_engine", lambda prob, obj, devices=None: Engine(prob, obj))
+    prob, obj = problems.build("polar_tsto_shipped")
+    assert prob.number_of_variables >= og.AUTO_HIP_FROM
+    prob.maxIterator = 1
+    with pytest.warns(RuntimeWarning, match="HIP SQP core is not available"):
+        prob.solve(obj, maxiter=2)
+    capsys.readouterr()
+    assert prob.sqp_core_used == "scipy" and prob.sqp_core_fallback == reason
+    assert prob.last_result.nit == 2
+    # forcing the core does not fall back: it fails loudly
+    prob2, obj2 = problems.build("polar_tsto_shipped")
+    prob2.maxIterator = 1
+    with pytest.raises((RuntimeError, ImportError)):
+        prob2.solve(obj2, maxiter=2, sqp_core="hip")
+    capsys.readouterr()

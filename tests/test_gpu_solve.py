@@ -86,6 +86,18 @@ def test_devices_and_the_hip_sqp_core_work_together(monkeypatch, capsys):
     assert one[5] == four[5] == "hip" and one[6] == 1 and four[6] == 4
     assert np.array_equal(one[0], four[0]) and np.array_equal(one[1], four[1])
     assert one[2:5] == four[2:5]
+    # the exact-Jacobian mode is a single-device kernel: with devices= it keeps the one-device buffers (no sharding, no
+    # failure), and the iterates are those of the run without devices=
+    def run_exact(devices):
+        prob, obj = problems.build("goddard")
+        prob.maxIterator = 1
+        prob.solve(obj, maxiter=6, devices=devices, jacobian="exact", sqp_core="hip")
+        capsys.readouterr()
+        out = (prob.last_result.x.copy(), prob.last_result.nit, prob._engine._sqp_cache[0].sharded_over)
+        prob._engine.close()
+        return out
+    a, b = run_exact(None), run_exact([0, 0])
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2] == 1
 
 
 @pytest.mark.parametrize("name,maxiter", [("launch4", 11), ("low_thrust", 11)])

@@ -642,24 +642,19 @@ class _Emitter:
                 tb = self.term_index[key]
                 # the additions stay in order (Python's left-to-right sum); where the terms come from is the
                 # accessor's business (default: evaluated in place, sum_term)
-                # (default: evaluated in place, sum_term).  An accessor that holds the block's base terms
-                # (term_cache) supplies them with the one term that reads its perturbed variable swapped in:
-                # the loop is then LDS reads and adds, no control flow inside
+                # An accessor that holds the block's base terms (term_cache) supplies them with the one term that
+                # reads its perturbed variable swapped in: the loop is then LDS reads and adds (_cached_sum_lines)
                 lines += ["%s{" % pad,
                           "%s    const double* tcp = term_cache_of(x, %d, 0);" % (pad, tb),
                           "%s    if (tcp) {" % pad,
                           "%s        const int qd = term_q_of(x, %d, 0);" % (pad, tb),
                           "%s        const S td = term_v_of(x, %d, 0);" % (pad, tb),
-                          # (the terms of a group of eight are loaded whatever q is, all of them before the group's
-                          # additions: left to itself the compiler turns every select into a load under an exec mask -
-                          # eight saveexec / restore pairs in front of every eight additions)
-                          "%s        for (int q0 = 0; q0 < %d; q0 += 8) {" % (pad, ln),
-                          "%s            double tv_[8];" % pad,
-                          "%s            _Pragma(\"unroll\") for (int u = 0; u < 8; ++u) tv_[u] = tcp[q0 + u < %d ? q0 + u : %d];" % (pad, ln, ln - 1),
-                          "%s            _Pragma(\"unroll\") for (int u = 0; u < 8; ++u) OG_KEEP(tv_[u]);" % pad,
-                          "%s            _Pragma(\"unroll\") for (int u = 0; u < 8; ++u)" % pad,
-                          "%s                if (q0 + u < %d) %s = %s + (q0 + u == qd ? td : S(tv_[u]));" % (pad, ln, name, name),
-                          "%s        }" % pad,
+                          # (the terms are loaded in groups whatever q is, a group ahead of the additions that use it:
+                          # left to itself the compiler turns every select into a load under an exec mask.  The chain of a
+                          # sequential sum is as long as the sum - 512 terms at C5 - and the longest thing a light
+                          # workgroup of the fused launch does: 11 ns per term like this, 33 with a select on every term
+                          # and the loads waited for group by group)
+                          ] + self._cached_sum_lines(pad + "        ", name, ln) + [
                           "%s    } else {" % pad,
                           "%s        _Pragma(\"unroll 8\")" % pad,
                           "%s        for (int q = 0; q < %d; ++q) %s = %s + sum_term(%d, q, x, cv);" % (pad, ln, name, name, tb),
@@ -667,6 +662,42 @@ class _Emitter:
                           "%s}" % pad]
             names[e] = name
         return bool(found)
+
+    @staticmethod
+    def _cached_sum_lines(pad, name, ln, G=4):
+        """``name += term`` over the ``ln`` cached terms at ``tcp`` with term ``qd`` replaced by ``td``, in order.
+        Two register buffers of G terms take turns (the loads of one are under way while the other is added; the
+        cache is readable 16 doubles past its end, so no load needs a clamp or a predicate).  Only a group in which
+        some lane of the wavefront has its perturbed term pays for the selects: everywhere else the chain is one
+        addition per term."""
+        def load(buf, at):
+            return '%s_Pragma("unroll") for (int u = 0; u < %d; ++u) %s[u] = tcp[%s + u];' % (pad, G, buf, at)
+
+        def keep(buf):
+            return '%s_Pragma("unroll") for (int u = 0; u < %d; ++u) OG_KEEP(%s[u]);' % (pad, G, buf)
+
+        def group(buf, at, cnt):
+            return ['%sif (OG_ANY((unsigned)(qd - (%s)) < %du)) {' % (pad, at, cnt),
+                    '%s    _Pragma("unroll") for (int u = 0; u < %d; ++u) %s = %s + (%s + u == qd ? td : S(%s[u]));'
+                    % (pad, cnt, name, name, at, buf),
+                    '%s} else {' % pad,
+                    '%s    _Pragma("unroll") for (int u = 0; u < %d; ++u) %s = %s + S(%s[u]);' % (pad, cnt, name, name, buf),
+                    '%s}' % pad]
+        # (a buffer is waited for BEFORE the other one's loads go out: the wait is then for everything outstanding,
+        # which the compiler gets right, and those loads have the G additions that follow to arrive)
+        L = ['%sdouble ta_[%d], tb_[%d];' % (pad, G, G), load("ta_", "0"), '%sint q0 = 0;' % pad,
+             '%sfor (; q0 + %d <= %d; q0 += %d) {' % (pad, 2 * G, ln, 2 * G),
+             "    " + keep("ta_"), "    " + load("tb_", "q0 + %d" % G)] + ["    " + l for l in group("ta_", "q0", G)] + \
+            ["    " + keep("tb_"), "    " + load("ta_", "q0 + %d" % (2 * G))] + \
+            ["    " + l for l in group("tb_", "q0 + %d" % G, G)] + ['%s}' % pad]
+        rest = ln % (2 * G)
+        if rest >= G:
+            L += [keep("ta_"), load("tb_", "q0 + %d" % G)] + group("ta_", "q0", G)
+            if rest > G:
+                L += [keep("tb_")] + group("tb_", "q0 + %d" % G, rest - G)
+        elif rest:
+            L += [keep("ta_")] + group("ta_", "q0", rest)
+        return L
 
     def term_functions(self):
         """``sum_term(tb, q, x, cv)``: term q of block tb; ``sum_term_reads(tb, q, j)``: does it read p[j]?"""

@@ -28,10 +28,13 @@
 
 // OG_KEEP(x): the value is materialised here (device code: an empty asm that claims to read and write the register), so
 // that a load feeding a select is not sunk into the select's arm and executed under an exec mask
+// OG_ANY(c): true in every lane of the wavefront if c holds in any of them (a branch on it is uniform: no exec masks)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OG_KEEP(x) asm volatile("" : "+v"(x))
+#define OG_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
 #else
 #define OG_KEEP(x) ((void)0)
+#define OG_ANY(c) (c)
 #endif
 
 namespace ogm {

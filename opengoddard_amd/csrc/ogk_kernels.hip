@@ -133,7 +133,7 @@ __device__ __forceinline__ XColT make_xcolt(const ogk_args& a, const int j, cons
     return x;
 }
 constexpr bool TERM_CACHE = OgGen::N_TERMS > 0 && OgGen::N_TERMS <= 2048;      // LDS doubles a workgroup spends on it
-constexpr int TERM_DOUBLES = TERM_CACHE ? OgGen::N_TERMS : 0;
+constexpr int TERM_DOUBLES = TERM_CACHE ? OgGen::N_TERMS + 16 : 0;     // (+16: the generated sum loops read whole groups of eight, one group ahead)
 
 // all threads of a workgroup: the base terms into LDS (the caller's barrier publishes them)
 template <int THREADS>

@@ -2401,8 +2401,18 @@ struct og_qp_s {
     unsigned wide_token = 0u;
     double* wy_part = nullptr;         // column slices of a product (k_wy_w with blockIdx.y > 0), summed by k_wy_sum
     size_t wy_part_cap = 0;
-    double *wy_w = nullptr, *wy_m = nullptr, *wy_t = nullptr, *wy_small = nullptr;   // 2 x (rows x 64) coefficients, M, T = M^-1, 2 x (64 x 16)
+    double *wy_w = nullptr, *wy_m = nullptr, *wy_t = nullptr, *wy_small = nullptr;   // 2 x (rows x 64) coefficients, M, T = M^-1 (one per block of a sweep), 2 x (64 x 16)
     void* blas = nullptr;              // rocblas_handle
+    // The block reflectors are applied to the rest of C Z and to Z on two streams of their own while the caller's stream
+    // goes on with the next block's panels (OGSQP_WIDE_AHEAD=0: everything on the caller's stream, one after the other)
+    struct WyLane {
+        hipStream_t s = nullptr;       // lane 0: the stream of the call
+        void* blas = nullptr;
+        double *w = nullptr, *part = nullptr;
+    } lane[3];
+    bool wide_ahead = false;
+    std::vector<hipEvent_t> ev_t, ev_tc;   // per block: T is there (caller's stream) / the rest of C Z has it applied (lane 1)
+    hipEvent_t ev_join[2] = {nullptr, nullptr};
     int spin_limit = 1 << 25;          // bound of the inter-workgroup waits (OGSQP_SPIN_LIMIT: tests force a loss with 1)
     int recoveries = 0;                // subproblems re-run with the separate-launch forms after a wait gave up
     bool lq_ahead = true;              // OGSQP_LQ=16: panel and trailing update as separate launches
@@ -2508,17 +2518,18 @@ bool load_blas() {
 }
 
 // C (m x n, column-major, ldc) = alpha op(A) op(B) + beta C
-int blas_gemm(og_qp_s* qp, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
+int blas_gemm(void* handle, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
               int ldb, double beta, double* C, int ldc) {
     if (m <= 0 || n <= 0) return 0;
-    const int rc = g_blas.dgemm(qp->blas, ta, tb, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc);
+    const int rc = g_blas.dgemm(handle, ta, tb, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc);
     if (rc != 0) return fail(8, "og_qp_solve_dev: rocblas_dgemm failed (status " + std::to_string(rc) + ")");
     return 0;
 }
 
 // W (rows x 64) = A V' by k_wy_w; few rows are split over the chip by columns (partials in wy_part, summed in order)
 void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const double* V, int ldv, int nb, double* W,
-                 int* nsplit_out, hipStream_t s) {
+                 int* nsplit_out, hipStream_t s, double* part = nullptr) {
+    if (!part) part = qp->wy_part;
     const int tiles = (rows + 16 * WYW_WAVES - 1) / (16 * WYW_WAVES), nblk = (L + 15) / 16;
     // enough workgroups for every SIMD of the chip (a workgroup is two wavefronts that issue 16 MFMAs per 2 KB of A)
     // (few rows: at most 32 slices - the kernels that add the slices up walk them one after the other)
@@ -2526,7 +2537,7 @@ void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const do
     nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, qp->wy_part_cap / ((size_t)rows * LQW_BLOCK)));
     const int kb_per = (nblk + nsplit - 1) / nsplit;
     nsplit = (nblk + kb_per - 1) / kb_per;
-    double* dst = nsplit > 1 ? qp->wy_part : W;
+    double* dst = nsplit > 1 ? part : W;
     hipLaunchKernelGGL(k_wy_w, dim3(tiles, nsplit), dim3(64 * WYW_WAVES), 0, s, A, ld, rows, L, V, ldv, nb, dst, kb_per);
     if (nsplit_out) {
         *nsplit_out = nsplit;                         // the caller sums the slices itself (k_wy_small_finish)
@@ -2534,7 +2545,7 @@ void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const do
     }
     if (nsplit > 1) {
         const long count = (long)rows * LQW_BLOCK;
-        hipLaunchKernelGGL(k_wy_sum, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const double*)qp->wy_part,
+        hipLaunchKernelGGL(k_wy_sum, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const double*)part,
                            nsplit, count, W);
     }
 }
@@ -2542,23 +2553,28 @@ void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const do
 // rows <- rows - ((rows V') M^-1) V for `rows` rows of length L starting at A (leading dimension ld), V: nb reflectors
 // (row-major, leading dimension ldv) over the same L columns, M from k_wy_make_m.  Row-major X (r x c, ld) is the
 // column-major c x r matrix with the same ld: all three products are plain GEMMs on those views.
-int wy_apply_block(og_qp_s* qp, double* A, int ld, int rows, int L, const double* V, int ldv, int nb, hipStream_t s) {
+int wy_apply_block(og_qp_s* qp, const og_qp_s::WyLane& ln, double* A, int ld, int rows, int L, const double* V, int ldv,
+                   int nb, const double* T) {
     if (rows <= 0) return 0;
-    double* W = qp->wy_w;                                         // rows x LQW_BLOCK (as column-major: LQW_BLOCK x rows)
-    double* W2 = qp->wy_w + (size_t)rows * LQW_BLOCK;
-    launch_wy_w(qp, A, ld, rows, L, V, ldv, nb, W, nullptr, s);                                                // W = A V'
+    double* W = ln.w;                                             // rows x LQW_BLOCK (as column-major: LQW_BLOCK x rows)
+    double* W2 = ln.w + (size_t)rows * LQW_BLOCK;
+    launch_wy_w(qp, A, ld, rows, L, V, ldv, nb, W, nullptr, ln.s, ln.part);                                    // W = A V'
     // W2 = W T (T = M^-1, row-major, upper triangular): as column-major, W2' = T' W' with T' = the array read column-major
-    OG_TRY(blas_gemm(qp, BLAS_N, BLAS_N, nb, rows, nb, 1.0, qp->wy_t, LQW_BLOCK, W, LQW_BLOCK, 0.0, W2, LQW_BLOCK));
-    return blas_gemm(qp, BLAS_N, BLAS_N, L, rows, nb, -1.0, V, ldv, W2, LQW_BLOCK, 1.0, A, ld);               // A' -= V' W2'
+    OG_TRY(blas_gemm(ln.blas, BLAS_N, BLAS_N, nb, rows, nb, 1.0, T, LQW_BLOCK, W, LQW_BLOCK, 0.0, W2, LQW_BLOCK));
+    return blas_gemm(ln.blas, BLAS_N, BLAS_N, L, rows, nb, -1.0, V, ldv, W2, LQW_BLOCK, 1.0, A, ld);          // A' -= V' W2'
 }
 
 // The sweep over rows longer than LQW_SLAB entries, from reflector k on, in blocks of LQW_BLOCK reflectors: returns the
 // first reflector it did not handle (rows short enough for the look-ahead kernels, or msweep).
 int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s, int* done) {
+    og_qp_s::WyLane& l0 = qp->lane[0];
+    l0.s = s, l0.blas = qp->blas, l0.w = qp->wy_w, l0.part = qp->wy_part;
     if (g_blas.set_stream(qp->blas, s) != 0) return fail(8, "og_qp_solve_dev: rocblas_set_stream failed");
-    while (k < msweep && nq - k > LQW_SLAB) {
+    const bool ahead = qp->wide_ahead;
+    int rc = 0, b = 0;
+    while (!rc && k < msweep && nq - k > LQW_SLAB) {
         const int k0 = k, nbk = std::min(LQW_BLOCK, msweep - k0), L0 = nq - k0;
-        for (int sub = 0; sub < nbk; sub += LQ16) {
+        for (int sub = 0; sub < nbk && !rc; sub += LQ16) {
             const int kk = k0 + sub, nb16 = std::min(LQ16, msweep - kk), len = nq - kk;
             const int nwg = (len + LQW_SLAB - 1) / LQW_SLAB;
             double* V = qp->Vall + (size_t)kk * ldw + kk;
@@ -2575,21 +2591,54 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
                 launch_wy_w(qp, A, ldw, rest, len, V, ldw, LQ16, qp->wy_part, &nsplit, s);
                 hipLaunchKernelGGL(k_wy_small_finish, dim3(1), dim3(256), 0, s, (const double*)qp->wy_part, nsplit, rest,
                                    (const Lq16Panel*)qp->panelw, W2);
-                OG_TRY(blas_gemm(qp, BLAS_N, BLAS_N, len, rest, LQ16, -1.0, V, ldw, W2, LQ16, 1.0, A, ldw));
+                rc = blas_gemm(qp->blas, BLAS_N, BLAS_N, len, rest, LQ16, -1.0, V, ldw, W2, LQ16, 1.0, A, ldw);
             }
         }
-        // the block reflector: M = T^-1 from the Gram matrix of its nbk reflector vectors (columns k0 .. nq)
+        if (rc) break;
+        // the block reflector: M = T^-1 from the Gram matrix of its nbk reflector vectors (columns k0 .. nq); every block
+        // of a sweep has its own T (the lanes that apply it may be a few blocks behind)
         const double* Vb = qp->Vall + (size_t)k0 * ldw + k0;
+        double* T = qp->wy_t + (size_t)b * LQW_BLOCK * LQW_BLOCK;
         launch_wy_w(qp, Vb, ldw, nbk, L0, Vb, ldw, nbk, qp->wy_m, nullptr, s);                    // S = V V' (nbk x 64)
         hipLaunchKernelGGL(k_wy_make_m, dim3(1), dim3(256), 0, s, qp->wy_m, nbk);
-        hipLaunchKernelGGL(k_wy_invert, dim3(1), dim3(LQW_BLOCK), 0, s, (const double*)qp->wy_m, nbk, qp->wy_t);
+        hipLaunchKernelGGL(k_wy_invert, dim3(1), dim3(LQW_BLOCK), 0, s, (const double*)qp->wy_m, nbk, T);
         // ... applied to what is left of C Z (and of the warm-start rows) and to Z
-        OG_TRY(wy_apply_block(qp, qp->Tc + (size_t)(k0 + nbk) * ldw + k0, ldw, msweep - k0 - nbk, L0, Vb, ldw, nbk, s));
-        OG_TRY(wy_apply_block(qp, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, s));
+        double* Arest = qp->Tc + (size_t)(k0 + nbk) * ldw + k0;
+        const int rows_rest = msweep - k0 - nbk;
+        if (!ahead) {
+            // (in the same two pieces as below: the column slices of a product - hence its rounding - depend on the
+            // number of rows, and the two orders of execution are to give the same bits)
+            const int nxt = std::min(LQW_BLOCK, rows_rest);
+            rc = wy_apply_block(qp, l0, Arest, ldw, nxt, L0, Vb, ldw, nbk, T);
+            if (!rc) rc = wy_apply_block(qp, l0, Arest + (size_t)nxt * ldw, ldw, rows_rest - nxt, L0, Vb, ldw, nbk, T);
+            if (!rc) rc = wy_apply_block(qp, l0, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, T);
+        } else {
+            // Only the next block's rows are needed before its panels can start: they are done here, on this stream; the
+            // other rows of C Z (lane 1) and Z (lane 2) get the block on their own streams - the panels are one
+            // latency chain on four workgroups, the applications stream through the whole matrix: side by side they use
+            // what the other leaves idle.  Same arithmetic on disjoint rows: the results do not depend on the overlap.
+            const og_qp_s::WyLane &l1 = qp->lane[1], &l2 = qp->lane[2];
+            const int nxt = std::min(LQW_BLOCK, rows_rest);
+            OG_HIP(hipEventRecord(qp->ev_t[b], s));
+            if (b > 0) OG_HIP(hipStreamWaitEvent(s, qp->ev_tc[b - 1], 0));   // (lane 1 had these rows for block b - 1)
+            rc = wy_apply_block(qp, l0, Arest, ldw, nxt, L0, Vb, ldw, nbk, T);
+            OG_HIP(hipStreamWaitEvent(l1.s, qp->ev_t[b], 0));
+            if (!rc) rc = wy_apply_block(qp, l1, Arest + (size_t)nxt * ldw, ldw, rows_rest - nxt, L0, Vb, ldw, nbk, T);
+            OG_HIP(hipEventRecord(qp->ev_tc[b], l1.s));
+            OG_HIP(hipStreamWaitEvent(l2.s, qp->ev_t[b], 0));
+            if (!rc) rc = wy_apply_block(qp, l2, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, T);
+        }
         k = k0 + nbk;
+        ++b;
+    }
+    if (ahead && b > 0) {                                         // the caller's stream goes on when both lanes are through
+        for (int l = 0; l < 2; ++l) {
+            OG_HIP(hipEventRecord(qp->ev_join[l], qp->lane[1 + l].s));
+            OG_HIP(hipStreamWaitEvent(s, qp->ev_join[l], 0));
+        }
     }
     *done = k;
-    return 0;
+    return rc;
 }
 
 // out = (the `rows` columns of A from col0 on, or the ones sel names)' Jw: the map of non-empty slabs, then the product
@@ -2743,7 +2792,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
             const size_t vrows = ((size_t)qp->meq + qc + LQW_BLOCK - 1) / LQW_BLOCK * LQW_BLOCK + LQW_BLOCK;
             A(&qp->Vall, vrows * ldw); A(&qp->panelw, 1); A(&qp->wide_mail, 1); A(&qp->wide_count, 4);
             A(&qp->wy_w, 2 * (n1 + vrows) * LQW_BLOCK); A(&qp->wy_m, (size_t)LQW_BLOCK * LQW_BLOCK);
-            A(&qp->wy_t, (size_t)LQW_BLOCK * LQW_BLOCK);
+            const size_t nblocks = vrows / LQW_BLOCK + 1;
+            A(&qp->wy_t, nblocks * LQW_BLOCK * LQW_BLOCK);
             qp->wy_part_cap = std::max((size_t)WYW_SPLIT_MAX * 2 * LQW_BLOCK * LQW_BLOCK, 4 * (n1 + vrows) * LQW_BLOCK);
             A(&qp->wy_part, qp->wy_part_cap);
             A(&qp->wy_small, (size_t)2 * LQ16 * LQW_BLOCK);
@@ -2756,6 +2806,28 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
             }
             if (!rc && g_blas.create(&qp->blas) != 0) rc = fail(8, "og_qp_create: rocblas_create_handle failed");
             if (!rc && g_blas.set_atomics) g_blas.set_atomics(qp->blas, 0);       // no atomics: results repeat bit for bit
+            const char* wahead = getenv("OGSQP_WIDE_AHEAD");
+            if (!rc && !(wahead && std::string(wahead) == "0")) {
+                for (int l = 1; l < 3 && !rc; ++l) {
+                    og_qp_s::WyLane& ln = qp->lane[l];
+                    A(&ln.w, 2 * (n1 + vrows) * LQW_BLOCK);
+                    A(&ln.part, qp->wy_part_cap);
+                    if (!rc && hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) != hipSuccess)
+                        rc = fail(5, "og_qp_create: hipStreamCreate failed");
+                    if (!rc && g_blas.create(&ln.blas) != 0) rc = fail(8, "og_qp_create: rocblas_create_handle failed");
+                    if (!rc && g_blas.set_atomics) g_blas.set_atomics(ln.blas, 0);
+                    if (!rc && g_blas.set_stream(ln.blas, ln.s) != 0) rc = fail(8, "og_qp_create: rocblas_set_stream failed");
+                    if (!rc && hipEventCreateWithFlags(&qp->ev_join[l - 1], hipEventDisableTiming) != hipSuccess)
+                        rc = fail(5, "og_qp_create: hipEventCreate failed");
+                }
+                qp->ev_t.assign(nblocks, nullptr);
+                qp->ev_tc.assign(nblocks, nullptr);
+                for (size_t e = 0; e < nblocks && !rc; ++e)
+                    if (hipEventCreateWithFlags(&qp->ev_t[e], hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&qp->ev_tc[e], hipEventDisableTiming) != hipSuccess)
+                        rc = fail(5, "og_qp_create: hipEventCreate failed");
+                qp->wide_ahead = !rc;
+            }
             if (rc) {
                 og_qp_destroy(qp);
                 return rc;
@@ -2776,6 +2848,13 @@ void og_qp_destroy(og_qp_handle qp) {
     (void)hipSetDevice(qp->device);
     for (void* p : qp->owned) (void)hipFree(p);
     if (qp->blas && g_blas.destroy) (void)g_blas.destroy(qp->blas);
+    for (int l = 1; l < 3; ++l) {
+        if (qp->lane[l].blas && g_blas.destroy) (void)g_blas.destroy(qp->lane[l].blas);
+        if (qp->lane[l].s) (void)hipStreamDestroy(qp->lane[l].s);
+        if (qp->ev_join[l - 1]) (void)hipEventDestroy(qp->ev_join[l - 1]);
+    }
+    for (hipEvent_t e : qp->ev_t) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : qp->ev_tc) if (e) (void)hipEventDestroy(e);
     if (qp->jt_stage) (void)hipFree(qp->jt_stage);
     if (qp->stream) (void)hipStreamDestroy(qp->stream);
     delete qp;

@@ -729,6 +729,37 @@ def test_gpu_wide_sweep_agrees_with_the_old_kernels(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gpu_wide_sweep_on_side_streams_gives_the_bits_of_the_one_stream_order(monkeypatch):
+    """The block reflectors of the wide sweep are applied to the rest of C Z and to Z on two streams of the handle's own
+    while the caller's stream factors the next block (events order what depends on what); ``OGSQP_WIDE_AHEAD=0`` runs
+    the same kernels on the same pieces one after the other on the caller's stream.  Disjoint rows, same arithmetic:
+    the step, the multipliers and the change count must be the same BITS - a missing dependency between the streams
+    would show here (several subproblems per handle, so that consecutive sweeps overlap too)."""
+    rng = np.random.default_rng(77)
+    n, meq, mg = 4300, 2000, 100
+    Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+    A, cc = np.vstack([C, G]), np.concatenate([c, h])
+    results = {}
+    for form in ("ahead", "serial"):
+        monkeypatch.delenv("OGSQP_WIDE_AHEAD", raising=False)
+        if form == "serial":
+            monkeypatch.setenv("OGSQP_WIDE_AHEAD", "0")
+        core = _sqp_native.QpCore(n, meq, mg)
+        out = []
+        for rep in range(3):
+            core.set_factor(Z * (1.0 + 0.25 * rep))
+            core.set_active()
+            d, mult, bm, status, iters = core.solve(A, g, cc, lb, ub)
+            out.append((d.copy(), mult.copy(), status, iters))
+        assert core.recoveries() == 0
+        core.close()
+        results[form] = out
+    for (d0, m0, s0, i0), (d1, m1, s1, i1) in zip(results["serial"], results["ahead"]):
+        assert s0 == s1 == 1 and i0 == i1
+        assert np.array_equal(d0, d1) and np.array_equal(m0, m1)
+
+
+@pytest.mark.gpu
 def test_device_resident_jacobian_equals_host_staged():
     """og_qp_solve_dev on the Jacobian the sweep kernel left in HBM == og_qp_solve on its host copy;
     og_jt_times gives the cost gradient and the gradient of the Lagrangian."""

@@ -73,3 +73,10 @@ if len(light):
     o = np.argsort(lw)
     for part, idx in enumerate(np.array_split(o, 10)):
         print("      tenth %d: %5.2f  %5.2f  %5.2f" % (part, np.median(us(light[idx, 1])), np.median(us(light[idx, 7])), us(light[idx, 7]).max()))
+    # the slowest item wavefronts of the light workgroups, stamp by stamp (service wavefronts have no 'operands' stamp... they
+    # return before the items' stamps: column 6 is 0 for them)
+    it = np.where((rec[:, 0] == 1) & (rec[:, 6] > 0))[0]
+    it = it[np.argsort(-rec[it, 7])[:10]]
+    print("   slowest item wavefronts (light): wg / start / barrier / operands of the column / tails of the first rounds / flag seen / items done / end")
+    for i in it:
+        print("      wg %4d  %s" % (wg[i], "  ".join("%6.2f" % us(rec[i, c]) for c in (1, 2, 3, 6, 4, 5, 7))))

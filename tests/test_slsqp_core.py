@@ -492,7 +492,7 @@ def test_gpu_qp_replays_scipy_goldens_at_baseline_sizes(name, worst, typical, mo
     solved by the HIP core in its default configuration (row-parallel active-set method, warm-started from the previous
     subproblem's active rows; at C5 the wide LQ sweep).  Same bounds as the restatement's own replay at C3 / C4: the
     conditioning of these subproblems sets them (test_slsqp_restatement_replays_scipy_goldens_at_baseline_sizes); C5's
-    golden holds SciPy's first two major iterations (10 minutes each for the Fortran core) and its first subproblem is
+    golden holds SciPy's first two major iterations (1.6 hours each for the Fortran core) and its first subproblem is
     the worst conditioned of the three (the referee puts either solver at 1e-5 .. 4e-5 of its step)."""
     if not os.path.exists(os.path.join(ROOT, "tests", "golden", "slsqp_%s.npz" % name)):
         pytest.skip("no SciPy golden for %s in this tree" % name)

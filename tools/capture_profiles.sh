@@ -15,7 +15,7 @@ Q="--quick --no-cpu-baseline --sqp-iterations 0"
 for w in polar_tsto low_thrust launch4; do
     rm -rf $out/ktrace_$w
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace_$w -o b -- \
-        python $R/bench.py --workload $w --steps 200 --warmup 20 --reps 5 $Q > $out/ktrace_$w.log 2>&1
+        python $R/bench.py --workload $w --steps 200 --warmup 20 --reps 25 $Q > $out/ktrace_$w.log 2>&1
     for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf $out/pmc_${c}_$w
         timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${c}_$w -o b -- \

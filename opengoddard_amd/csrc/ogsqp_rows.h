@@ -162,9 +162,23 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         double* bA = d;
         for (int i = tid; i < q; i += ROWS_THREADS) bA[i] = g.bval[g.act[i]];
         __syncthreads();
+        // (one workgroup reads the inverse twice per removal: what it costs is the number of round trips, so eight rows
+        // of the first product and four of the second are in flight per thread, the sums in their old order - 82 us per removal at C3 before)
         for (int j = tid; j < q; j += ROWS_THREADS) {          // M' y1 = -b_A  ->  y1 = -RI' b_A
+            // (two sums, even and odd rows, as ever - the order of the additions is part of the result - but eight
+            // rows requested before the first of them is used)
             double acc0 = 0.0, acc1 = 0.0;
             int i = 0;
+            for (; i + 7 < q; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = RI[(long)a.slot[i + u] * qcap + j];
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    acc0 += v[u] * bA[i + u];
+                    acc1 += v[u + 1] * bA[i + u + 1];
+                }
+            }
             for (; i + 1 < q; i += 2) {
                 acc0 += RI[(long)a.slot[i] * qcap + j] * bA[i];
                 acc1 += RI[(long)a.slot[i + 1] * qcap + j] * bA[i + 1];
@@ -175,16 +189,29 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         __syncthreads();
         double worst = INFINITY;
         int kworst = 0x7fffffff;
-        for (int i = wave; i < q; i += ROWS_WAVES) {           // y = N u  ->  u = RI y1
-            const double* row = RI + (long)a.slot[i] * qcap;
-            double acc = 0.0;
-            for (int j = lane; j < q; j += 64) acc += row[j] * y1[j];
-            acc = wave_sum(acc);
+        for (int i0 = 4 * wave; i0 < q; i0 += 4 * ROWS_WAVES) {    // y = N u  ->  u = RI y1, four rows per wavefront and trip
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            const double* row[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) row[u] = RI + (long)a.slot[min(i0 + u, q - 1)] * qcap;
+            for (int j = lane; j < q; j += 64) {
+                const double yj = y1[j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] += row[u][j] * yj;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
             if (lane == 0) {
-                rv[i] = acc;
-                if (acc < worst) {
-                    worst = acc;
-                    kworst = i;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u;
+                    if (i < q) {
+                        rv[i] = acc[u];
+                        if (acc[u] < worst || (acc[u] == worst && i < kworst)) {
+                            worst = acc[u];
+                            kworst = i;
+                        }
+                    }
                 }
             }
         }

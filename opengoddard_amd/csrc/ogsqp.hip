@@ -2589,7 +2589,7 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
                 double* W2 = qp->wy_small;                                  // rest x 16
                 int nsplit = 1;
                 launch_wy_w(qp, A, ldw, rest, len, V, ldw, LQ16, qp->wy_part, &nsplit, s);
-                hipLaunchKernelGGL(k_wy_small_finish, dim3(1), dim3(256), 0, s, (const double*)qp->wy_part, nsplit, rest,
+                hipLaunchKernelGGL(k_wy_small_finish, dim3(1), dim3(1024), 0, s, (const double*)qp->wy_part, nsplit, rest,
                                    (const Lq16Panel*)qp->panelw, W2);
                 rc = blas_gemm(qp->blas, BLAS_N, BLAS_N, len, rest, LQ16, -1.0, V, ldw, W2, LQ16, 1.0, A, ldw);
             }

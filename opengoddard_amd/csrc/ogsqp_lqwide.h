@@ -412,22 +412,23 @@ __global__ __launch_bounds__(256) void k_wy_sum(const double* __restrict__ part,
 // The later rows of a block after one of its 16-reflector panels: W1 = sum of the slices (rows x LQW_BLOCK, the first 16
 // entries of a row are its products with the panel's vectors), W2 = W1 T16 (T of the panel kernel, upper triangular):
 // out (rows x 16, row-major) for the GEMM that subtracts W2 V16.  A thread per (row, reflector).
-__global__ __launch_bounds__(256) void k_wy_small_finish(const double* __restrict__ part, int nsplit, int rows,
-                                                         const Lq16Panel* __restrict__ panel, double* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_wy_small_finish(const double* __restrict__ part, int nsplit, int rows,
+                                                          const Lq16Panel* __restrict__ panel, double* __restrict__ out) {
     __shared__ double s_w[64][LQ16 + 1];
-    const int tid = threadIdx.x, r = tid >> 4, j = tid & 15;          // (rows <= 48: one workgroup of 16 x 16 threads x 4)
-    for (int r0 = 0; r0 < rows; r0 += 16) {
+    const int tid = threadIdx.x, r = tid >> 4, j = tid & 15;          // (rows <= 48: ONE pass of 64 x 16 threads)
+    for (int r0 = 0; r0 < rows; r0 += 64) {
         const int rr = r0 + r;
         double acc = 0.0;
         if (rr < rows) {
-            // (the slices' loads go out eight at a time; the additions stay in order)
-            for (int y0 = 0; y0 < nsplit; y0 += 8) {
-                double v[8];
+            // (the kernel is as long as its round trips to the slices: their loads go out sixteen at a time; the
+            // additions stay in order)
+            for (int y0 = 0; y0 < nsplit; y0 += 16) {
+                double v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 16; ++u)
                     v[u] = y0 + u < nsplit ? part[((long)(y0 + u) * rows + rr) * LQW_BLOCK + j] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 16; ++u)
                     if (y0 + u < nsplit) acc += v[u];
             }
         }

@@ -18,7 +18,7 @@ os.makedirs(dst, exist_ok=True)
 lines = ["# rocprofv3 summary, round %s (MI355X, gfx950)" % rnd, "",
          "Commands (run from /tmp with TMPDIR=/tmp, see tools/kstats.sh):",
          "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload W --steps 200 --warmup 20 "
-         "--reps 5 --quick --no-cpu-baseline --sqp-iterations 0` (tools/capture_profiles.sh)",
+         "--reps 25 --quick --no-cpu-baseline --sqp-iterations 0` (tools/capture_profiles.sh)",
          "`rocprofv3 --pmc FETCH_SIZE -- ...` and `rocprofv3 --pmc WRITE_SIZE -- ...` (separate passes, 50 steps).",
          "A step is ONE `ogk_fused` launch into a registered persistent-zero buffer (all sizes); "
          "`*_split` = the same workload with OGPSX_SWEEP=split.  The other `ogk_eval` / `ogk_sweep` / `ogk_exact_struct` "

@@ -271,6 +271,55 @@ def scipy_core_sample(eng, prob, lb, ub, iterations):
             "wall_s": wall, "ms_per_major_iteration": 1e3 * wall / done}
 
 
+# what the `solve` leg runs (the reference's loop, ``optimize.py:738-755``: restarts of ``maxiter`` major iterations
+# until SLSQP reports exit mode 0): C3 with 400 iterations per restart (the reference's default of 25 resets the
+# quasi-Newton matrix too often for this size to converge inside maxIterator restarts), C4 with the defaults
+SOLVE_OPTIONS = {"polar_tsto": {"maxiter": 400}, "low_thrust": {}, "launch4": {"maxiter": 3000},
+                 "goddard": {"ftol": 1e-10}}
+
+
+def solve_leg(name, options=None, check=True):
+    """Second half of BASELINE.json's metric, measured whole: ``Problem.solve`` (this package's, default SQP core = the
+    HIP one at these sizes) from the problem's own initial guess to SLSQP's exit mode 0 - wall-clock of the call, split
+    into callbacks (values + Jacobians), QP subproblems and BFGS updates - and, NOT timed, the independent check of
+    what it returned: the KKT residuals of the reference's NLP at the returned point, every number of which comes from
+    the NumPy restatement of the reference path (oracle/kkt.py; the checker, never the thing measured)."""
+    import contextlib
+    import io
+    from opengoddard_amd import problems
+    options = dict(SOLVE_OPTIONS.get(name, {}) if options is None else options)
+    prob, obj = problems.build(name)
+    buf = io.StringIO()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(buf):
+        prob.solve(obj, sqp_core="hip", **options)
+    wall = time.perf_counter() - t0
+    text = buf.getvalue()
+    tm = prob.sqp_timings
+    res = prob.last_result
+    parts = {k: sum(t[k] for t in tm) for k in ("callbacks", "qp", "bfgs")}
+    out = {"workload": name, "n": int(prob.number_of_variables), "options": dict(options, sqp_core="hip"),
+           "exit_mode": int(res.status), "converged": bool(res.status == 0), "wall_s": wall,
+           "callbacks_s": parts["callbacks"], "qp_s": parts["qp"], "bfgs_s": parts["bfgs"],
+           "driver_and_python_s": wall - sum(parts.values()),
+           "restarts": text.count("---- iteration"), "major_iterations_of_last_restart": int(res.nit),
+           "qp_solves": int(sum(t["qp_solves"] for t in tm)),
+           "active_set_changes": int(sum(t["qp_iterations"] for t in tm)),
+           "recoveries": int(sum(t.get("recoveries", 0) for t in tm)), "cost": float(res.fun),
+           "what": "Problem.solve(obj, **options) from the problem's initial guess; wall_s is the whole call "
+                   "(tracing, module load and handle creation included)"}
+    if check:
+        from oracle import kkt
+        t0 = time.perf_counter()
+        k = kkt.residuals(prob, obj, res.x, prob._engine.m_eq)
+        k["checker"] = "oracle/kkt.py on oracle/np_path.py (NumPy restatement of the reference path), %.1f s of CPU" % (
+            time.perf_counter() - t0)
+        out["kkt"] = k
+        out["cost_by_the_oracle"] = k["cost"]
+    prob._engine.close()
+    return out
+
+
 def _sqp_result(res, wall, t, iterations):
     return {"core": "hip (include/ogsqp.h)", "major_iterations": int(res.nit - 1 if res.status == 9 else res.nit),
             "exit_mode": int(res.status), "wall_s": wall, "callbacks_s": t["callbacks"], "qp_s": t["qp"],
@@ -400,6 +449,8 @@ def main():
                     help="initialise RCCL and run the all-gather even with one rank (plumbing test)")
     ap.add_argument("--quick", action="store_true", help="only the timed region and the roofline (profiling runs)")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the forced rebuild of the workload's kernel module")
+    ap.add_argument("--no-solve", action="store_true",
+                    help="skip the solve leg (Problem.solve to exit mode 0 at C3 and C4 + the oracle's KKT check: ~45 s)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 from ONE process: og_comm_init + og_multi_fd_sweep_enqueue over the N devices (no launcher)")
     a = ap.parse_args()
@@ -734,6 +785,15 @@ def main():
         # subproblem needs minutes there and runs in tests/test_slsqp_core.py instead)
         result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations,
                                 a.sqp_reference_iterations if n <= 1600 else 0, check_first_qp=n <= 3000)
+    if world == 1 and rank == 0 and not a.quick and not a.no_solve and not a.nodes:
+        # wall-clock to SLSQP convergence (second half of the metric) with the oracle's KKT check of the optimum: the
+        # headline workload, and C4 (BASELINE.json's next configuration) beside it when the headline is C3
+        try:
+            result["solve"] = solve_leg(a.workload)
+            if a.workload == "polar_tsto":
+                result["solve"]["also"] = [solve_leg("low_thrust")]
+        except Exception as exc:                               # a failed leg must not lose the line
+            result["solve"] = {"error": repr(exc)}
     if collective:
         # every rank's replicas hold the whole matrix: compare rank 0's with every other rank's (checksums)
         sums = torch.stack([sh.replica.sum(dtype=torch.float64) for sh in sweeps]).to(pg_dev)

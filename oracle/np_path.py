@@ -18,7 +18,7 @@ reference), so parity is anchored on the reference's call site (``optimize.py:72
 no ``jac``) and pinned by golden vectors captured from the reference + SciPy in
 ``tests/golden/`` (``tools/make_golden.py``).  With NumPy doing the same operations in the
 same order as the reference, this restatement reproduces the goldens bit for bit on the same
-NumPy build (``tests/test_oracle_vs_golden.py``).
+NumPy build (``tests/test_oracle_and_codegen.py::test_numpy_oracle_reproduces_reference_bitwise``).
 
 It is also the "port" CPU baseline: the serial column loop is exactly how the reference
 spends its time.

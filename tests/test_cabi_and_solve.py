@@ -54,6 +54,32 @@ def oracle_engine():
     og.ENGINE_FACTORY = None
 
 
+def test_kkt_oracle_tells_an_optimum_from_a_start(oracle_engine, capsys):
+    """oracle/kkt.py (the checker of the converged solves on the GPU box, tests/test_gpu_solve.py and bench.py's solve
+    leg) on the two configurations SciPy's own core finishes here: at the optimum SciPy returns every residual is
+    small (the reference's ftol of 1e-6 leaves 1e-4 of stationarity at C1; C2 with ftol 1e-8: 1.3e-4, with 1e-10: 5e-6), at the initial guess the
+    same function reports an infeasible, non-stationary point; a degenerate active set (C2's singular arc: 42 rows at
+    zero, 6 of them priced negative by a plain least-squares fit) is handled by releasing those rows."""
+    from oracle import kkt, np_path
+    for name, opts, bound in (("brachistochrone", {}, 2e-4), ("goddard", {"ftol": 1e-8}, 5e-4)):
+        prob, obj = problems.build(name)
+        prob.solve(obj, sqp_core="scipy", **opts)
+        capsys.readouterr()
+        assert prob.last_result.status == 0
+        k = kkt.residuals(prob, obj, prob.last_result.x, prob._engine.m_eq)
+        assert k["kkt"] <= bound and k["feasibility"] <= 1e-8 and k["dual"] == 0.0, k
+        assert abs(k["cost"] - prob.last_result.fun) <= 1e-12
+        fresh, obj2 = problems.build(name)
+        lb, ub = np_path.bounds_arrays(fresh)
+        k0 = kkt.residuals(fresh, obj2, np.clip(fresh.p, lb, ub), prob._engine.m_eq)
+        assert k0["kkt"] >= 0.5 and k0["feasibility"] >= 0.5
+        # a point that is feasible but not optimal: the optimum with its final time stretched is caught by stationarity
+        # or feasibility, never passed
+        x = prob.last_result.x.copy()
+        x[-1] *= 1.05
+        assert kkt.residuals(prob, obj, x, prob._engine.m_eq)["kkt"] >= 1e-3
+
+
 def test_solve_host_logic_brachistochrone(oracle_engine, capsys):
     """Restart loop, jac= plumbing, caching and quirk Q13 with the oracle engine injected:
     converges to the known answer tf = sqrt(pi) (reference: 1.77245410898455)."""

@@ -678,6 +678,35 @@ def test_lgl_kernel_matches_host_bitwise():
         assert np.array_equal(d_D.cpu().numpy(), D)
 
 
+@pytest.mark.parametrize("n", (3, 4, 5, 10, 20, 25, 30, 40, 50, 80, 100, 128, 200))
+def test_lgl_kernel_against_the_reference_golden(n):
+    """The DEVICE LGL kernels (``og_lgl_dev``: what builds D for every handle) beside the reference's own
+    ``_nodes_LGL`` / ``_weight_LGL`` / ``_differentiation_matrix_LGL`` (``optimize.py:183-213``) as captured in
+    tests/golden/lgl.npz, with north_star's tolerances: index order identical, tau within 1e-15, w and D within 1e-12
+    relative, the same structural zeros (VERDICT r4 #8a: the golden comparison used to live in the CPU suite only)."""
+    import ctypes as C
+    import os
+    import torch
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lgl.npz"))
+    lib = _native.lib()
+    dev = torch.device("cuda", 0)
+    d_tau = torch.empty(n, dtype=torch.float64, device=dev)
+    d_w = torch.empty(n, dtype=torch.float64, device=dev)
+    d_D = torch.empty((n, n), dtype=torch.float64, device=dev)
+    _native.check(lib.og_lgl_dev(n, C.c_void_p(d_tau.data_ptr()), C.c_void_p(d_w.data_ptr()),
+                                 C.c_void_p(d_D.data_ptr()), None), "og_lgl_dev")
+    tau, w, D = d_tau.cpu().numpy(), d_w.cpu().numpy(), d_D.cpu().numpy()
+    rt, rw, rD = G["tau_%d" % n], G["w_%d" % n], G["D_%d" % n]
+    assert np.all(np.diff(tau) > 0) and tau[0] == -1.0 and tau[-1] == 1.0
+    assert np.max(np.abs(tau - rt)) <= 1e-15
+    assert np.array_equal(tau, -tau[::-1])
+    assert np.max(np.abs(w / rw - 1.0)) <= 1e-12
+    nz = rD != 0
+    assert np.array_equal(D == 0, ~nz)
+    assert np.max(np.abs(D[nz] / rD[nz] - 1.0)) <= 1e-12
+    assert D[0, 0] == -n * (n - 1) * 0.25 and D[-1, -1] == n * (n - 1) * 0.25
+
+
 def test_hardware_probe():
     """MFMA f64 = k-ordered fma chain; f64 div/sqrt/og_math bit-identical host vs device."""
     import os

@@ -21,7 +21,6 @@
 //
 // Reductions run in a fixed order: results are bit-reproducible from run to run.
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -2393,7 +2392,7 @@ struct og_qp_s {
     double* V16b = nullptr;            // ... of the panel the look-ahead factors during the trailing update
     Lq16Panel* panel16b = nullptr;
     // rows longer than one workgroup's registers (n + 1 > 2048): column-split panels, 64-reflector blocks, GEMMs (ogsqp_lqwide.h)
-    bool lq_wide = false;              // (on from og_qp_create when n + 1 > LQW_SLAB and rocBLAS loads; OGSQP_LQ=8 / 16 turn it off)
+    bool lq_wide = false;              // (on from og_qp_create when n + 1 > LQW_SLAB; OGSQP_LQ=8 / 16 and OGSQP_WIDE=0 turn it off)
     double* Vall = nullptr;            // reflector vectors of the whole sweep, row k = reflector k (zero left of its panel)
     Lq16Panel* panelw = nullptr;       // T of the panel being applied inside a block
     LqWideMail* wide_mail = nullptr;
@@ -2402,12 +2401,10 @@ struct og_qp_s {
     double* wy_part = nullptr;         // column slices of a product (k_wy_w with blockIdx.y > 0), summed by k_wy_sum
     size_t wy_part_cap = 0;
     double *wy_w = nullptr, *wy_m = nullptr, *wy_t = nullptr, *wy_small = nullptr;   // 2 x (rows x 64) coefficients, M, T = M^-1 (one per block of a sweep), 2 x (64 x 16)
-    void* blas = nullptr;              // rocblas_handle
     // The block reflectors are applied to the rest of C Z and to Z on two streams of their own while the caller's stream
     // goes on with the next block's panels (OGSQP_WIDE_AHEAD=0: everything on the caller's stream, one after the other)
     struct WyLane {
         hipStream_t s = nullptr;       // lane 0: the stream of the call
-        void* blas = nullptr;
         double *w = nullptr, *part = nullptr;
     } lane[3];
     bool wide_ahead = false;
@@ -2484,48 +2481,6 @@ size_t rows_lds_bytes(int nr, int qcap) {          // k_rows_decide: the incomin
 }  // namespace
 
 namespace {
-// ---- rocBLAS for the plain GEMMs of the wide sweep (resolved at run time: the copy already in the process, e.g.
-// torch's, is reused; the prototypes are rocblas.h's)
-struct blas_api {
-    void* lib = nullptr;
-    int (*create)(void**) = nullptr;
-    int (*destroy)(void*) = nullptr;
-    int (*set_stream)(void*, hipStream_t) = nullptr;
-    int (*set_atomics)(void*, int) = nullptr;
-    int (*dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*,
-                 double*, int) = nullptr;
-} g_blas;
-constexpr int BLAS_N = 111, BLAS_T = 112;              // rocblas_operation_none / _transpose
-
-bool load_blas() {
-    if (g_blas.dgemm) return true;
-    const char* names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so.5", "/opt/rocm/lib/librocblas.so"};
-    for (const char* nm : names) {
-        void* lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) continue;
-        void* sym = dlsym(lib, "rocblas_dgemm");
-        if (!sym) continue;
-        g_blas.lib = lib;
-        g_blas.dgemm = (decltype(g_blas.dgemm))sym;
-        g_blas.create = (decltype(g_blas.create))dlsym(lib, "rocblas_create_handle");
-        g_blas.destroy = (decltype(g_blas.destroy))dlsym(lib, "rocblas_destroy_handle");
-        g_blas.set_stream = (decltype(g_blas.set_stream))dlsym(lib, "rocblas_set_stream");
-        g_blas.set_atomics = (decltype(g_blas.set_atomics))dlsym(lib, "rocblas_set_atomics_mode");
-        if (g_blas.create && g_blas.destroy && g_blas.set_stream) return true;
-        g_blas = blas_api();
-    }
-    return false;
-}
-
-// C (m x n, column-major, ldc) = alpha op(A) op(B) + beta C
-int blas_gemm(void* handle, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
-              int ldb, double beta, double* C, int ldc) {
-    if (m <= 0 || n <= 0) return 0;
-    const int rc = g_blas.dgemm(handle, ta, tb, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc);
-    if (rc != 0) return fail(8, "og_qp_solve_dev: rocblas_dgemm failed (status " + std::to_string(rc) + ")");
-    return 0;
-}
-
 // W (rows x 64) = A V' by k_wy_w; few rows are split over the chip by columns (partials in wy_part, summed in order)
 void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const double* V, int ldv, int nb, double* W,
                  int* nsplit_out, hipStream_t s, double* part = nullptr) {
@@ -2550,28 +2505,48 @@ void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const do
     }
 }
 
+// A <- A - C V with the coefficients C = W T (T != nullptr: 64 reflectors, W from launch_wy_w) or C = W (16 reflectors,
+// coefficients ready): k_wy_update, the rows in tiles of 64, the columns in as many slices as fill the chip
+void launch_wy_update(double* A, int ld, int rows, int L, const double* V, int ldv, int nb, const double* W, int ldc,
+                      const double* T, hipStream_t s) {
+    if (rows <= 0 || L <= 0) return;
+    const int tiles = (rows + 16 * WYU_WAVES - 1) / (16 * WYU_WAVES), nblk = (L + 15) / 16;
+    int nsplit = std::max(1, std::min(2048 / tiles, nblk / 4));
+    const int kb_per = (nblk + nsplit - 1) / nsplit;
+    nsplit = (nblk + kb_per - 1) / kb_per;
+    if (T)
+        hipLaunchKernelGGL((k_wy_update<LQW_BLOCK / 16, true>), dim3(tiles, nsplit), dim3(64 * WYU_WAVES), 0, s, A, ld, rows, L,
+                           V, ldv, nb, W, ldc, T, kb_per);
+    else
+        hipLaunchKernelGGL((k_wy_update<1, false>), dim3(tiles, nsplit), dim3(64 * WYU_WAVES), 0, s, A, ld, rows, L, V, ldv,
+                           nb, W, ldc, T, kb_per);
+}
+
 // rows <- rows - ((rows V') M^-1) V for `rows` rows of length L starting at A (leading dimension ld), V: nb reflectors
-// (row-major, leading dimension ldv) over the same L columns, M from k_wy_make_m.  Row-major X (r x c, ld) is the
-// column-major c x r matrix with the same ld: all three products are plain GEMMs on those views.
-int wy_apply_block(og_qp_s* qp, const og_qp_s::WyLane& ln, double* A, int ld, int rows, int L, const double* V, int ldv,
-                   int nb, const double* T) {
-    if (rows <= 0) return 0;
-    double* W = ln.w;                                             // rows x LQW_BLOCK (as column-major: LQW_BLOCK x rows)
-    double* W2 = ln.w + (size_t)rows * LQW_BLOCK;
+// (row-major, leading dimension ldv) over the same L columns, T = M^-1 from k_wy_make_m / k_wy_invert: two passes over
+// the rows, both hand-written for the FP64 matrix cores (k_wy_w, k_wy_update)
+void wy_apply_block(og_qp_s* qp, const og_qp_s::WyLane& ln, double* A, int ld, int rows, int L, const double* V, int ldv,
+                    int nb, const double* T) {
+    if (rows <= 0) return;
+    double* W = ln.w;                                             // rows x LQW_BLOCK
     launch_wy_w(qp, A, ld, rows, L, V, ldv, nb, W, nullptr, ln.s, ln.part);                                    // W = A V'
-    // W2 = W T (T = M^-1, row-major, upper triangular): as column-major, W2' = T' W' with T' = the array read column-major
-    OG_TRY(blas_gemm(ln.blas, BLAS_N, BLAS_N, nb, rows, nb, 1.0, T, LQW_BLOCK, W, LQW_BLOCK, 0.0, W2, LQW_BLOCK));
-    return blas_gemm(ln.blas, BLAS_N, BLAS_N, L, rows, nb, -1.0, V, ldv, W2, LQW_BLOCK, 1.0, A, ld);          // A' -= V' W2'
+    launch_wy_update(A, ld, rows, L, V, ldv, nb, W, LQW_BLOCK, T, ln.s);                                      // A -= (W T) V
 }
 
 // The sweep over rows longer than LQW_SLAB entries, from reflector k on, in blocks of LQW_BLOCK reflectors: returns the
 // first reflector it did not handle (rows short enough for the look-ahead kernels, or msweep).
 int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s, int* done) {
     og_qp_s::WyLane& l0 = qp->lane[0];
-    l0.s = s, l0.blas = qp->blas, l0.w = qp->wy_w, l0.part = qp->wy_part;
-    if (g_blas.set_stream(qp->blas, s) != 0) return fail(8, "og_qp_solve_dev: rocblas_set_stream failed");
+    l0.s = s, l0.w = qp->wy_w, l0.part = qp->wy_part;
     const bool ahead = qp->wide_ahead;
     int rc = 0, b = 0;
+    // (a failing runtime call ends the loop through rc instead of returning: the exit below joins the lanes first)
+#define WIDE_HIP(expr)                                                                                   \
+    do {                                                                                                 \
+        const hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess && !rc)                                                                     \
+            rc = fail(5, std::string("og_qp_solve_dev: ") + #expr + " failed: " + hipGetErrorString(e_)); \
+    } while (0)
     while (!rc && k < msweep && nq - k > LQW_SLAB) {
         const int k0 = k, nbk = std::min(LQW_BLOCK, msweep - k0), L0 = nq - k0;
         for (int sub = 0; sub < nbk && !rc; sub += LQ16) {
@@ -2591,7 +2566,7 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
                 launch_wy_w(qp, A, ldw, rest, len, V, ldw, LQ16, qp->wy_part, &nsplit, s);
                 hipLaunchKernelGGL(k_wy_small_finish, dim3(1), dim3(1024), 0, s, (const double*)qp->wy_part, nsplit, rest,
                                    (const Lq16Panel*)qp->panelw, W2);
-                rc = blas_gemm(qp->blas, BLAS_N, BLAS_N, len, rest, LQ16, -1.0, V, ldw, W2, LQ16, 1.0, A, ldw);
+                launch_wy_update(A, ldw, rest, len, V, ldw, LQ16, W2, LQ16, nullptr, s);
             }
         }
         if (rc) break;
@@ -2609,9 +2584,9 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
             // (in the same two pieces as below: the column slices of a product - hence its rounding - depend on the
             // number of rows, and the two orders of execution are to give the same bits)
             const int nxt = std::min(LQW_BLOCK, rows_rest);
-            rc = wy_apply_block(qp, l0, Arest, ldw, nxt, L0, Vb, ldw, nbk, T);
-            if (!rc) rc = wy_apply_block(qp, l0, Arest + (size_t)nxt * ldw, ldw, rows_rest - nxt, L0, Vb, ldw, nbk, T);
-            if (!rc) rc = wy_apply_block(qp, l0, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, T);
+            wy_apply_block(qp, l0, Arest, ldw, nxt, L0, Vb, ldw, nbk, T);
+            wy_apply_block(qp, l0, Arest + (size_t)nxt * ldw, ldw, rows_rest - nxt, L0, Vb, ldw, nbk, T);
+            wy_apply_block(qp, l0, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, T);
         } else {
             // Only the next block's rows are needed before its panels can start: they are done here, on this stream; the
             // other rows of C Z (lane 1) and Z (lane 2) get the block on their own streams - the panels are one
@@ -2619,24 +2594,30 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
             // what the other leaves idle.  Same arithmetic on disjoint rows: the results do not depend on the overlap.
             const og_qp_s::WyLane &l1 = qp->lane[1], &l2 = qp->lane[2];
             const int nxt = std::min(LQW_BLOCK, rows_rest);
-            OG_HIP(hipEventRecord(qp->ev_t[b], s));
-            if (b > 0) OG_HIP(hipStreamWaitEvent(s, qp->ev_tc[b - 1], 0));   // (lane 1 had these rows for block b - 1)
-            rc = wy_apply_block(qp, l0, Arest, ldw, nxt, L0, Vb, ldw, nbk, T);
-            OG_HIP(hipStreamWaitEvent(l1.s, qp->ev_t[b], 0));
-            if (!rc) rc = wy_apply_block(qp, l1, Arest + (size_t)nxt * ldw, ldw, rows_rest - nxt, L0, Vb, ldw, nbk, T);
-            OG_HIP(hipEventRecord(qp->ev_tc[b], l1.s));
-            OG_HIP(hipStreamWaitEvent(l2.s, qp->ev_t[b], 0));
-            if (!rc) rc = wy_apply_block(qp, l2, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, T);
+            WIDE_HIP(hipEventRecord(qp->ev_t[b], s));
+            if (b > 0) WIDE_HIP(hipStreamWaitEvent(s, qp->ev_tc[b - 1], 0));   // (lane 1 had these rows for block b - 1)
+            wy_apply_block(qp, l0, Arest, ldw, nxt, L0, Vb, ldw, nbk, T);
+            WIDE_HIP(hipStreamWaitEvent(l1.s, qp->ev_t[b], 0));
+            wy_apply_block(qp, l1, Arest + (size_t)nxt * ldw, ldw, rows_rest - nxt, L0, Vb, ldw, nbk, T);
+            WIDE_HIP(hipEventRecord(qp->ev_tc[b], l1.s));
+            WIDE_HIP(hipStreamWaitEvent(l2.s, qp->ev_t[b], 0));
+            wy_apply_block(qp, l2, qp->Jw + k0, ldw, nq, L0, Vb, ldw, nbk, T);
         }
         k = k0 + nbk;
         ++b;
     }
-    if (ahead && b > 0) {                                         // the caller's stream goes on when both lanes are through
-        for (int l = 0; l < 2; ++l) {
-            OG_HIP(hipEventRecord(qp->ev_join[l], qp->lane[1 + l].s));
-            OG_HIP(hipStreamWaitEvent(s, qp->ev_join[l], 0));
+    if (ahead && b > 0 && !rc) {                                  // the caller's stream goes on when both lanes are through
+        for (int l = 0; l < 2 && !rc; ++l) {
+            WIDE_HIP(hipEventRecord(qp->ev_join[l], qp->lane[1 + l].s));
+            WIDE_HIP(hipStreamWaitEvent(s, qp->ev_join[l], 0));
         }
     }
+    if (rc && ahead) {
+        // an error on the way out: what is already queued on the lanes must not go on writing C Z and Z under
+        // the caller's feet - or under the next attempt's: both lanes are drained before the error is handed up
+        for (int l = 1; l < 3; ++l) (void)hipStreamSynchronize(qp->lane[l].s);
+    }
+#undef WIDE_HIP
     *done = k;
     return rc;
 }
@@ -2784,11 +2765,11 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         qp->lq_ahead = !(lq && std::string(lq) == "16");
         const char* tr = getenv("OGSQP_TRSV");
         qp->trsv_mode = (tr && std::string(tr) == "block") ? 1 : (tr && std::string(tr) == "single") ? 2 : 0;
-        // rows longer than one workgroup holds: the wide sweep (ogsqp_lqwide.h) when the default kernels are selected and
-        // rocBLAS is there for its GEMMs (otherwise round 2's 8-reflector kernels serve those rows, as before)
+        // rows longer than one workgroup holds: the wide sweep (ogsqp_lqwide.h) when the default kernels are selected
+        // (OGSQP_WIDE=0: round 2's 8-reflector kernels serve those rows, as before round 4)
         const char* wide = getenv("OGSQP_WIDE");
         if (qp->lq16 && qp->lq_ahead && n1 > (size_t)LQW_SLAB && n1 <= (size_t)LQW_SLAB * LQW_MAX &&
-            !(wide && std::string(wide) == "0") && load_blas()) {
+            !(wide && std::string(wide) == "0")) {
             const size_t vrows = ((size_t)qp->meq + qc + LQW_BLOCK - 1) / LQW_BLOCK * LQW_BLOCK + LQW_BLOCK;
             A(&qp->Vall, vrows * ldw); A(&qp->panelw, 1); A(&qp->wide_mail, 1); A(&qp->wide_count, 4);
             A(&qp->wy_w, 2 * (n1 + vrows) * LQW_BLOCK); A(&qp->wy_m, (size_t)LQW_BLOCK * LQW_BLOCK);
@@ -2804,8 +2785,6 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
                 hipLaunchKernelGGL(k_lq_wide_arm, dim3((cells + 255) / 256), dim3(256), 0, 0, qp->wide_mail);
                 if (hipDeviceSynchronize() != hipSuccess) rc = fail(5, "og_qp_create: arming the panel mailbox failed");
             }
-            if (!rc && g_blas.create(&qp->blas) != 0) rc = fail(8, "og_qp_create: rocblas_create_handle failed");
-            if (!rc && g_blas.set_atomics) g_blas.set_atomics(qp->blas, 0);       // no atomics: results repeat bit for bit
             const char* wahead = getenv("OGSQP_WIDE_AHEAD");
             if (!rc && !(wahead && std::string(wahead) == "0")) {
                 for (int l = 1; l < 3 && !rc; ++l) {
@@ -2814,9 +2793,6 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
                     A(&ln.part, qp->wy_part_cap);
                     if (!rc && hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) != hipSuccess)
                         rc = fail(5, "og_qp_create: hipStreamCreate failed");
-                    if (!rc && g_blas.create(&ln.blas) != 0) rc = fail(8, "og_qp_create: rocblas_create_handle failed");
-                    if (!rc && g_blas.set_atomics) g_blas.set_atomics(ln.blas, 0);
-                    if (!rc && g_blas.set_stream(ln.blas, ln.s) != 0) rc = fail(8, "og_qp_create: rocblas_set_stream failed");
                     if (!rc && hipEventCreateWithFlags(&qp->ev_join[l - 1], hipEventDisableTiming) != hipSuccess)
                         rc = fail(5, "og_qp_create: hipEventCreate failed");
                 }
@@ -2847,9 +2823,7 @@ void og_qp_destroy(og_qp_handle qp) {
     if (!qp) return;
     (void)hipSetDevice(qp->device);
     for (void* p : qp->owned) (void)hipFree(p);
-    if (qp->blas && g_blas.destroy) (void)g_blas.destroy(qp->blas);
     for (int l = 1; l < 3; ++l) {
-        if (qp->lane[l].blas && g_blas.destroy) (void)g_blas.destroy(qp->lane[l].blas);
         if (qp->lane[l].s) (void)hipStreamDestroy(qp->lane[l].s);
         if (qp->ev_join[l - 1]) (void)hipEventDestroy(qp->ev_join[l - 1]);
     }
@@ -3231,8 +3205,18 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
                 break;
             }
             // every pair of launches is one change (or the end of the warm start): the device's own limit ends the loop
-            if (launched > (long)ga.limit + nwarm + 64)
+            if (launched > (long)ga.limit + nwarm + 64) {
+                // (a wait that gave up earlier in this attempt - sweep, chained solve - leaves garbage the active-set
+                // kernels cannot make progress on: that is a lost attempt, to be re-run with the forms that wait for
+                // nothing, not an internal error)
+                OG_HIP(hipMemcpyAsync(hflag, qp->flag, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+                OG_HIP(hipStreamSynchronize(s));
+                if (hflag[2] || hflag[3]) {
+                    *lost = 1;
+                    return 0;
+                }
                 return fail(8, "og_qp_solve_dev: the active-set kernels made no progress (internal error)");
+            }
             if (batch < 128) batch *= 2;
         }
 #undef OG_ROWS_APPLY
@@ -3317,7 +3301,14 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
                         hst.iters ? (double)hst.tr[e] / hst.iters : 0.0);
         }
 #endif
-        if (habort) return fail(7, "og_qp_solve_dev: the cooperative active-set kernel lost a workgroup at a barrier");
+        if (habort) {
+            OG_HIP(hipMemcpy(hflag, qp->flag, 4 * sizeof(int), hipMemcpyDeviceToHost));
+            if (hflag[2] || hflag[3]) {              // (as above: the input of the loop came from a lost wait)
+                *lost = 1;
+                return 0;
+            }
+            return fail(7, "og_qp_solve_dev: the cooperative active-set kernel lost a workgroup at a barrier");
+        }
     } else if (rows_mode && nr > 0) {
         // done above
     } else if (nr > 0) {

@@ -1,6 +1,7 @@
 // ogsqp_lqwide.h - the LQ sweep for rows LONGER than the 2048 entries one workgroup's registers hold (C5: n + 1 = 6149):
-// a 16-reflector panel kernel whose COLUMNS are split over several workgroups, and the block-reflector plumbing
-// (64 reflectors per block) that lets everything else of the sweep be plain library GEMMs.  Included by ogsqp.hip
+// a 16-reflector panel kernel whose COLUMNS are split over several workgroups, and the block-reflector kernels
+// (64 reflectors per block: k_wy_w, k_wy_make_m, k_wy_invert, k_wy_update) that stream the rest of the matrix twice per
+// 64 reflectors on the FP64 matrix cores.  Included by ogsqp.hip
 // inside its anonymous namespace, after ogsqp_lq16.h; DESIGN.md section 9.
 //
 // Until round 4 such rows went through round 2's 8-reflector kernels until the sweep had shortened them: one
@@ -17,10 +18,11 @@
 //                       updates its own slab.  16 exchanges per panel instead of 16 x 8 workgroup-wide reductions over
 //                       rows that do not fit.
 //   the rest            with V of a 64-row block (four panels) and M = T^-1 = diag(1 / beta) + striu(V V')
-//                       (k_wy_make_m), the update of every other row is  A <- A - ((A V') M^-1) V: two GEMMs
-//                       (rocBLAS, plain library GEMMs) around a per-row triangular solve with M (k_wy_solve) - for
-//                       the rows of the block's later panels (16 reflectors at a time, T of the panel kernel), for the
-//                       rest of C Z and for Z.  The matrix is streamed once per 64 reflectors instead of once per 8.
+//                       (k_wy_make_m, inverted by k_wy_invert), the update of every other row is
+//                       A <- A - ((A V') M^-1) V: W = A V' by k_wy_w, then k_wy_update (coefficients W M^-1 and the
+//                       rank-64 update in one pass over A; round 5 - rocBLAS dgemm before) - for the rows of the
+//                       block's later panels (16 reflectors at a time, T of the panel kernel), for the rest of C Z and
+//                       for Z.  The matrix is read twice and written once per 64 reflectors instead of once per 8.
 //
 // A wait that gives up raises flag[2] like the look-ahead's: the subproblem is then solved again by the old kernels.
 
@@ -389,6 +391,119 @@ __global__ __launch_bounds__(64 * WYW_WAVES) void k_wy_w(const double* __restric
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int i = 0; i < 4; ++i) out[16 * q + 4 * i + g] = acc[q][i];
+    }
+}
+
+// A <- A - (W T) V  (HAS_T: the block reflector, W = A V' from k_wy_w, T = M^-1 from k_wy_invert, 64 reflectors)  or
+// A <- A - W2 V      (the 16 reflectors of one panel on the later rows of its block, W2 from k_wy_small_finish)
+// for `rows` rows of length L at A - hand-written for the FP64 matrix cores (round 5; rounds 3-4 posed both products as
+// library GEMMs and resolved rocblas_dgemm at run time).  A workgroup = 4 wavefronts x 16 rows walks its slice of the
+// columns (blockIdx.y, kb_per blocks of 16) once: everything is in the transposed form of k_lq_apply16 -
+//   coefficients  Z' = T' W'   A operand T[4 s + g][16 q + n], B operand W[row n][4 s + g]; the accumulator (register i
+//                              of lane (n, g) = reflector 16 q + 4 i + g, row n) IS the B operand of the update
+//   update        X' -= V' Z'  per 16-column block: A operand V[16 q + 4 i + g][16 b + pm(n)] out of the block's tile
+//                              of V in LDS (64 x 16, double-buffered, one barrier per block; pm(m) = 4 (m & 3) + (m >> 2)
+//                              permutes the columns so that register i of lane (n, g) is column 16 b + 4 g + i of row n -
+//                              the 32 bytes the lane loaded and stores), 16 v_mfma_f64_16x16x4 per wavefront and block
+// - so A is read once and written once per block reflector (2 KB in, 2 KB out per 16 MFMAs: the matrix cores are half
+// busy at the HBM rate), V comes from the L2 once per 64 rows.  Every row's result depends on its own data only: the
+// bits do not depend on the grid, the slices or the stream the launch runs on.
+constexpr int WYU_WAVES = 4;
+template <int NBQ, bool HAS_T>
+__global__ __launch_bounds__(64 * WYU_WAVES) void k_wy_update(double* __restrict__ A, int ld, int rows, int L,
+                                                             const double* __restrict__ V, int ldv, int nb,
+                                                             const double* __restrict__ W, int ldc,
+                                                             const double* __restrict__ T, int kb_per) {
+    constexpr int NBV = 16 * NBQ;
+    __shared__ __attribute__((aligned(32))) double s_v[2][NBV][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int r = (int)blockIdx.x * 16 * WYU_WAVES + 16 * wv + n;
+    const bool valid = r < rows;
+    const int rc = min(r, rows - 1);
+    double* row = A + (long)rc * ld;
+    const int nblk_all = (L + 15) / 16;
+    const int b_lo = (int)blockIdx.y * kb_per, b_hi = min(nblk_all, b_lo + kb_per);
+    if (b_lo >= b_hi) return;                                   // (uniform over the workgroup)
+    // ---- coefficients
+    d4 z[NBQ];
+    const double* crow = W + (long)rc * ldc;
+    if (HAS_T) {
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) z[q] = d4{0.0, 0.0, 0.0, 0.0};
+        double wk[4 * NBQ];
+#pragma unroll
+        for (int st = 0; st < 4 * NBQ; ++st) wk[st] = 4 * st + g < nb ? crow[4 * st + g] : 0.0;
+#pragma unroll
+        for (int st = 0; st < 4 * NBQ; ++st) {
+            const double* trow = T + (long)(4 * st + g) * LQW_BLOCK + n;
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q)
+                if (16 * q + 15 >= 4 * st)                      // (T is upper triangular: blocks left of the diagonal are zero)
+                    z[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(trow[16 * q], wk[st], z[q], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[q][i] = 16 * q + 4 * i + g < nb ? crow[16 * q + 4 * i + g] : 0.0;
+    }
+    // ---- the walk over my slice of the columns
+    const int pm = 4 * (n & 3) + (n >> 2);
+    const int vr = tid >> 2, vc = 4 * (tid & 3);               // my dbl4 of the V tile (NBV * 4 of them, one per thread at most)
+    const bool loads_v = tid < NBV * 4;
+    const double* vsrc = V + (long)min(vr, NBV - 1) * ldv + vc;
+    const bool v_on = loads_v && vr < nb;
+    auto load_v = [&](int b) {
+        dbl4 a = {0.0, 0.0, 0.0, 0.0};
+        if (v_on) {
+            a = *(const dbl4*)(vsrc + 16 * b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (16 * b + vc + i >= L) a[i] = 0.0;
+        }
+        return a;
+    };
+    auto load_x = [&](int b) { return *(const dbl4*)(row + min(16 * b + 4 * g, 4 * ((L - 1) / 4))); };
+    dbl4 x = load_x(b_lo);
+    {
+        const dbl4 a = load_v(b_lo);
+        if (loads_v) *(dbl4*)&s_v[b_lo & 1][vr][vc] = a;
+    }
+    __syncthreads();
+    for (int b = b_lo; b < b_hi; ++b) {
+        dbl4 xn = x, an = {0.0, 0.0, 0.0, 0.0};
+        if (b + 1 < b_hi) {
+            an = load_v(b + 1);
+            xn = load_x(b + 1);
+        }
+        const double (*vt)[16] = s_v[b & 1];
+        d4 o0 = d4{0.0, 0.0, 0.0, 0.0}, o1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) {
+            double a4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = vt[16 * q + 4 * i + g][pm];
+            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], z[q][0], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], z[q][1], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], z[q][2], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], z[q][3], o1, 0, 0, 0);
+        }
+        const int j0 = 16 * b + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] -= o0[i] + o1[i];
+        if (valid) {
+            if (j0 + 3 < L) {
+                *(dbl4*)(row + j0) = x;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j0 + i < L) row[j0 + i] = x[i];
+            }
+        }
+        if (b + 1 < b_hi && loads_v) *(dbl4*)&s_v[(b + 1) & 1][vr][vc] = an;
+        x = xn;
+        __syncthreads();
     }
 }
 

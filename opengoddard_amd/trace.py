@@ -19,6 +19,7 @@ Anything else raises :class:`TraceError` - there is no silent CPU fallback.
 from __future__ import annotations
 
 import numbers
+import threading
 
 import numpy as np
 
@@ -137,6 +138,52 @@ def const_value(node):
     return float(np.frombuffer(node[1], dtype=np.float64)[0])
 
 
+_FOLD_UN = {"neg": np.negative, "sqrt": np.sqrt, "exp": np.exp, "log": np.log, "sin": np.sin, "cos": np.cos,
+            "tan": np.tan, "abs": np.absolute, "atan": np.arctan, "asin": np.arcsin, "acos": np.arccos,
+            "tanh": np.tanh, "sinh": np.sinh, "cosh": np.cosh, "expm1": np.expm1, "log1p": np.log1p,
+            "log2": np.log2, "log10": np.log10, "cbrt": np.cbrt}
+_FOLD_BIN = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.true_divide, "max": np.maximum,
+             "min": np.minimum, "atan2": np.arctan2, "hypot": np.hypot, "mod": np.remainder}
+_FOLD_CMP = {"lt": np.less, "le": np.less_equal, "gt": np.greater, "ge": np.greater_equal, "eq": np.equal,
+             "ne": np.not_equal}
+
+
+def concrete_value(g, nid, _memo=None):
+    """The NumPy value of node ``nid`` when it does not depend on the decision vector (built from constants by
+    slicing, indexing, concatenation and elementwise operations only), else None.  A callback may keep plain numbers in
+    a buffer it got from ``np.zeros`` - a lookup table, a flag - and then ask for ``float(buf[i])``, ``if buf[0] > 0``,
+    ``buf.astype(int)`` or hand it to a NumPy routine: such a buffer is a traced CONSTANT, and these requests have a
+    concrete answer (they used to trace, when ``np.zeros`` still returned an ndarray)."""
+    memo = {} if _memo is None else _memo
+    if nid in memo:
+        return memo[nid]
+    node = g.nodes[nid]
+    kind = node[0]
+    out = None
+    with np.errstate(all="ignore"):
+        if kind == "const":
+            out = np.float64(const_value(node))
+        elif kind == "cvec":
+            out = g.cvecs[node[1]]
+        elif kind == "slice":
+            v = concrete_value(g, node[1], memo)
+            out = None if v is None else v[node[2]:node[2] + node[3]]
+        elif kind == "idx":
+            v = concrete_value(g, node[1], memo)
+            out = None if v is None else v[node[2]]
+        elif kind == "cat":
+            parts = [concrete_value(g, c, memo) for c in node[1]]
+            out = None if any(v is None for v in parts) else np.concatenate([np.atleast_1d(v) for v in parts])
+        elif kind == "un" and node[1] in _FOLD_UN:
+            v = concrete_value(g, node[2], memo)
+            out = None if v is None else _FOLD_UN[node[1]](v)
+        elif kind in ("bin", "cmp") and node[1] in (_FOLD_BIN if kind == "bin" else _FOLD_CMP):
+            a, b = concrete_value(g, node[2], memo), concrete_value(g, node[3], memo)
+            out = None if a is None or b is None else (_FOLD_BIN if kind == "bin" else _FOLD_CMP)[node[1]](a, b)
+    memo[nid] = out
+    return out
+
+
 _UNARY = {
     np.negative: "neg", np.sqrt: "sqrt", np.exp: "exp", np.log: "log", np.sin: "sin",
     np.cos: "cos", np.tan: "tan", np.absolute: "abs", np.fabs: "abs", np.square: "square",
@@ -247,17 +294,39 @@ class Sym:
         for i in range(len(self)):
             yield self[i]
 
+    def _concrete(self):
+        """NumPy value when this expression is a constant of the trace (see :func:`concrete_value`), else None."""
+        return concrete_value(self.g, self.id)
+
     def __bool__(self):
+        v = self._concrete()
+        if v is not None:
+            return bool(v)                               # (NumPy's own rule for arrays of more than one element)
         raise TraceError("Python control flow on a traced value (if/while/and/or on the decision "
                          "variables) cannot be turned into a GPU kernel")
 
     def __float__(self):
+        v = self._concrete()
+        if v is not None:
+            return float(v)
         raise TraceError("float() of a traced value: the callback needs a concrete number")
 
-    __int__ = __float__
-    __index__ = __float__
+    def __int__(self):
+        v = self._concrete()
+        if v is not None:
+            return int(v)
+        raise TraceError("int() of a traced value: the callback needs a concrete number")
+
+    def __index__(self):
+        v = self._concrete()
+        if v is not None and np.ndim(v) == 0 and float(v) == int(v):
+            return int(v)
+        raise TraceError("a traced value used as an index: the callback needs a concrete integer")
 
     def __array__(self, *a, **k):
+        v = self._concrete()
+        if v is not None:
+            return np.array(v, *a, **{key: val for key, val in k.items() if key == "dtype"})
         raise TraceError("a traced value was passed to a NumPy routine the tracer does not "
                          "understand (only elementwise ufuncs, hstack/concatenate/append, where)")
 
@@ -280,6 +349,9 @@ class Sym:
 
     def astype(self, dtype, **kw):
         if np.dtype(dtype) != np.float64:
+            v = self._concrete()
+            if v is not None:
+                return np.asarray(v).astype(dtype, **kw)       # a constant-only buffer: a plain array again
             raise TraceError("astype(%s) of a traced value: callbacks are traced in float64" % (dtype,))
         return self.copy()
 
@@ -663,6 +735,19 @@ def _axis_of(kwargs, args, pos):
 def _array_function(func, args, kwargs):
     """NumPy functions (``__array_function__`` protocol) on traced vectors and matrices."""
     name = getattr(func, "__name__", str(func))
+    # constants of the trace (buffers that only ever received plain numbers) go in as the arrays they are; a call whose
+    # traced arguments are ALL constants is NumPy's own call
+    def plain(v, depth=0):
+        if isinstance(v, Sym):
+            c = v._concrete()
+            return v if c is None else np.array(c)
+        if isinstance(v, (list, tuple)) and depth < 2 and any(isinstance(it, Sym) for it in v):
+            return type(v)(plain(it, depth + 1) for it in v)
+        return v
+    p_args = tuple(plain(v) for v in args)
+    p_kwargs = {k: plain(v) for k, v in kwargs.items()}
+    if not _has_traced(list(p_args)) and not _has_traced(list(p_kwargs.values())):
+        return func(*p_args, **p_kwargs)
     if func in (np.hstack, np.concatenate):
         axis = kwargs.get("axis", 0) if func is np.concatenate else 0
         items = list(args[0])
@@ -1419,6 +1504,15 @@ def _has_traced(obj, depth=0):
     return False
 
 
+# One trace at a time, and only the tracing thread sees the patched constructors: ``np.zeros`` & co. are replaced on the
+# numpy MODULE for the duration of a trace (there is no narrower hook for ``np.zeros(n)`` inside user code), so a second
+# thread that traces, or merely calls ``np.zeros`` from code outside the allow-list, must not be handed a traced buffer
+# of somebody else's graph.  ``_TRACE_LOCK`` serialises traces; ``_TRACING_THREAD`` is the one thread whose
+# calls are intercepted - every other thread gets NumPy's own function.
+_TRACE_LOCK = threading.RLock()
+_TRACING_THREAD = None
+
+
 class tracing_numpy:
     """While the callbacks are traced, the NumPy constructors a callback uses to make its OUTPUT buffer -
     ``np.zeros / ones / empty / full (n)`` and ``((r, n))`` - return traced constants, so that ``out[i] = expression``
@@ -1432,18 +1526,23 @@ class tracing_numpy:
         self.graph = graph
 
     def __enter__(self):
-        global _ACTIVE_GRAPH
-        self._saved_graph = _ACTIVE_GRAPH
+        global _ACTIVE_GRAPH, _TRACING_THREAD
+        _TRACE_LOCK.acquire()
+        self._saved_graph, self._saved_thread = _ACTIVE_GRAPH, _TRACING_THREAD
         _ACTIVE_GRAPH = self.graph
+        _TRACING_THREAD = threading.get_ident()
         self._orig = {name: getattr(np, name) for name in self.NAMES}
         orig = self._orig
+
+        def mine():
+            return _ACTIVE_GRAPH is not None and threading.get_ident() == _TRACING_THREAD
 
         def make_filled(name, fill_of):
             def ctor(shape, *args, **kwargs):
                 g = _ACTIVE_GRAPH
                 dtype = kwargs.get("dtype", args[1] if name == "full" and len(args) > 1 else
                                    (args[0] if name != "full" and args else None))
-                plain = (g is None or not _from_user_code() or set(kwargs) - {"dtype", "fill_value"}
+                plain = (g is None or not mine() or not _from_user_code() or set(kwargs) - {"dtype", "fill_value"}
                          or (dtype is not None and np.dtype(dtype) != np.float64))
                 fill = fill_of(args, kwargs)
                 if not plain and not isinstance(fill, Sym):
@@ -1459,20 +1558,22 @@ class tracing_numpy:
             return ctor
 
         def array(obj, *args, **kwargs):
-            if _ACTIVE_GRAPH is not None and _has_traced(obj):
+            if mine() and _has_traced(obj):
                 dtype = kwargs.get("dtype", args[0] if args else None)
                 if dtype is not None and np.dtype(dtype) != np.float64:
+                    if isinstance(obj, Sym) and obj._concrete() is not None:
+                        return orig["array"](obj._concrete(), *args, **kwargs)      # a constant-only buffer
                     raise TraceError("np.array(..., dtype=%s) of traced values: callbacks are traced in float64" % (dtype,))
                 return _array_of(obj, copy=kwargs.get("copy", True) is not False)
             return orig["array"](obj, *args, **kwargs)
 
         def asarray(obj, *args, **kwargs):
-            if _ACTIVE_GRAPH is not None and _has_traced(obj):
+            if mine() and _has_traced(obj):
                 return _array_of(obj, copy=False)
             return orig["asarray"](obj, *args, **kwargs)
 
         def asanyarray(obj, *args, **kwargs):
-            if _ACTIVE_GRAPH is not None and _has_traced(obj):
+            if mine() and _has_traced(obj):
                 return _array_of(obj, copy=False)
             return orig["asanyarray"](obj, *args, **kwargs)
 
@@ -1484,10 +1585,11 @@ class tracing_numpy:
         return self
 
     def __exit__(self, *exc):
-        global _ACTIVE_GRAPH
+        global _ACTIVE_GRAPH, _TRACING_THREAD
         for name, fn in self._orig.items():
             setattr(np, name, fn)
-        _ACTIVE_GRAPH = self._saved_graph
+        _ACTIVE_GRAPH, _TRACING_THREAD = self._saved_graph, self._saved_thread
+        _TRACE_LOCK.release()
         return False
 
 

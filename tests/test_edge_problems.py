@@ -323,7 +323,54 @@ def preallocated_outputs():
     return prob, Params()
 
 
-CASES = {"bryson_denham": bryson_denham, "ragged_two_phase": ragged_two_phase,
+def constant_scratch_buffers():
+    """Buffers from ``np.zeros`` / ``np.ones`` that only ever hold plain numbers - a lookup table, a flag vector, an
+    integer index list - next to traced ones: ``float(buf[i])``, ``if buf[0] > 0``, ``buf.astype(int)``,
+    a buffer handed to a NumPy routine and to ``np.array(..., dtype=int)`` all have concrete answers."""
+    def dynamics(prob, obj, section):
+        x = prob.states(0, section)
+        u = prob.controls(0, section)
+        gains = np.zeros(3)
+        gains[0], gains[1], gains[2] = 0.5, 1.5, 2.5
+        k = float(gains[1])                               # a concrete number out of a constant buffer
+        dx = Dynamics(prob, section)
+        dx[0] = k * u - x if gains[0] > 0 else u          # control flow on a constant
+        return dx()
+
+    def equality(prob, obj):
+        x = prob.states_all_section(0)
+        pick = np.ones(2)
+        pick[1] = 7.0
+        idx = pick.astype(int)                            # -> array([1, 7]) again a plain array
+        rows = Condition()
+        rows.equal(x[0], 0.25)
+        rows.equal(x[int(pick[1])] - x[idx[0]], 0.0)
+        return rows()
+
+    def inequality(prob, obj):
+        u = prob.controls_all_section(0)
+        table = np.zeros(4)
+        table[:] = [0.0, 1.0, 4.0, 9.0]
+        scale = np.interp(1.5, np.arange(4.0), table)     # a NumPy routine on a constant buffer: 2.5
+        steps = np.array(np.ones(3) * 2.0, dtype=int)     # dtype=int of a constant buffer
+        out = np.zeros(5)                                 # ... and a buffer that DOES receive traced values
+        out[0] = float(steps.sum())
+        out[1:] = scale - u[0:4] ** 2
+        rows = Condition()
+        rows.lower_bound(out, -1.0)
+        return rows()
+
+    prob = Problem([0.0, 1.0], [9], [1], [1], 3)
+    rng = np.random.default_rng(5)
+    prob.p[:-1] = rng.uniform(-1.0, 1.0, prob.number_of_variables - 1)
+    prob.dynamics = [dynamics]
+    prob.cost = lambda prob, obj: prob.time_final(-1)
+    prob.equality = equality
+    prob.inequality = inequality
+    return prob, Params()
+
+
+CASES = {"bryson_denham": bryson_denham, "constant_scratch_buffers": constant_scratch_buffers, "ragged_two_phase": ragged_two_phase,
          "smooth_knots": smooth_knots, "running_cost_shapes": running_cost_shapes,
          "wide_functions": wide_functions, "wide_reductions": wide_reductions,
          "preallocated_outputs": preallocated_outputs}
@@ -351,6 +398,45 @@ def test_trace_and_twin_match_numpy_oracle(name):
     scale = np.maximum(1.0, np.abs(F)) + 200.0
     bound = 1e-9 * np.abs(JTo) + 64 * np.finfo(float).eps * scale[None, :] / np.abs(h)[:, None]
     assert np.all(np.abs(JT - JTo) <= bound)
+
+
+def test_other_threads_keep_numpys_own_constructors_while_a_trace_runs():
+    """``np.zeros`` & co. are replaced on the numpy module while callbacks are traced; only the tracing thread sees the
+    replacement: another thread calling ``np.zeros(4)`` from its own code in the middle of a trace gets an
+    ndarray, never a traced buffer of somebody else's graph; and a second trace started meanwhile waits for the first."""
+    import threading
+    from opengoddard_amd import trace
+    inside, release = threading.Event(), threading.Event()
+    seen = {}
+    prob, obj = preallocated_outputs()
+    plain_inequality = prob.inequality
+
+    def blocking_inequality(p, o):
+        seen["tracer"] = type(np.zeros(3)).__name__           # this thread: a traced buffer
+        inside.set()
+        assert release.wait(30)
+        return plain_inequality(p, o)
+
+    prob.inequality = blocking_inequality
+    result = {}
+    t = threading.Thread(target=lambda: result.setdefault("P", codegen.trace_problem(prob, obj)))
+    t.start()
+    assert inside.wait(30)
+    try:
+        seen["other"] = np.zeros(4)
+        seen["other_array"] = np.asarray([1.0, 2.0])
+        second = threading.Thread(target=lambda: result.setdefault("Q", codegen.trace_problem(*bryson_denham(8))))
+        second.start()
+        second.join(0.5)
+        assert second.is_alive()                               # the second trace waits for the lock
+    finally:
+        release.set()
+    t.join(60)
+    second.join(60)
+    assert seen["tracer"] == "Sym"
+    assert type(seen["other"]) is np.ndarray and type(seen["other_array"]) is np.ndarray
+    assert result["P"].m > 0 and result["Q"].m > 0
+    assert np.zeros is trace.np.zeros and type(np.zeros(2)) is np.ndarray      # restored
 
 
 def test_bryson_denham_known_answer_with_oracle_engine(capsys):

@@ -579,12 +579,19 @@ def test_gpu_first_subproblem_of_the_baseline_configurations(name, monkeypatch):
     # the refinement has converged: its last sweeps move the step by far less than either solver's distance
     assert max(rinfo["step_moved"][-3:]) <= 1e-3 * min(dist["hip"], dist["restatement"]) + 1e-15, rinfo["step_moved"]
     assert rinfo["min_multiplier_of_inequalities"] is None or rinfo["min_multiplier_of_inequalities"] >= -1e-7
-    assert dist["hip"] <= 10.0 * max(dist["restatement"], 1e-12), dist
-    # the two solvers against each other: no further apart than their distances to the exact step allow, and the
-    # multipliers (one more solve with the same triangle) within 100 x that
+    # the HIP core may be at most twice as far from the exact step as the restatement with LAPACK's LQ (round 5: the
+    # wide sweep's T factor is refined and its slice sums compensated; round 4 tolerated 10 x at every size)
+    assert dist["hip"] <= 2.0 * max(dist["restatement"], 1e-12), dist
+    # the two solvers against each other: no further apart than their distances to the exact step allow
     print("          pairwise step %.3e, multipliers %.3e" % (pairwise, mult_err))
     assert pairwise <= 1.05 * (dist["hip"] + dist["restatement"]) + 1e-12
-    assert dist["hip"] <= 1e-4 and mult_err <= max(1e-4, 100.0 * (dist["hip"] + dist["restatement"]))
+    if name == "launch4":
+        # C5's first subproblem is the worst conditioned of the three (either solver 1e-5 .. 4e-5 from the exact step):
+        # absolute bounds from the referee's distances, multipliers (one more solve with the same triangle) within 100 x
+        assert dist["hip"] <= 1e-4 and mult_err <= max(1e-4, 100.0 * (dist["hip"] + dist["restatement"]))
+    else:
+        # C3 / C4: the absolute bounds of rounds 1-3 (a regression up to 1e-4 must not pass here)
+        assert pairwise <= 1e-6 and mult_err <= 1e-4
     # what does not depend on the conditioning: the step is feasible for the linearisation and a KKT point
     dd = d[:n]
     delta = d[n] if d.size > n else 0.0

@@ -169,6 +169,10 @@ int og_shard_plan(og_handle h, int32_t world, int32_t* block_cols, int64_t* bloc
 int og_shard_comm_unique_id(uint8_t* id128);
 int og_shard_comm_init(og_handle h, const uint8_t* id128, int32_t rank, int32_t world);
 void og_shard_comm_destroy(og_handle h);
+/* What RCCL reports about the handle's communicator: ncclCommCount, ncclCommUserRank, ncclCommCuDevice - so that a
+ * launcher (bench.py --gpus N) can print that the all-gather really spans N ranks on N devices.  (No reference
+ * counterpart: the reference has no multi-device path) */
+int og_shard_comm_info(og_handle h, int32_t* nranks, int32_t* rank, int32_t* device);
 int og_shard_all_gather_dev(og_handle h, const double* d_send, double* d_recv, void* hip_stream);
 int og_shard_pack_dev(og_handle h, int32_t rank, const double* d_JT_block, double* d_send, void* hip_stream);
 /* og_fd_sweep_dev of rank's block and og_shard_pack_dev in ONE launch: the sweep kernel stores every non-zero

@@ -57,6 +57,7 @@ SIGNATURES = {
     "og_shard_comm_unique_id": (C.c_int, [C.c_void_p]),
     "og_shard_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "og_shard_comm_destroy": (None, [C.c_void_p]),
+    "og_shard_comm_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_shard_all_gather_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "og_shard_sweep_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

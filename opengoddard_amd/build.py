@@ -30,6 +30,11 @@ HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off",
              "-Wno-unused-value"] + os.environ.get("OG_EXTRA_HIPFLAGS", "").split()
 
 
+# flags for the callback modules only (a stamped build of one workload's kernels - -DOGK_TRACE=1 - must not change the
+# digest of libogpsx.so / libogsqp.so and make every later process rebuild them)
+MODULE_FLAGS = os.environ.get("OG_MODULE_HIPFLAGS", "").split()
+
+
 class BuildError(RuntimeError):
     pass
 
@@ -112,7 +117,7 @@ def build_sqp(force=False):
 
 def module_digest(header_source):
     """Key of a callback module: generated header + kernel sources + flags."""
-    return _digest_files(_kernel_sources(), extra=header_source)
+    return _digest_files(_kernel_sources(), extra=header_source + " ".join(MODULE_FLAGS))
 
 
 def module_path(digest):
@@ -162,7 +167,7 @@ def build_module(header_source, digest=None, force=False, out_suffix="", parts=N
         target = wanted[index]
         tmp = target + ".tmp%d" % os.getpid()
         define = ["-DOGK_PART=%d" % MODULE_PARTS[index]] if split else []
-        _run([hipcc()] + HIP_FLAGS + define + ["-I" + CSRC, "-DOG_GEN_HEADER=\"%s\"" % header, kernels, "-o", tmp])
+        _run([hipcc()] + HIP_FLAGS + MODULE_FLAGS + define + ["-I" + CSRC, "-DOG_GEN_HEADER=\"%s\"" % header, kernels, "-o", tmp])
         return tmp, target
 
     if not split:

@@ -1103,6 +1103,25 @@ int og_shard_comm_init(og_handle p, const uint8_t* id128, int32_t rank, int32_t 
     return 0;
 }
 
+int og_shard_comm_info(og_handle p, int32_t* nranks, int32_t* rank, int32_t* device) {
+    if (!p) return fail(1, "og_shard_comm_info: null handle");
+    if (!p->shard_comm) return fail(1, "og_shard_comm_info: call og_shard_comm_init first");
+    // what RCCL itself says about the communicator (not what the launcher asked for)
+    typedef int (*query_fn)(ogn_comm, int*);
+    const query_fn count = (query_fn)dlsym(g_comm.api.lib, "ncclCommCount");
+    const query_fn user = (query_fn)dlsym(g_comm.api.lib, "ncclCommUserRank");
+    const query_fn dev = (query_fn)dlsym(g_comm.api.lib, "ncclCommCuDevice");
+    if (!count || !user || !dev) return fail(7, "og_shard_comm_info: ncclCommCount / UserRank / CuDevice not found");
+    int v[3] = {-1, -1, -1};
+    const int rc = count((ogn_comm)p->shard_comm, &v[0]) | user((ogn_comm)p->shard_comm, &v[1]) |
+                   dev((ogn_comm)p->shard_comm, &v[2]);
+    if (rc != 0) return fail(7, "og_shard_comm_info: an RCCL query failed");
+    if (nranks) *nranks = v[0];
+    if (rank) *rank = v[1];
+    if (device) *device = v[2];
+    return 0;
+}
+
 void og_shard_comm_destroy(og_handle p) {
     if (p && p->shard_comm && g_comm.api.CommDestroy) g_comm.api.CommDestroy((ogn_comm)p->shard_comm);
     if (p) p->shard_comm = nullptr;

@@ -2375,6 +2375,9 @@ struct og_qp_s {
     unsigned* bar = nullptr;
     int* abort_flag = nullptr;
     int gi_mode = 0;                   // 0 rows (k_rows_decide / k_rows_apply, the default), 1 the two older kernels
+    int rows_stage = 0;                // ... their second pass out of LDS: 0 where two workgroups fit a compute unit, 1 / -1 forced
+    bool rows_stream = true;           // rows of more than 1024 null-space coordinates are streamed (k_rows_apply_stream);
+                                       // OGSQP_ROWS=reg: the register kernels k_rows_apply<TAIL> for every length
     bool warm_enabled = true;          // start the active-set method from the previous subproblem's active rows
     std::vector<int> warm;             // ... in the canonical numbering of og_qp_get_active
     bool warm_use = true;              // ... when the last two solutions shared most of their active rows (early in an
@@ -2729,6 +2732,10 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     if (!rc && (hipFuncSetAttribute((const void*)k_rows_decide, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LDS_LIMIT) != hipSuccess ||
                 hipFuncSetAttribute((const void*)k_rows_invert, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LDS_LIMIT) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_rows_apply_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LDS_LIMIT) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_rows_apply_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LDS_LIMIT) != hipSuccess))
         rc = fail(5, "og_qp_create: cannot raise the dynamic LDS limit");
     {
@@ -2760,6 +2767,9 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         // select the two older kernels (kept for comparison; they need their own, smaller, LDS budget)
         qp->gi_mode = (mode && (std::string(mode) == "single" || std::string(mode) == "coop" || std::string(mode) == "old")) ? 1 : 0;
         if (qp->gi_mode == 1 && gi_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) qp->gi_mode = 0;
+        const char* rowsk = getenv("OGSQP_ROWS");
+        qp->rows_stream = !(rowsk && std::string(rowsk) == "reg");
+        qp->rows_stage = (rowsk && std::string(rowsk) == "stage") ? 1 : (rowsk && std::string(rowsk) == "nostage") ? -1 : 0;
         const char* lq = getenv("OGSQP_LQ");
         qp->lq16 = !(lq && std::string(lq) == "8");
         qp->lq_ahead = !(lq && std::string(lq) == "16");
@@ -3151,7 +3161,8 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
         ra.rec = qp->rec;
         const int nrows = mg + nq;
         ra.G1 = std::max(8, std::min(128, (qp->qcap + 15) / 16));
-        ra.G2 = std::max(1, std::min(2048, (nrows + 1 + ROWS_WAVES - 1) / ROWS_WAVES));   // a wavefront per row
+        // a wavefront per row (2048 workgroups at most: k_rows_decide reads that many partial prices in one trip)
+        ra.G2 = std::max(1, std::min(2048, (nrows + 1 + ROWS_WAVES - 1) / ROWS_WAVES));
         const size_t lds1 = rows_lds_bytes(nr, qp->qcap);
         OG_STAGE("rows init");
         hipLaunchKernelGGL(k_rows_init, dim3((mt + n1 + 255) / 256 + 1), dim3(ROWS_THREADS), 0, s, ra, qp->diagL,
@@ -3162,9 +3173,18 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
                                ra, (const double*)qp->Tc, (const double*)qp->diagL);
         }
         const int tail_lanes = (nr + 63) / 64;
+        // long rows are streamed, the row staged in LDS when five vectors of the null space fit a workgroup's share
+        const size_t nrp = (size_t)tail_lanes * 64;
+        const bool stream = qp->rows_stream && tail_lanes > 16;
+        // (two workgroups per compute unit at least; OGSQP_ROWS=stage / nostage force one form where it fits)
+        const bool stage = stream && qp->rows_stage >= 0 &&
+                           5 * nrp * sizeof(double) <= (qp->rows_stage > 0 ? LDS_LIMIT : (size_t)64 * 1024);
+        const size_t lds2 = (stage ? 5 : 1) * nrp * sizeof(double);
 #define OG_ROWS_APPLY()                                                                                      \
     do {                                                                                                     \
-        if (tail_lanes <= 8) hipLaunchKernelGGL(k_rows_apply<8>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra);   \
+        if (stream && stage) hipLaunchKernelGGL(k_rows_apply_stream<true>, dim3(ra.G2), dim3(ROWS_THREADS), lds2, s, ra); \
+        else if (stream) hipLaunchKernelGGL(k_rows_apply_stream<false>, dim3(ra.G2), dim3(ROWS_THREADS), lds2, s, ra); \
+        else if (tail_lanes <= 8) hipLaunchKernelGGL(k_rows_apply<8>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra);   \
         else if (tail_lanes <= 16) hipLaunchKernelGGL(k_rows_apply<16>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
         else if (tail_lanes <= 32) hipLaunchKernelGGL(k_rows_apply<32>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
         else hipLaunchKernelGGL(k_rows_apply<80>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra);                  \

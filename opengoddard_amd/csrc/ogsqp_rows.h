@@ -606,52 +606,90 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
 // Second kernel of a change: the pass over the rows, one wavefront per row with the whole row in registers
 // (TAIL coordinates per lane: rows of up to 64 * TAIL null-space entries).  The walk covers the constraint rows,
 // then y (which lives in the same coordinates), then - when a row leaves - the rows of the inverse.
+//
+// Round 5 (80 us per change at C5, 143 MB at 1.8 TB/s).  The kernel was four residency rounds of
+// wavefronts that each ran the chain  state word -> decision -> its vectors -> row -> sum -> store  once: its duration
+// was round trips, not bytes.  Now (a) the state word, the decision and both vectors are requested together (none of
+// their addresses depends on another's value; the masks that do are applied afterwards), (b) the two vectors share
+// ONE array in LDS - the incoming normal lives on the coordinates >= q0, the leaving reflector on those < q0; in
+// registers they cost 4 * TAIL VGPRs -, and (c) the 3 * TAIL lane masks of the row loop are no longer loop invariants
+// (see the loop): 256 VGPRs + 232 AGPRs + spilled scalar pairs, one wavefront per SIMD, became a kernel that several
+// wavefronts per SIMD fit, and the grid covers the rows in one or two residency rounds instead of eight.  The
+// sums are the same sums in the same order (lane l adds its coordinates l, l + 64, ... in ascending order, then
+// wave_sum): same bits as rounds 3-4.
 template <int TAIL>
 __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
     __shared__ double redv[ROWS_WAVES];
     __shared__ int redi[ROWS_WAVES];
     const GiArgs& g = a.g;
     GiState* st = g.st;
-    if (st->phase >= 2) return;
-    const RowsDecision rec = *a.rec;
-    const int kind = rec.kind;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
     const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
-    const int q0 = rec.q;
+    // ---- one round trip for everything whose address is known: state, decision, the two vectors.  The vectors are the
+    // same for every row: they live in LDS (in registers they cost 4 * TAIL VGPRs and the kernel one wavefront per SIMD)
+    __shared__ double s_c[64 * TAIL];
+    const int phase = st->phase;
+    const double ynorm = st->ynorm;
+    const RowsDecision rec = *a.rec;
+    double draw[(TAIL + ROWS_WAVES - 1) / ROWS_WAVES], vraw[(TAIL + ROWS_WAVES - 1) / ROWS_WAVES];
+#pragma unroll
+    for (int c = 0; c < (TAIL + ROWS_WAVES - 1) / ROWS_WAVES; ++c) {
+        const int j = tid + ROWS_THREADS * c;
+        draw[c] = a.dvec[j < nr ? j : 0];
+        vraw[c] = a.vvec[j < qcap ? j : 0];
+    }
+    if (phase >= 2) return;
+    const int kind = rec.kind;
     const int nrows = mg + nq;
     const bool moves = (kind == 1 || kind == 2) && !rec.dependent;
     const bool leaves = kind == 2 || kind == 3;
-    const double slack = FEASIBLE * st->ynorm;
-    // per lane: the incoming normal's tail (d2, zero on the first q0 coordinates) and the leaving reflector's vector
-    double dreg[TAIL], vreg[TAIL];
+    const double slack = FEASIBLE * ynorm;
+    // s_c: the incoming normal's tail (d2, on the coordinates >= q0) and the leaving reflector's vector (< q0)
 #pragma unroll
-    for (int e = 0; e < TAIL; ++e) {
-        const int j = lane + 64 * e;
-        dreg[e] = (moves && j >= q0 && j < nr) ? a.dvec[j] : 0.0;
-        vreg[e] = (leaves && j < q0) ? a.vvec[j] : 0.0;
+    for (int c = 0; c < (TAIL + ROWS_WAVES - 1) / ROWS_WAVES; ++c) {
+        const int j = tid + ROWS_THREADS * c;
+        if (j < 64 * TAIL)
+            s_c[j] = j < rec.q ? ((leaves && j < qcap) ? vraw[c] : 0.0) : ((moves && j < nr) ? draw[c] : 0.0);
     }
+    __syncthreads();
+    // (volatile: the vector is loop-invariant, and the compiler would otherwise pull it back into 2 * TAIL registers)
+    const volatile double* vc = s_c;
+    // the first q0 coordinates of a row matter when a row leaves (its reflector lives there) and for the values
+    // after a warm start; the tail when the incoming row moves the point - a full step at q0 = 300 of 468
+    // coordinates streams a third of the matrix
+    const bool head = leaves || kind == 4, tail = moves;
+    const int extra = leaves ? rec.q - 1 : 0;              // rows of the inverse that stay (positions after the shift)
+    const int last = nrows + extra, stride = a.G2 * ROWS_WAVES;
     double best = INFINITY;
     int besti = 0x7fffffff;
-    const int extra = leaves ? q0 - 1 : 0;                 // rows of the inverse that stay (positions after the shift)
-    for (int r = w * ROWS_WAVES + wave; r <= nrows + extra; r += a.G2 * ROWS_WAVES) {
+
+    for (int r = w * ROWS_WAVES + wave; r <= last; r += stride) {
+        // (the grid gives every wavefront ONE row as a rule.  The masks below compare lane + 64 e with q0, nr, len: as
+        // loop invariants the compiler kept all 3 * TAIL of them alive in scalar register pairs, spilled those into
+        // vector registers and left the kernel one wavefront per SIMD at C5 - rounds 3-4.  An opaque copy per trip
+        // makes them values of the trip: they are computed where they are used.)
+        int q0 = rec.q, nrv = nr;
+        asm volatile("" : "+s"(q0), "+s"(nrv));
         const bool is_y = r == nrows, is_inv = r > nrows;
         double* row = is_inv ? g.RI[0] + (long)a.slot[r - nrows - 1] * qcap : is_y ? g.y : rows_ptr(g, r);
-        const int len = is_inv ? q0 : nr;
+        const int len = is_inv ? q0 : nrv;
         double dot = (is_y || is_inv) ? 0.0 : a.dots[r];
         const double xq = (kind == 1 && !is_inv) ? row[q0] : 0.0;
         if (kind != 0) {
             double x[TAIL];
+            // (the two sums of rounds 3-4, term for term: the normal's entries are zero below q0, the reflector's from q0 on)
             double acc_d = 0.0, acc_v = 0.0;
-            // the first q0 coordinates of a row matter when a row leaves (its reflector lives there) and for the
-            // values after a warm start; the tail when the incoming row moves the point - a full step at q0 = 300
-            // of 468 coordinates streams a third of the matrix
-            const bool head = leaves || kind == 4, tail = moves;
 #pragma unroll
             for (int e = 0; e < TAIL; ++e) {
                 const int j = lane + 64 * e;
                 x[e] = (j < len && (j < q0 ? head : tail)) ? row[j] : 0.0;
-                acc_d += x[e] * dreg[e];
-                acc_v += x[e] * vreg[e];
+            }
+#pragma unroll
+            for (int e = 0; e < TAIL; ++e) {
+                const int j = lane + 64 * e;
+                const double cj = vc[j];
+                acc_d += x[e] * (j < q0 ? 0.0 : cj);
+                acc_v += x[e] * (j < q0 ? cj : 0.0);
             }
             if (kind == 4) {
                 if (!is_y) {
@@ -677,7 +715,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
 #pragma unroll
                         for (int e = 0; e < TAIL; ++e) {
                             const int j = lane + 64 * e;
-                            if (j >= q0 && j < nr) row[j] = x[e] - f * (dreg[e] - (j == q0 ? rec.alpha : 0.0));
+                            if (j >= q0 && j < nrv) row[j] = x[e] - f * (vc[j] - (j == q0 ? rec.alpha : 0.0));
                         }
                     }
                 }
@@ -687,7 +725,148 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
 #pragma unroll
                     for (int e = 0; e < TAIL; ++e) {
                         const int j = lane + 64 * e;
-                        if (j < q0) row[j] = x[e] - f * vreg[e];
+                        if (j < q0) row[j] = x[e] - f * vc[j];
+                    }
+                }
+            }
+        }
+        if (is_y || is_inv || leaves) continue;            // the same row p goes on after a removal: no pricing
+        if (r < mg) {
+            if (g.scale[r] > 0.0 && !g.isact[r]) {
+                const double v = (g.bval[r] + dot) / g.scale[r] + g.own[r] + slack;
+                if (v < best || (v == best && r < besti)) {
+                    best = v;
+                    besti = r;
+                }
+            }
+        } else {
+            const int lo = r, hi = r + nq;
+            if (g.scale[lo] > 0.0 && !g.isact[lo]) {
+                const double v = (g.bval[lo] + dot) / g.scale[lo] + g.own[lo] + slack;
+                if (v < best || (v == best && lo < besti)) {
+                    best = v;
+                    besti = lo;
+                }
+            }
+            if (g.scale[hi] > 0.0 && !g.isact[hi]) {
+                const double v = (g.bval[hi] - dot) / g.scale[hi] + g.own[hi] + slack;
+                if (v < best || (v == best && hi < besti)) {
+                    best = v;
+                    besti = hi;
+                }
+            }
+        }
+    }
+    if (!leaves) {
+        block_argmin(best, besti, redv, redi);
+        if (tid == 0) {
+            a.price[w].value = best;
+            a.price[w].index = besti;
+        }
+    }
+}
+
+// Long rows (more than 16 x 64 null-space coordinates: C5's 2017).  Holding such a row in registers - 2 * TAIL of them,
+// with TAIL lane masks per comparison - cost the register kernel its occupancy: 256 VGPRs + 232 AGPRs, ONE wavefront
+// per SIMD, the 8 199 rows of C5 in eight residency rounds of round trips, 80 us per change for 143 MB (1.8 TB/s).
+// Here the row is STREAMED in strips of 64 coordinates with run-time bounds - only the strips the change touches: the
+// tail from q0 on when the point moves, the head below q0 when a row leaves -, the sums in the register kernel's order
+// (lane l adds its coordinates l, l + 64, ... in ascending order; strips outside the range contributed exact zeros
+// there), a few dozen registers, eight loads in flight per wavefront.  What the second pass needs of the row again comes
+// out of LDS (STAGE: one row per wavefront next to the shared vector - 5 x 8 nr bytes per workgroup, two workgroups per
+// compute unit at C5) or, for rows too long for that, from the caches.  Same bits as k_rows_apply<TAIL>
+// (OGSQP_ROWS=reg selects the register kernels for every length; tests/test_slsqp_core.py compares the two).
+template <bool STAGE>
+__global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply_stream(RowsArgs a) {
+    extern __shared__ double lds[];
+    __shared__ double redv[ROWS_WAVES];
+    __shared__ int redi[ROWS_WAVES];
+    const GiArgs& g = a.g;
+    GiState* st = g.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
+    const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
+    const int nrp = (nr + 63) & ~63;
+    double* s_c = lds;
+    double* s_x = lds + nrp + (STAGE ? wave * nrp : 0);
+    const int phase = st->phase;
+    const double ynorm = st->ynorm;
+    const RowsDecision rec = *a.rec;
+    if (phase >= 2) return;
+    const int kind = rec.kind;
+    const int q0 = rec.q;
+    const int nrows = mg + nq;
+    const bool moves = (kind == 1 || kind == 2) && !rec.dependent;
+    const bool leaves = kind == 2 || kind == 3;
+    const double slack = FEASIBLE * ynorm;
+    // the incoming normal's tail (coordinates >= q0) and the leaving reflector's vector (< q0) in one array
+    for (int j = tid; j < nrp; j += ROWS_THREADS) {
+        const double dv = a.dvec[j < nr ? j : 0], vv = a.vvec[j < qcap ? j : 0];
+        s_c[j] = j < q0 ? ((leaves && j < qcap) ? vv : 0.0) : ((moves && j < nr) ? dv : 0.0);
+    }
+    __syncthreads();
+    const bool head = leaves || kind == 4, tail = moves;
+    const int extra = leaves ? q0 - 1 : 0;
+    const int last = nrows + extra, stride = a.G2 * ROWS_WAVES;
+    double best = INFINITY;
+    int besti = 0x7fffffff;
+    for (int r = w * ROWS_WAVES + wave; r <= last; r += stride) {
+        const bool is_y = r == nrows, is_inv = r > nrows;
+        double* row = is_inv ? g.RI[0] + (long)a.slot[r - nrows - 1] * qcap : is_y ? g.y : rows_ptr(g, r);
+        const int len = is_inv ? q0 : nr;
+        double dot = (is_y || is_inv) ? 0.0 : a.dots[r];
+        const double xq = (kind == 1 && !is_inv) ? row[q0] : 0.0;
+        if (kind != 0) {
+            // strips [e_lo, e_hi) of 64 coordinates hold everything the change reads of this row
+            const int e_lo = head ? 0 : q0 >> 6;
+            const int e_hi = tail ? (len + 63) >> 6 : (min(q0, len) + 63) >> 6;
+            double acc_d = 0.0, acc_v = 0.0, acc_y = 0.0;
+#pragma unroll 8
+            for (int e = e_lo; e < e_hi; ++e) {
+                const int j = lane + 64 * e;
+                const double xv = (j < len && (j < q0 ? head : tail)) ? row[j] : 0.0;
+                if (STAGE) s_x[j] = xv;
+                const double cj = s_c[j];
+                acc_d += xv * (j < q0 ? 0.0 : cj);
+                acc_v += xv * (j < q0 ? cj : 0.0);
+                if (kind == 4) acc_y += (j < q0) ? xv * g.y[j] : 0.0;
+            }
+            if (kind == 4) {
+                if (!is_y) {
+                    dot = wave_sum(acc_y);
+                    if (lane == 0) a.dots[r] = dot;
+                }
+            } else {
+                if (moves && !is_inv && (kind == 1 || !is_y)) {
+                    const double gi = wave_sum(acc_d);
+                    if (!is_y) {
+                        dot += rec.t * gi;
+                        if (lane == 0) a.dots[r] = dot;
+                    }
+                    if (kind == 1) {
+                        // reflector of the incoming row on the tail: v = d2 - alpha e_q0
+                        const double f = rec.beta * (gi - rec.alpha * xq);
+                        const int t_hi = (nr + 63) >> 6;
+#pragma unroll 8
+                        for (int e = q0 >> 6; e < t_hi; ++e) {
+                            const int j = lane + 64 * e;
+                            if (j >= q0 && j < nr) {
+                                const double xv = STAGE ? s_x[j] : row[j];
+                                row[j] = xv - f * (s_c[j] - (j == q0 ? rec.alpha : 0.0));
+                            }
+                        }
+                    }
+                }
+                if (leaves) {
+                    // reflector of the leaving row on the first q0 coordinates
+                    const double f = rec.beta_out * wave_sum(acc_v);
+                    const int h_hi = (q0 + 63) >> 6;
+#pragma unroll 8
+                    for (int e = 0; e < h_hi; ++e) {
+                        const int j = lane + 64 * e;
+                        if (j < q0) {
+                            const double xv = STAGE ? s_x[j] : row[j];
+                            row[j] = xv - f * s_c[j];
+                        }
                     }
                 }
             }

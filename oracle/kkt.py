@@ -79,12 +79,17 @@ def residuals(prob, obj, x, m_eq, active_tol=1e-6, bound_tol=1e-9, jacobian=None
     # prices arbitrarily - are released (multiplier 0) and the fit repeated, most negative half first.
     act = list(act)
     at_lo, at_up = list(at_lo), list(at_up)
+    floor = None                                              # stationarity no choice of multipliers on these rows beats
     for _ in range(200):
         fixed = np.array(at_lo + at_up, dtype=int)
         free = np.setdiff1d(np.arange(n), fixed)
         M = np.hstack([Aeq, Ain[:, act]])
         lam, *_ = np.linalg.lstsq(M[free], g[free], rcond=None)
         r = g - M @ lam
+        if floor is None:
+            # the first fit is on EVERY row at zero, signs free: its residual is a lower bound (in the 2-norm) for any
+            # certificate - a large value here means the point is not stationary, whatever the pruning below does
+            floor = (float(np.max(np.abs(r[free]), initial=0.0)), float(np.linalg.norm(r[free])))
         z_lo, z_up = r[at_lo], -r[at_up]                      # g - A'lam = z_lo - z_up, both >= 0 at an optimum
         signed = np.concatenate([lam[m_eq:], z_lo, z_up])
         worst = float(np.min(signed, initial=0.0))
@@ -114,5 +119,7 @@ def residuals(prob, obj, x, m_eq, active_tol=1e-6, bound_tol=1e-9, jacobian=None
             "inequalities_at_zero": int(np.count_nonzero(cin <= active_tol)),
             "free_variables": int(free.size), "equalities": int(m_eq),
             "largest_multiplier": float(np.max(np.abs(lam), initial=0.0)),
+            "stationarity_2norm": float(np.linalg.norm(r_free)) / gscale,
+            "stationarity_floor_signs_free": floor[0] / gscale, "stationarity_floor_2norm": floor[1] / gscale,
             "gradient_scale": gscale,
             "jacobian": "central differences (rel. step %.0e) of oracle/np_path.stacked_values" % REL_STEP}

@@ -767,6 +767,36 @@ def test_gpu_wide_sweep_on_side_streams_gives_the_bits_of_the_one_stream_order(m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,meq,mg", [(1500, 300, 200), (2400, 300, 60)])
+def test_gpu_streamed_rows_give_the_bits_of_the_register_kernels(n, meq, mg, monkeypatch):
+    """Round 5: rows of more than 1024 null-space coordinates are STREAMED by ``k_rows_apply_stream`` (run-time strips of
+    64 coordinates, the second pass out of LDS or the caches) instead of held in registers by ``k_rows_apply<TAIL>``
+    (one wavefront per SIMD at C5).  Same sums in the same order: step, multipliers, active set and change count must be
+    the same BITS in all three forms - cold start, a warm-started second subproblem (phase -1 removals, the kind-3 / kind-4
+    passes) and a third one."""
+    rng = np.random.default_rng(n)
+    Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+    A, cc = np.vstack([C, G]), np.concatenate([c, h])
+    results = {}
+    for form in ("reg", "nostage", "stage"):
+        monkeypatch.setenv("OGSQP_ROWS", form)
+        core = _sqp_native.QpCore(n, meq, mg)
+        out = []
+        for rep in range(3):
+            core.set_factor(Z * (1.0 + 0.25 * rep))
+            d, mult, bm, status, iters = core.solve(A, g * (1.0 + 0.1 * rep), cc, lb, ub)
+            out.append((d.copy(), mult.copy(), bm.copy(), status, iters, sorted(int(v) for v in core.get_active())))
+        core.close()
+        results[form] = out
+    monkeypatch.delenv("OGSQP_ROWS")
+    assert results["reg"][0][4] > 20                                  # the active-set loop did run
+    for form in ("nostage", "stage"):
+        for (d0, m0, b0, s0, i0, a0), (d1, m1, b1, s1, i1, a1) in zip(results["reg"], results[form]):
+            assert s0 == s1 == 1 and i0 == i1 and a0 == a1, (form, s0, s1, i0, i1)
+            assert np.array_equal(d0, d1) and np.array_equal(m0, m1) and np.array_equal(b0, b1), form
+
+
+@pytest.mark.gpu
 def test_device_resident_jacobian_equals_host_staged():
     """og_qp_solve_dev on the Jacobian the sweep kernel left in HBM == og_qp_solve on its host copy;
     og_jt_times gives the cost gradient and the gradient of the Lagrangian."""

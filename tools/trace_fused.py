@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): phase timing of every workgroup of ogk_fused from in-kernel stamps
 (s_memrealtime, 100 MHz: 10 ns per tick, one clock for the whole chip), read back through og_trace_read.
-    OG_EXTRA_HIPFLAGS=-DOGK_TRACE=1 OGPSX_TRACE=1 OGPSX_SWEEP=fused python tools/trace_fused.py [workload]
+    OG_MODULE_HIPFLAGS=-DOGK_TRACE=1 OGPSX_TRACE=1 OGPSX_SWEEP=fused python tools/trace_fused.py [workload] [--json] [--nodes a,b]
 Record per wavefront: kind (0 evaluation, 1 light, 2 heavy part, 3 MFMA tile), start, four phase stamps, end.
+``--json`` (bench.py's measured_chain): one JSON line with the dependent chain of a launch - per kind of workgroup the
+smallest (last end - first start) over its workgroups, the largest of those over the kinds - and the kernel span.
 """
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-assert "OGK_TRACE" in os.environ.get("OG_EXTRA_HIPFLAGS", ""), "set OG_EXTRA_HIPFLAGS=-DOGK_TRACE=1"
+assert "OGK_TRACE" in os.environ.get("OG_MODULE_HIPFLAGS", "") + os.environ.get("OG_EXTRA_HIPFLAGS", ""), \
+    "set OG_MODULE_HIPFLAGS=-DOGK_TRACE=1"
 os.environ["OGPSX_TRACE"] = "1"
 import torch
 from opengoddard_amd import _native, problems
 from opengoddard_amd.engine import HipEngine
-name = sys.argv[1] if len(sys.argv) > 1 else "polar_tsto"
-prob, obj = problems.build(name)
+argv = [v for v in sys.argv[1:] if not v.startswith("--")]
+as_json = "--json" in sys.argv
+name = argv[0] if argv else "polar_tsto"
+nodes = sys.argv[sys.argv.index("--nodes") + 1] if "--nodes" in sys.argv else None
+if nodes:
+    argv = [v for v in argv if v != nodes]
+    name = argv[0] if argv else "polar_tsto"
+prob, obj = problems.build(name, **({"nodes": [int(v) for v in nodes.split(",")]} if nodes else {}))
 eng = HipEngine(prob, obj)
 n, m = eng.n, eng.m
 lb = np.array([-np.inf if b[0] is None else b[0] for b in prob.bounds])
@@ -38,6 +47,26 @@ live = rec[:, 1] > 0
 rec, wg = rec[live], wg[live]
 t0 = rec[:, 1].min()
 us = lambda v: (v - t0) * 0.01
+if as_json:
+    import json
+    # the records hold the last launches stamped; one launch's workgroups share a start within a few us: take the records
+    # of the LAST launch (starts within 100 us of the latest start)
+    last = rec[:, 1] > rec[:, 1].max() - 10000
+    r1, w1 = rec[last], wg[last]
+    by_kind = {}
+    for kind, label in ((0, "evaluation"), (1, "light"), (2, "heavy_part"), (3, "mfma_tile")):
+        sel = r1[:, 0] == kind
+        if not sel.any():
+            continue
+        spans = []
+        for g in np.unique(w1[sel]):
+            rows = r1[sel & (w1 == g)]
+            spans.append((rows[:, 7].max() - rows[:, 1].min()) * 0.01)
+        by_kind[label] = float(np.min(spans))
+    print(json.dumps({"chain_us": max(by_kind.values()), "by_kind_us": by_kind,
+                      "kernel_span_us": float((r1[:, 7].max() - r1[:, 1].min()) * 0.01), "workload": name,
+                      "wavefront_records": int(len(r1))}))
+    sys.exit(0)
 print("%s (%s): %d wavefront records, kernel span %.2f us (first start to last end)" % (
     name, eng.sweep_mode, len(rec), us(rec[:, 7].max())))
 names = {0: "evaluation", 1: "light", 2: "heavy part", 3: "MFMA tile"}

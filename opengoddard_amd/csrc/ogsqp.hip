@@ -2401,6 +2401,8 @@ struct og_qp_s {
     LqWideMail* wide_mail = nullptr;
     unsigned* wide_count = nullptr;    // monotone count of the panel workgroups' steps, ever
     unsigned wide_token = 0u;
+    bool wide_inblock = true;          // the later rows of a block get a panel's reflectors in ONE launch (k_wy_inblock);
+    unsigned wide_in_token = 0u;       // OGSQP_WIDE_INBLOCK=0: product over slices, finish, update as three launches
     double* wy_part = nullptr;         // column slices of a product (k_wy_w with blockIdx.y > 0), summed by k_wy_sum
     size_t wy_part_cap = 0;
     double *wy_w = nullptr, *wy_m = nullptr, *wy_t = nullptr, *wy_small = nullptr;   // 2 x (rows x 64) coefficients, M, T = M^-1 (one per block of a sweep), 2 x (64 x 16)
@@ -2484,17 +2486,25 @@ size_t rows_lds_bytes(int nr, int qcap) {          // k_rows_decide: the incomin
 }  // namespace
 
 namespace {
+// column slices of a product with `rows` rows of length L: enough workgroups for every SIMD of the chip (a workgroup of
+// k_wy_w is two wavefronts that issue 16 MFMAs per 2 KB of A); few rows: at most 32 slices - the kernels that add the
+// slices up walk them one after the other.  (k_wy_inblock uses the SAME slices: its sums are these sums.)
+void wy_split(const og_qp_s* qp, int rows, int L, int* nsplit_out, int* kb_per_out) {
+    const int tiles = (rows + 16 * WYW_WAVES - 1) / (16 * WYW_WAVES), nblk = (L + 15) / 16;
+    int nsplit = std::max(1, std::min(std::min(tiles <= 4 ? 32 : WYW_SPLIT_MAX, 1024 / tiles), nblk / 4));
+    nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, qp->wy_part_cap / ((size_t)rows * LQW_BLOCK)));
+    const int kb_per = (nblk + nsplit - 1) / nsplit;
+    *nsplit_out = (nblk + kb_per - 1) / kb_per;
+    *kb_per_out = kb_per;
+}
+
 // W (rows x 64) = A V' by k_wy_w; few rows are split over the chip by columns (partials in wy_part, summed in order)
 void launch_wy_w(og_qp_s* qp, const double* A, int ld, int rows, int L, const double* V, int ldv, int nb, double* W,
                  int* nsplit_out, hipStream_t s, double* part = nullptr) {
     if (!part) part = qp->wy_part;
-    const int tiles = (rows + 16 * WYW_WAVES - 1) / (16 * WYW_WAVES), nblk = (L + 15) / 16;
-    // enough workgroups for every SIMD of the chip (a workgroup is two wavefronts that issue 16 MFMAs per 2 KB of A)
-    // (few rows: at most 32 slices - the kernels that add the slices up walk them one after the other)
-    int nsplit = std::max(1, std::min(std::min(tiles <= 4 ? 32 : WYW_SPLIT_MAX, 1024 / tiles), nblk / 4));
-    nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, qp->wy_part_cap / ((size_t)rows * LQW_BLOCK)));
-    const int kb_per = (nblk + nsplit - 1) / nsplit;
-    nsplit = (nblk + kb_per - 1) / kb_per;
+    const int tiles = (rows + 16 * WYW_WAVES - 1) / (16 * WYW_WAVES);
+    int nsplit = 1, kb_per = 1;
+    wy_split(qp, rows, L, &nsplit, &kb_per);
     double* dst = nsplit > 1 ? part : W;
     hipLaunchKernelGGL(k_wy_w, dim3(tiles, nsplit), dim3(64 * WYW_WAVES), 0, s, A, ld, rows, L, V, ldv, nb, dst, kb_per);
     if (nsplit_out) {
@@ -2564,12 +2574,21 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
             const int rest = k0 + nbk - (kk + nb16);
             if (rest > 0) {
                 double* A = qp->Tc + (size_t)(kk + nb16) * ldw + kk;
-                double* W2 = qp->wy_small;                                  // rest x 16
-                int nsplit = 1;
-                launch_wy_w(qp, A, ldw, rest, len, V, ldw, LQ16, qp->wy_part, &nsplit, s);
-                hipLaunchKernelGGL(k_wy_small_finish, dim3(1), dim3(1024), 0, s, (const double*)qp->wy_part, nsplit, rest,
-                                   (const Lq16Panel*)qp->panelw, W2);
-                launch_wy_update(A, ldw, rest, len, V, ldw, LQ16, W2, LQ16, nullptr, s);
+                int nsplit = 1, kb_per = 1;
+                wy_split(qp, rest, len, &nsplit, &kb_per);
+                if (qp->wide_inblock && rest <= 16 * WIB_WAVES && kb_per <= WIB_KB) {
+                    // one launch: the slices' workgroups exchange their shares of the products (k_wy_inblock)
+                    qp->wide_in_token += (unsigned)nsplit;
+                    hipLaunchKernelGGL(k_wy_inblock, dim3(nsplit), dim3(64 * WIB_WAVES), 0, s, A, ldw, rest, len,
+                                       (const double*)V, ldw, nb16, (const Lq16Panel*)qp->panelw, qp->wy_part, kb_per,
+                                       qp->wide_count + 1, qp->wide_in_token, qp->flag + 2, qp->spin_limit);
+                } else {
+                    double* W2 = qp->wy_small;                              // rest x 16
+                    launch_wy_w(qp, A, ldw, rest, len, V, ldw, LQ16, qp->wy_part, &nsplit, s);
+                    hipLaunchKernelGGL(k_wy_small_finish, dim3(1), dim3(1024), 0, s, (const double*)qp->wy_part, nsplit, rest,
+                                       (const Lq16Panel*)qp->panelw, W2);
+                    launch_wy_update(A, ldw, rest, len, V, ldw, LQ16, W2, LQ16, nullptr, s);
+                }
             }
         }
         if (rc) break;
@@ -2788,6 +2807,10 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
             qp->wy_part_cap = std::max((size_t)WYW_SPLIT_MAX * 2 * LQW_BLOCK * LQW_BLOCK, 4 * (n1 + vrows) * LQW_BLOCK);
             A(&qp->wy_part, qp->wy_part_cap);
             A(&qp->wy_small, (size_t)2 * LQ16 * LQW_BLOCK);
+            if (!rc && hipMemset(qp->wide_count, 0, 4 * sizeof(unsigned)) != hipSuccess)
+                rc = fail(5, "og_qp_create: hipMemset failed");
+            const char* inblock = getenv("OGSQP_WIDE_INBLOCK");
+            qp->wide_inblock = !(inblock && std::string(inblock) == "0");
             if (!rc && hipMemset(qp->Vall, 0, vrows * ldw * sizeof(double)) != hipSuccess)
                 rc = fail(5, "og_qp_create: hipMemset failed");
             if (!rc) {

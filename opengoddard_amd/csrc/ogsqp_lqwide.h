@@ -507,6 +507,142 @@ __global__ __launch_bounds__(64 * WYU_WAVES) void k_wy_update(double* __restrict
     }
 }
 
+// The later rows of a block after one of its 16-reflector panels, in ONE launch (round 5; k_wy_w over column slices +
+// k_wy_small_finish + the rank-16 update were three launches and ~75 us of the sweep's chain per panel, 195 times per
+// C5 subproblem):  rows <- rows - ((rows V16') T16) V16  for `rows` <= 48 rows of length L.  Workgroup y of the grid owns
+// the column slice [16 kb_per y, 16 kb_per (y + 1)): it loads its slice of the rows into registers and of the 16
+// vectors into LDS ONCE, forms its share of the products (the MFMA chain of k_wy_w), posts it, and waits for the
+// others' shares - the workgroups are the whole grid of the launch, at most 32, and wait only for each other (counter
+// + bounded spin as in the look-ahead sweep: a wait that gives up raises the flag the host turns into a re-run with the
+// separate launches); every workgroup then adds the shares up in the order of the slices, multiplies by the panel's T
+// (the sums of k_wy_small_finish, term for term) and updates the slice it still holds (the MFMA chain of
+// k_wy_update<1, false>).  Same slices, same sums, same chains: the BITS of the three launches.
+constexpr int WIB_WAVES = 3;                     // 48 rows
+constexpr int WIB_KB = 16;                       // 16-column blocks per slice at most
+__global__ __launch_bounds__(64 * WIB_WAVES) void k_wy_inblock(double* __restrict__ A, int ld, int rows, int L,
+                                                              const double* __restrict__ V, int ldv, int nb,
+                                                              const Lq16Panel* __restrict__ panel, double* part,
+                                                              int kb_per, unsigned* counter, unsigned expect,
+                                                              int* __restrict__ lost, int spin_limit) {
+    constexpr int VS = 16 * WIB_KB + 16;
+    constexpr int NT = 64 * WIB_WAVES;
+    __shared__ __attribute__((aligned(32))) double s_v[LQ16][VS];
+    __shared__ double s_w[16 * WIB_WAVES][LQ16 + 1];
+    __shared__ double s_w2[16 * WIB_WAVES][LQ16 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int y = blockIdx.x, nsl = gridDim.x;
+    const int nblk_all = (L + 15) / 16;
+    const int b_lo = y * kb_per, nbk = min(nblk_all, b_lo + kb_per) - b_lo;      // (>= 1: the grid is ceil(nblk / kb_per))
+    const int r = 16 * wv + n;
+    const bool valid = r < rows;
+    const int rc = min(r, rows - 1);
+    double* row = A + (long)rc * ld;
+    // ---- my slice: the rows into registers, the vectors into LDS
+    dbl4 x[WIB_KB];
+#pragma unroll
+    for (int u = 0; u < WIB_KB; ++u) {
+        x[u] = dbl4{0.0, 0.0, 0.0, 0.0};
+        if (u < nbk) {
+            const int j0 = 16 * (b_lo + u) + 4 * g;
+            x[u] = *(const dbl4*)(row + min(j0, 4 * ((L - 1) / 4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (j0 + i >= L) x[u][i] = 0.0;
+        }
+    }
+    for (int e = tid; e < LQ16 * nbk * 4; e += NT) {
+        const int vr = e / (nbk * 4), c4 = e % (nbk * 4);
+        const int col = 16 * b_lo + 4 * c4;
+        dbl4 a = {0.0, 0.0, 0.0, 0.0};
+        if (vr < nb) {
+            a = *(const dbl4*)(V + (long)vr * ldv + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (col + i >= L) a[i] = 0.0;
+        }
+        *(dbl4*)&s_v[vr][4 * c4] = a;
+    }
+    __syncthreads();
+    // ---- my share of W' = V X'
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < WIB_KB; ++u) {
+        if (u < nbk) {
+            const dbl4 vq = *(const dbl4*)&s_v[n][16 * u + 4 * g];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vq[i], x[u][i], acc, 0, 0, 0);
+        }
+    }
+    if (valid) {
+        double* mine = part + ((long)y * (16 * WIB_WAVES) + r) * LQ16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __hip_atomic_store(mine + 4 * i + g, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lq_wait_for(counter, expect, lost, spin_limit);
+    }
+    __syncthreads();
+    // ---- everybody's shares, in the order of the slices; then W2 = W1 T16 (upper triangular)
+    for (int e = tid; e < rows * LQ16; e += NT) {
+        const int rr = e / LQ16, j = e % LQ16;
+        double sum = 0.0;
+        for (int y0 = 0; y0 < nsl; y0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = y0 + u < nsl ? __hip_atomic_load(part + ((long)(y0 + u) * (16 * WIB_WAVES) + rr) * LQ16 + j,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (y0 + u < nsl) sum += v[u];
+        }
+        s_w[rr][j] = sum;
+    }
+    __syncthreads();
+    for (int e = tid; e < rows * LQ16; e += NT) {
+        const int rr = e / LQ16, j = e % LQ16;
+        double w2 = 0.0;
+        for (int i = 0; i <= j; ++i) w2 = fma(s_w[rr][i], panel->T[i][j], w2);
+        s_w2[rr][j] = w2;
+    }
+    __syncthreads();
+    d4 z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = 4 * i + g < nb ? s_w2[rc][4 * i + g] : 0.0;
+    // ---- X' -= V' Z' on the slice I hold
+    const int pm = 4 * (n & 3) + (n >> 2);
+#pragma unroll
+    for (int u = 0; u < WIB_KB; ++u) {
+        if (u < nbk) {
+            double a4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = s_v[4 * i + g][16 * u + pm];
+            d4 o0 = d4{0.0, 0.0, 0.0, 0.0}, o1 = d4{0.0, 0.0, 0.0, 0.0};
+            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], z[0], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], z[1], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], z[2], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], z[3], o1, 0, 0, 0);
+            const int j0 = 16 * (b_lo + u) + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[u][i] -= o0[i] + o1[i];
+            if (valid) {
+                if (j0 + 3 < L) {
+                    *(dbl4*)(row + j0) = x[u];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (j0 + i < L) row[j0 + i] = x[u][i];
+                }
+            }
+        }
+    }
+}
+
 // out[e] = sum over the slices y < nsplit of part[y * count + e], in order (count = rows * LQW_BLOCK entries)
 __global__ __launch_bounds__(256) void k_wy_sum(const double* __restrict__ part, int nsplit, long count,
                                                 double* __restrict__ out) {

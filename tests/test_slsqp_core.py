@@ -767,6 +767,38 @@ def test_gpu_wide_sweep_on_side_streams_gives_the_bits_of_the_one_stream_order(m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,meq,mg", [(4300, 2000, 100), (2500, 470, 40)])
+def test_gpu_in_block_update_in_one_launch_gives_the_bits_of_the_three_launches(n, meq, mg, monkeypatch):
+    """Round 5: inside a 64-reflector block of the wide sweep the later panels' rows get each panel's reflectors from ONE
+    launch (``k_wy_inblock``: the column slices' workgroups exchange their shares of the products through memory and a
+    counter) instead of three (product over slices, finish, rank-16 update).  Same slices, same sums, same MFMA chains:
+    the BITS must be equal - a race in the exchange would show as a difference (three subproblems per handle; the second
+    shape has a partial last block and a partial last panel: 470 = 7 x 64 + 22 equalities)."""
+    rng = np.random.default_rng(n + 1)
+    Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+    A, cc = np.vstack([C, G]), np.concatenate([c, h])
+    results = {}
+    for form in ("one", "three"):
+        monkeypatch.delenv("OGSQP_WIDE_INBLOCK", raising=False)
+        if form == "three":
+            monkeypatch.setenv("OGSQP_WIDE_INBLOCK", "0")
+        core = _sqp_native.QpCore(n, meq, mg)
+        out = []
+        for rep in range(3):
+            core.set_factor(Z * (1.0 + 0.25 * rep))
+            core.set_active()
+            d, mult, bm, status, iters = core.solve(A, g, cc, lb, ub)
+            out.append((d.copy(), mult.copy(), status, iters))
+        assert core.recoveries() == 0
+        core.close()
+        results[form] = out
+    monkeypatch.delenv("OGSQP_WIDE_INBLOCK", raising=False)
+    for (d0, m0, s0, i0), (d1, m1, s1, i1) in zip(results["three"], results["one"]):
+        assert s0 == s1 == 1 and i0 == i1
+        assert np.array_equal(d0, d1) and np.array_equal(m0, m1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,meq,mg", [(1500, 300, 200), (2400, 300, 60)])
 def test_gpu_streamed_rows_give_the_bits_of_the_register_kernels(n, meq, mg, monkeypatch):
     """Round 5: rows of more than 1024 null-space coordinates are STREAMED by ``k_rows_apply_stream`` (run-time strips of

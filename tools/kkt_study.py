@@ -28,12 +28,13 @@ ap.add_argument("--ftol", default="1e-6,1e-8,1e-10")
 ap.add_argument("--restarts", type=int, default=None)
 ap.add_argument("--time-limit", type=float, default=240.0)
 ap.add_argument("--save-x", action="store_true")
+ap.add_argument("--jacobian", default="fd", choices=["fd", "exact"])
 a = ap.parse_args()
 for ftol in [float(v) for v in a.ftol.split(",")]:
     prob, obj = problems.build(a.workload)
     if a.restarts is not None:
         prob.maxIterator = a.restarts
-    opts = {"ftol": ftol, "sqp_core": "hip"}
+    opts = {"ftol": ftol, "sqp_core": "hip", "jacobian": a.jacobian}
     if a.maxiter is not None:
         opts["maxiter"] = a.maxiter
     t0 = time.perf_counter()
@@ -55,7 +56,7 @@ for ftol in [float(v) for v in a.ftol.split(",")]:
     res = prob.last_result
     k = kkt.residuals(prob, obj, res.x, prob._engine.m_eq)
     tm = prob.sqp_timings
-    print(json.dumps({"workload": a.workload, "ftol": ftol, "maxiter": a.maxiter, "exit_mode": int(res.status),
+    print(json.dumps({"workload": a.workload, "ftol": ftol, "jacobian": a.jacobian, "maxiter": a.maxiter, "exit_mode": int(res.status),
                       "stopped_by_time_limit": stopped, "wall_s": wall, "restarts": buf.getvalue().count("---- iteration"),
                       "qp_solves": int(sum(t["qp_solves"] for t in tm)), "cost": float(res.fun),
                       "kkt": {key: k[key] for key in ("kkt", "feasibility", "stationarity", "stationarity_2norm",

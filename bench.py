@@ -906,7 +906,7 @@ def main():
         result["cold_start_s"] = cold_start(a.workload, a.nodes)
         # (import -> traced -> compiled -> handle -> F and the whole Jacobian of the first point on the host)
         result["first_solve_s"] = result["cold_start_s"].get("total_s")
-    if world == 1 and rank == 0 and a.sqp_iterations > 0 and n + 1 <= 8192 and not a.quick:
+    if world == 1 and rank == 0 and a.sqp_iterations > 0 and n + 1 <= 16384 and not a.quick:
         # (round 4: C5 too - its subproblems take 0.07-0.15 s since the wide LQ sweep; the CPU checker of the first
         # subproblem needs minutes there and runs in tests/test_slsqp_core.py instead)
         result["sqp"] = sqp_leg(eng, prob, a.sqp_iterations,

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(AView A, int col0, int rows, co
                                                  int kblocks) {
     __shared__ double As[16][80];
     __shared__ double Bs[16][80];
-    __shared__ short s_list[512];
+    __shared__ short s_list[1024];
     __shared__ int s_count;
     const int j0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -2401,8 +2401,10 @@ struct og_qp_s {
     LqWideMail* wide_mail = nullptr;
     unsigned* wide_count = nullptr;    // monotone count of the panel workgroups' steps, ever
     unsigned wide_token = 0u;
-    bool wide_inblock = true;          // the later rows of a block get a panel's reflectors in ONE launch (k_wy_inblock);
-    unsigned wide_in_token = 0u;       // OGSQP_WIDE_INBLOCK=0: product over slices, finish, update as three launches
+    bool wide_inblock = false;         // OGSQP_WIDE_INBLOCK=1: the later rows of a block get a panel's reflectors in ONE
+    unsigned wide_in_token = 0u;       // launch (k_wy_inblock) instead of three (product over slices, finish, update) - same
+                                       // bits; measured at C5: 7.00 instead of 7.07 s over 121 subproblems, not worth a
+                                       // kernel that waits for its neighbours: off by default
     double* wy_part = nullptr;         // column slices of a product (k_wy_w with blockIdx.y > 0), summed by k_wy_sum
     size_t wy_part_cap = 0;
     double *wy_w = nullptr, *wy_m = nullptr, *wy_t = nullptr, *wy_small = nullptr;   // 2 x (rows x 64) coefficients, M, T = M^-1 (one per block of a sweep), 2 x (64 x 16)
@@ -2648,7 +2650,7 @@ int lq_sweep_wide(og_qp_s* qp, int msweep, int nq, int ldw, int k, hipStream_t s
 int launch_gemm(og_qp_s* qp, const AView& A, int col0, int rows, int nq, int ldw, double* out, const int* sel,
                 hipStream_t s) {
     const int kblocks = (nq + 15) / 16, mblocks = (rows + 63) / 64;
-    if (kblocks > 512) return fail(4, "og_qp_solve_dev: more than 8192 variables");
+    if (kblocks > 1024) return fail(4, "og_qp_solve_dev: more than 16384 variables");
     hipLaunchKernelGGL(k_gemm_map, dim3(kblocks, mblocks), dim3(256), 0, s, A, col0, rows, nq, sel, qp->gemm_map, kblocks);
     hipLaunchKernelGGL(k_gemm_tn, dim3((nq + 63) / 64, mblocks), dim3(256), 0, s, A, col0, rows, qp->Jw, ldw, nq, out, sel,
                        (const unsigned char*)qp->gemm_map, kblocks);
@@ -2718,10 +2720,13 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         return fail(4, "og_qp_create: null space of the equalities too large for the LDS-resident part of the "
                        "active-set update (n + 1 - m_eq = " + std::to_string(qc) + ")");
     }
-    if (n1 > (size_t)LQ_PT_MAX * LQ_CPT_MAX) {
+    // rows of up to 8192 entries can go through round 2's one-workgroup panels (the forms every other sweep falls back
+    // to); longer ones - up to 16384 - exist only for the column-split panels of the wide sweep (ogsqp_lqwide.h)
+    if (n1 > (size_t)LQW_SLAB * LQW_MAX) {
         delete qp;
-        return fail(4, "og_qp_create: more than " + std::to_string(LQ_PT_MAX * LQ_CPT_MAX - 1) + " variables");
+        return fail(4, "og_qp_create: more than " + std::to_string(LQW_SLAB * LQW_MAX - 1) + " variables");
     }
+    const bool beyond_fallback = n1 > (size_t)LQ_PT_MAX * LQ_CPT_MAX;
     int rc = 0;
     auto A = [&](auto** p, size_t cnt) { if (!rc) rc = dev_alloc(qp, p, cnt); };
     // Tc and diagL: the equalities, then the rows of a warm start (at most qcap of them) behind them in the sweep
@@ -2810,7 +2815,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
             if (!rc && hipMemset(qp->wide_count, 0, 4 * sizeof(unsigned)) != hipSuccess)
                 rc = fail(5, "og_qp_create: hipMemset failed");
             const char* inblock = getenv("OGSQP_WIDE_INBLOCK");
-            qp->wide_inblock = !(inblock && std::string(inblock) == "0");
+            qp->wide_inblock = inblock && std::string(inblock) == "1";
             if (!rc && hipMemset(qp->Vall, 0, vrows * ldw * sizeof(double)) != hipSuccess)
                 rc = fail(5, "og_qp_create: hipMemset failed");
             if (!rc) {
@@ -2842,6 +2847,11 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
                 return rc;
             }
             qp->lq_wide = true;
+        }
+        if (beyond_fallback && !qp->lq_wide) {
+            og_qp_destroy(qp);
+            return fail(4, "og_qp_create: rows of more than " + std::to_string(LQ_PT_MAX * LQ_CPT_MAX) +
+                               " entries need the wide sweep (OGSQP_LQ / OGSQP_WIDE must not turn it off)");
         }
         const char* spin = getenv("OGSQP_SPIN_LIMIT");
         if (spin && atoi(spin) > 0) qp->spin_limit = atoi(spin);
@@ -3457,6 +3467,8 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     int rc = qp_solve_attempt(qp, d_jt, ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status, iterations,
                               hip_stream, &lost);
     if (rc || !lost) return rc;
+    if (qp->n1 > LQ_PT_MAX * LQ_CPT_MAX)
+        return fail(7, "og_qp_solve_dev: an inter-workgroup wait gave up and rows of this length have no form without one");
     // The look-ahead sweep and the chained triangular solves hand data between workgroups of ONE launch and assume the
     // workgroups they wait for are resident; on a device shared with other streams, ranks or tenants that may not hold,
     // and a bounded wait gives up.  Nothing was committed: the subproblem is solved again with the forms that wait for

@@ -28,7 +28,7 @@
 
 constexpr int LQW_E = 8;                         // groups of 256 columns per workgroup: slabs of 2048 columns
 constexpr int LQW_SLAB = 256 * LQW_E;
-constexpr int LQW_MAX = 4;                       // workgroups per panel: rows of up to 8192 entries
+constexpr int LQW_MAX = 8;                       // workgroups per panel: rows of up to 16384 entries (round 5; 4 / 8192 before)
 constexpr int LQW_BLOCK = 64;                    // reflectors per block reflector
 
 // The mailbox of the column-split panel.  Every value is its own flag: a slot holds LQW_PENDING - a NaN with a payload no

@@ -628,6 +628,24 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
     // ---- one round trip for everything whose address is known: state, decision, the two vectors.  The vectors are the
     // same for every row: they live in LDS (in registers they cost 4 * TAIL VGPRs and the kernel one wavefront per SIMD)
     __shared__ double s_c[64 * TAIL];
+    // Short rows (up to 512 coordinates: C3) are requested WHOLE in the same trip, before the decision is known - a
+    // constraint row's address depends on nothing the decision says; the part the change does not touch is masked out
+    // of the registers afterwards (the launch is a chain of round trips, not of bytes: 7.1 us with the row requested
+    // after the decision).  Rows of the inverse (their address hangs on a list entry) and longer rows load late.
+    constexpr bool EARLY = TAIL <= 8;
+    const int r_first = w * ROWS_WAVES + wave;
+    const bool early = EARLY && r_first <= mg + nq;
+    double xe[EARLY ? TAIL : 1];
+    double dot_e = 0.0;
+    if (early) {
+        const double* row0 = r_first == mg + nq ? g.y : rows_ptr(g, r_first);
+#pragma unroll
+        for (int e = 0; e < (EARLY ? TAIL : 1); ++e) {
+            const int j = lane + 64 * e;
+            xe[e] = row0[j < nr ? j : 0];
+        }
+        dot_e = a.dots[r_first < mg + nq ? r_first : 0];
+    }
     const int phase = st->phase;
     const double ynorm = st->ynorm;
     const RowsDecision rec = *a.rec;
@@ -673,16 +691,28 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
         const bool is_y = r == nrows, is_inv = r > nrows;
         double* row = is_inv ? g.RI[0] + (long)a.slot[r - nrows - 1] * qcap : is_y ? g.y : rows_ptr(g, r);
         const int len = is_inv ? q0 : nrv;
-        double dot = (is_y || is_inv) ? 0.0 : a.dots[r];
-        const double xq = (kind == 1 && !is_inv) ? row[q0] : 0.0;
+        const bool have = early && r == r_first;              // (this wavefront's first row came with the first trip)
+        double dot = (is_y || is_inv) ? 0.0 : (have ? dot_e : a.dots[r]);
+        double xq = (kind == 1 && !is_inv && !have) ? row[q0] : 0.0;
         if (kind != 0) {
             double x[TAIL];
             // (the two sums of rounds 3-4, term for term: the normal's entries are zero below q0, the reflector's from q0 on)
             double acc_d = 0.0, acc_v = 0.0;
+            if (have) {
+                double pick = 0.0;
 #pragma unroll
-            for (int e = 0; e < TAIL; ++e) {
-                const int j = lane + 64 * e;
-                x[e] = (j < len && (j < q0 ? head : tail)) ? row[j] : 0.0;
+                for (int e = 0; e < (EARLY ? TAIL : 1); ++e) {
+                    const int j = lane + 64 * e;
+                    x[e] = (j < len && (j < q0 ? head : tail)) ? xe[e] : 0.0;
+                    if (e == (q0 >> 6)) pick = xe[e];
+                }
+                if (kind == 1) xq = __shfl(pick, q0 & 63);    // entry q0 of the row: lane q0 % 64 of strip q0 / 64
+            } else {
+#pragma unroll
+                for (int e = 0; e < TAIL; ++e) {
+                    const int j = lane + 64 * e;
+                    x[e] = (j < len && (j < q0 ? head : tail)) ? row[j] : 0.0;
+                }
             }
 #pragma unroll
             for (int e = 0; e < TAIL; ++e) {

@@ -139,9 +139,11 @@ class DeviceJacobian:
         return len(self.engine.devices) if self._last == "multi" else 1
 
 
-# capacity of the QP core (include/ogsqp.h, csrc/ogsqp.hip og_qp_create / rows_lds_bytes): row segments of the panel
-# kernels hold n + 1 <= 8192 entries; the active-set kernels keep three vectors of the null-space dimension in LDS
-MAX_N1 = 8192
+# capacity of the QP core (include/ogsqp.h, csrc/ogsqp.hip og_qp_create / rows_lds_bytes): the column-split panels of the
+# wide LQ sweep take rows of n + 1 <= 16384 entries (round 5; 8192 before - the reference, ``optimize.py:759-781``, has no
+# bound, SciPy's core just gets slower: hours per major iteration from 6 000 variables on); the active-set kernels keep
+# three vectors of the null-space dimension in LDS
+MAX_N1 = 16384
 MAX_NULL_SPACE = 6736
 
 

@@ -211,7 +211,7 @@ def test_auto_falls_back_to_scipys_core_when_the_hip_core_cannot_take_the_proble
     import types
     from opengoddard_amd import sqp
     from oracle import np_path
-    assert "8192" in sqp.prepare(types.SimpleNamespace(n=9000, m_eq=10))
+    assert "16384" in sqp.prepare(types.SimpleNamespace(n=17000, m_eq=10))
     assert "null space" in sqp.prepare(types.SimpleNamespace(n=8000, m_eq=100))
     reason = sqp.prepare(types.SimpleNamespace(n=300, m_eq=100))           # this container: torch without a GPU
     assert reason is not None and ("GPU" in reason or "torch" in reason)

@@ -769,7 +769,8 @@ def test_gpu_wide_sweep_on_side_streams_gives_the_bits_of_the_one_stream_order(m
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,meq,mg", [(4300, 2000, 100), (2500, 470, 40)])
 def test_gpu_in_block_update_in_one_launch_gives_the_bits_of_the_three_launches(n, meq, mg, monkeypatch):
-    """Round 5: inside a 64-reflector block of the wide sweep the later panels' rows get each panel's reflectors from ONE
+    """Round 5 (opt-in, ``OGSQP_WIDE_INBLOCK=1``; measured 1 % of a C5 subproblem, so the three launches stay the
+    default): inside a 64-reflector block of the wide sweep the later panels' rows get each panel's reflectors from ONE
     launch (``k_wy_inblock``: the column slices' workgroups exchange their shares of the products through memory and a
     counter) instead of three (product over slices, finish, rank-16 update).  Same slices, same sums, same MFMA chains:
     the BITS must be equal - a race in the exchange would show as a difference (three subproblems per handle; the second
@@ -779,9 +780,7 @@ def test_gpu_in_block_update_in_one_launch_gives_the_bits_of_the_three_launches(
     A, cc = np.vstack([C, G]), np.concatenate([c, h])
     results = {}
     for form in ("one", "three"):
-        monkeypatch.delenv("OGSQP_WIDE_INBLOCK", raising=False)
-        if form == "three":
-            monkeypatch.setenv("OGSQP_WIDE_INBLOCK", "0")
+        monkeypatch.setenv("OGSQP_WIDE_INBLOCK", "1" if form == "one" else "0")
         core = _sqp_native.QpCore(n, meq, mg)
         out = []
         for rep in range(3):

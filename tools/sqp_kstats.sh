@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 p=$1; it=$2; tag=${3:-sqp_$p}
 out=/tmp/sqpk_$tag
 ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o b -- python $R/tools/sqp_solve.py $p $it 1e-6 hip > $out.log 2>&1 )
-grep -v amdgpu.ids $out.log | tail -3
+grep -v amdgpu.ids $out.log | grep -v rocprofv3 | tail -3
 f=$(ls $out/*kernel_stats.csv 2>/dev/null | head -1)
 mkdir -p $R/gpurun_out
 [ -n "$f" ] && cp $f $R/gpurun_out/${tag}_kernel_stats.csv && python - "$f" <<'PY'

@@ -917,7 +917,8 @@ def main():
         try:
             result["solve"] = solve_leg(a.workload)
             if a.workload == "polar_tsto":
-                result["solve"]["also"] = [solve_leg("low_thrust")]
+                # C4 with the reference's defaults, and with the tolerance at which SLSQP's exit test means a KKT point
+                result["solve"]["also"] = [solve_leg("low_thrust"), solve_leg("low_thrust", {"ftol": 1e-8, "maxiter": 400})]
         except Exception as exc:                               # a failed leg must not lose the line
             result["solve"] = {"error": repr(exc)}
     if ranks_report is not None:

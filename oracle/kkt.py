@@ -54,9 +54,11 @@ def central_jacobian(prob, obj, x, columns=None):
     return F0, JT
 
 
-def residuals(prob, obj, x, m_eq, active_tol=1e-6, bound_tol=1e-9, jacobian=None):
+def residuals(prob, obj, x, m_eq, active_tol=1e-6, bound_tol=1e-9, jacobian=None, max_rounds=200):
     """KKT residuals of the reference's NLP at ``x`` (see the module text).  ``jacobian=(F0, JT)`` lets a caller that
-    already has the oracle's Jacobian hand it in.  Returns a dict of plain floats / ints."""
+    already has the oracle's Jacobian hand it in; ``max_rounds`` bounds the number of fits (each a dense least-squares
+    problem of n x active rows: a quarter of a minute at C5) - rows still priced negative then show in ``dual``.
+    Returns a dict of plain floats / ints."""
     x = np.asarray(x, dtype=float)
     n = x.size
     lb, ub = np_path.bounds_arrays(prob)
@@ -80,7 +82,7 @@ def residuals(prob, obj, x, m_eq, active_tol=1e-6, bound_tol=1e-9, jacobian=None
     act = list(act)
     at_lo, at_up = list(at_lo), list(at_up)
     floor = None                                              # stationarity no choice of multipliers on these rows beats
-    for _ in range(200):
+    for _ in range(max(1, int(max_rounds))):
         fixed = np.array(at_lo + at_up, dtype=int)
         free = np.setdiff1d(np.arange(n), fixed)
         M = np.hstack([Aeq, Ain[:, act]])

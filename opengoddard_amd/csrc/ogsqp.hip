@@ -2417,7 +2417,8 @@ struct og_qp_s {
     bool wide_ahead = false;
     std::vector<hipEvent_t> ev_t, ev_tc;   // per block: T is there (caller's stream) / the rest of C Z has it applied (lane 1)
     hipEvent_t ev_join[2] = {nullptr, nullptr};
-    int spin_limit = 1 << 25;          // bound of the inter-workgroup waits (OGSQP_SPIN_LIMIT: tests force a loss with 1)
+    int spin_limit = 1 << 19;          // bound of the inter-workgroup waits: polls of ~1.5 us each, i.e. about a second (2^25 - a
+                                       // minute per lost wait - until round 5); OGSQP_SPIN_LIMIT: tests force a loss with 1
     int recoveries = 0;                // subproblems re-run with the separate-launch forms after a wait gave up
     bool lq_ahead = true;              // OGSQP_LQ=16: panel and trailing update as separate launches
     int trsv_mode = 0;                 // OGSQP_TRSV: 0 one chained launch, 1 ("block") a launch per block, 2 ("single")

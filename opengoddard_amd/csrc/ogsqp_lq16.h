@@ -304,7 +304,7 @@ struct Lq16Head {
 __device__ __forceinline__ void lq_wait_for(unsigned* word, unsigned expect, int* lost, int spin_limit) {
     int spins = 0;
     while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
-        if (++spins > spin_limit) {    // (2^25 by default, about a second: a workgroup that comes this late is not coming)
+        if (++spins > spin_limit) {    // (2^19 polls by default, about a second: a workgroup that comes this late is not coming)
             __hip_atomic_store(lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }

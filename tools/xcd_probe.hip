@@ -26,6 +26,8 @@ __device__ __forceinline__ void store_l2(double* p, double v) {
 }
 
 // mode 0: agent-scope atomics; mode 1: sc0 loads / stores (coherent in the XCD's L2 only)
+// (every wait is bounded by 200 000 polls, and the first wait that gives up ends the kernel on BOTH sides through a flag
+// polled with agent scope: accesses that are not coherent between the two workgroups are a result, not a hang)
 __global__ void pingpong(double* mail, int partner, int trips, int mode, long long* ticks, int* xcc) {
     const int b = blockIdx.x;
     if (b != 0 && b != partner) return;
@@ -35,28 +37,37 @@ __global__ void pingpong(double* mail, int partner, int trips, int mode, long lo
     xcc[b == 0 ? 0 : 1] = x;
     double* mine = mail + (b == 0 ? 0 : 64);
     double* theirs = mail + (b == 0 ? 64 : 0);
+    int* gave_up = (int*)(mail + 128);
     const long long t0 = __builtin_amdgcn_s_memrealtime();
+    int done = 0;
     for (int k = 1; k <= trips; ++k) {
         if (b == 0) {
             if (mode == 0) __hip_atomic_store(mine, (double)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else store_l2(mine, (double)k);
-            long spins = 0;
-            while (true) {
-                const double v = mode == 0 ? __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : load_l2(theirs);
-                if (v == (double)k || ++spins > 100000000) break;
-            }
-        } else {
-            long spins = 0;
-            while (true) {
-                const double v = mode == 0 ? __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : load_l2(theirs);
-                if (v == (double)k || ++spins > 100000000) break;
-            }
+        }
+        long spins = 0;
+        bool ok = false;
+        while (true) {
+            const double v = mode == 0 ? __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : load_l2(theirs);
+            if (v == (double)k) { ok = true; break; }
+            if (++spins > 200000 || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+        if (!ok) {
+            __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (b != 0) {
             if (mode == 0) __hip_atomic_store(mine, (double)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else store_l2(mine, (double)k);
         }
+        done = k;
     }
-    if (b == 0) ticks[0] = __builtin_amdgcn_s_memrealtime() - t0;
+    if (b == 0) {
+        ticks[0] = __builtin_amdgcn_s_memrealtime() - t0;
+        ticks[1] = done;
+    }
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     int *xcc, *hw;
     CK(hipMalloc(&xcc, 4096 * 4));
     CK(hipMalloc(&hw, 4096 * 4));
@@ -81,12 +92,16 @@ int main() {
             const int trips = 2000;
             hipLaunchKernelGGL(pingpong, dim3(partner + 1), dim3(64), 0, 0, mail, partner, trips, mode, ticks, xcc);
             CK(hipDeviceSynchronize());
-            long long t;
+            long long t[2];
             int x[2];
-            CK(hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(t, ticks, 16, hipMemcpyDeviceToHost));
             CK(hipMemcpy(x, xcc, 8, hipMemcpyDeviceToHost));
-            printf("ping-pong workgroups 0 <-> %2d (XCC %d / %d), %s: %.0f ns per round trip (two hand-offs)\n", partner, x[0], x[1],
-                   mode == 0 ? "agent-scope atomics" : "sc0 store / sc0 load   ", t * 10.0 / trips);
+            if (t[1] == trips)
+                printf("ping-pong workgroups 0 <-> %2d (XCC %d / %d), %s: %.0f ns per round trip (two hand-offs)\n", partner, x[0],
+                       x[1], mode == 0 ? "agent-scope atomics" : "sc0 store / sc0 load   ", t[0] * 10.0 / trips);
+            else
+                printf("ping-pong workgroups 0 <-> %2d (XCC %d / %d), %s: NOT COHERENT - gave up in round trip %lld\n", partner,
+                       x[0], x[1], mode == 0 ? "agent-scope atomics" : "sc0 store / sc0 load   ", t[1] + 1);
         }
     }
     return 0;

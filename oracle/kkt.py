@@ -82,7 +82,8 @@ def residuals(prob, obj, x, m_eq, active_tol=1e-6, bound_tol=1e-9, jacobian=None
     act = list(act)
     at_lo, at_up = list(at_lo), list(at_up)
     floor = None                                              # stationarity no choice of multipliers on these rows beats
-    for _ in range(max(1, int(max_rounds))):
+    rounds = max(1, int(max_rounds))
+    for round_no in range(rounds):
         fixed = np.array(at_lo + at_up, dtype=int)
         free = np.setdiff1d(np.arange(n), fixed)
         M = np.hstack([Aeq, Ain[:, act]])
@@ -96,7 +97,7 @@ def residuals(prob, obj, x, m_eq, active_tol=1e-6, bound_tol=1e-9, jacobian=None
         signed = np.concatenate([lam[m_eq:], z_lo, z_up])
         worst = float(np.min(signed, initial=0.0))
         scale = max(1.0, float(np.max(np.abs(lam), initial=0.0)), float(np.max(np.abs(signed), initial=0.0)))
-        if worst >= -1e-9 * scale:
+        if worst >= -1e-9 * scale or round_no == rounds - 1:   # (the last fit stands as it is: what is still negative shows in `dual`)
             break
         drop = signed <= 0.5 * worst
         ka, kl = len(act), len(at_lo)

@@ -157,24 +157,39 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16_wide(double* __restr
                 } else if (lane < 2 * LQ16 && first) {
                     __hip_atomic_store(mine + lane, s_xpc[b & 1][lane - LQ16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // lanes 0-15: row `lane`'s partial products of all workgroups; lanes 16-31: workgroup 0's pivot-column entries
-                double total = 0.0;
+                // lanes 0-15: row `lane`'s partial products of all workgroups; lanes 16-31: workgroup 0's pivot-column entries.
+                // (round 5: the slots of ALL workgroups are requested together and polled together - one trip through memory
+                // per exchange.  Until round 4 a lane waited for workgroup 0's slot, then asked for workgroup 1's, ...: nwg
+                // dependent trips of ~0.7 us, 2-3 us of every reflector step at C5.  The total is added up in the order of
+                // the workgroups as before: same bits.)
                 if (lane < 2 * LQ16) {
-                    const int w_lo = lane < LQ16 ? 0 : 0, w_hi = lane < LQ16 ? nwg : 1;
-                    for (int w = w_lo; w < w_hi; ++w) {
-                        const double* src = &mail->v[gen][b][w][lane];
-                        double val = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        int spins = 0;
-                        while ((unsigned long long)__double_as_longlong(val) == LQW_PENDING) {
-                            if (++spins > spin_limit) {
-                                __hip_atomic_store(lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                            val = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int w_hi = lane < LQ16 ? nwg : 1;
+                    double val[LQW_MAX];
+#pragma unroll
+                    for (int w = 0; w < LQW_MAX; ++w)
+                        val[w] = w < w_hi ? __hip_atomic_load(&mail->v[gen][b][w][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : 0.0;
+                    int spins = 0;
+                    while (true) {
+                        bool pending = false;
+#pragma unroll
+                        for (int w = 0; w < LQW_MAX; ++w)
+                            pending = pending || (w < w_hi && (unsigned long long)__double_as_longlong(val[w]) == LQW_PENDING);
+                        if (!pending) break;
+                        if (++spins > spin_limit) {
+                            __hip_atomic_store(lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
                         }
-                        total += val;
+                        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int w = 0; w < LQW_MAX; ++w)
+                            if (w < w_hi && (unsigned long long)__double_as_longlong(val[w]) == LQW_PENDING)
+                                val[w] = __hip_atomic_load(&mail->v[gen][b][w][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    double total = 0.0;
+#pragma unroll
+                    for (int w = 0; w < LQW_MAX; ++w)
+                        if (w < w_hi) total += val[w];
                     if (lane < LQ16) s_tot[lane] = total;
                     else s_pc[lane - LQ16] = total;
                 }

@@ -19,3 +19,6 @@ cut -c1-200 gpurun_out/r05_bench_driver_style.json
 for w in polar_tsto low_thrust launch4; do
   OG_MODULE_HIPFLAGS=-DOGK_TRACE=1 OGPSX_TRACE=1 OGPSX_SWEEP=fused timeout 600 python tools/trace_fused.py $w 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_trace_fused_$w.txt
 done
+( timeout 300 python tools/stress_sqp.py polar_tsto 100; timeout 300 python tools/stress_sqp.py launch4 12 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_stress_sqp.txt
+timeout 300 python tools/stress_determinism.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_stress_determinism.txt
+tail -3 gpurun_out/r05_stress_sqp.txt gpurun_out/r05_stress_determinism.txt

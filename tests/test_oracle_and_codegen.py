@@ -15,7 +15,7 @@ from opengoddard_amd import trace as tr
 from oracle import np_path, program_eval, twin
 
 ALL = problems.NAMES
-SHIPPED_TWINS = {"ex01": "cfg_brachistochrone", "ex04": "cfg_goddard",
+SHIPPED_TWINS = {"ex01": "cfg_brachistochrone", "ex04": "cfg_goddard", "ex05": "cfg_goddard_1knot", "ex08": "cfg_polar_ssto",
                  "ex09": "cfg_polar_tsto_shipped", "ex10": "cfg_low_thrust_shipped"}
 
 

@@ -2375,7 +2375,7 @@ struct og_qp_s {
     unsigned* bar = nullptr;
     int* abort_flag = nullptr;
     int gi_mode = 0;                   // 0 rows (k_rows_decide / k_rows_apply, the default), 1 the two older kernels
-    int rows_stage = 0;                // ... their second pass out of LDS: 0 where two workgroups fit a compute unit, 1 / -1 forced
+    int rows_stage = 0;                // ... their second pass out of LDS instead of the caches: only when forced (1)
     bool rows_stream = true;           // rows of more than 1024 null-space coordinates are streamed (k_rows_apply_stream);
                                        // OGSQP_ROWS=reg: the register kernels k_rows_apply<TAIL> for every length
     bool warm_enabled = true;          // start the active-set method from the previous subproblem's active rows
@@ -3210,9 +3210,9 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
         // long rows are streamed, the row staged in LDS when five vectors of the null space fit a workgroup's share
         const size_t nrp = (size_t)tail_lanes * 64;
         const bool stream = qp->rows_stream && tail_lanes > 16;
-        // (two workgroups per compute unit at least; OGSQP_ROWS=stage / nostage force one form where it fits)
-        const bool stage = stream && qp->rows_stage >= 0 &&
-                           5 * nrp * sizeof(double) <= (qp->rows_stage > 0 ? LDS_LIMIT : (size_t)64 * 1024);
+        // (the second pass re-reads the row from the caches by default: staging it in LDS - OGSQP_ROWS=stage, where five
+        // vectors fit - costs the occupancy the streamed form lives on: 111 instead of 47 us per change at C5)
+        const bool stage = stream && qp->rows_stage > 0 && 5 * nrp * sizeof(double) <= LDS_LIMIT;
         const size_t lds2 = (stage ? 5 : 1) * nrp * sizeof(double);
 #define OG_ROWS_APPLY()                                                                                      \
     do {                                                                                                     \

@@ -796,6 +796,130 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
     }
 }
 
+// Rounds 3-4's form of the pass (both vectors and the lane masks in registers, the row requested after the decision):
+// kept selectable (OGSQP_ROWS=r4) for rows of up to 1024 coordinates, where it is measured against the form above.
+template <int TAIL>
+__global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply_r4(RowsArgs a) {
+    __shared__ double redv[ROWS_WAVES];
+    __shared__ int redi[ROWS_WAVES];
+    const GiArgs& g = a.g;
+    GiState* st = g.st;
+    if (st->phase >= 2) return;
+    const RowsDecision rec = *a.rec;
+    const int kind = rec.kind;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
+    const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
+    const int q0 = rec.q;
+    const int nrows = mg + nq;
+    const bool moves = (kind == 1 || kind == 2) && !rec.dependent;
+    const bool leaves = kind == 2 || kind == 3;
+    const double slack = FEASIBLE * st->ynorm;
+    // per lane: the incoming normal's tail (d2, zero on the first q0 coordinates) and the leaving reflector's vector
+    double dreg[TAIL], vreg[TAIL];
+#pragma unroll
+    for (int e = 0; e < TAIL; ++e) {
+        const int j = lane + 64 * e;
+        dreg[e] = (moves && j >= q0 && j < nr) ? a.dvec[j] : 0.0;
+        vreg[e] = (leaves && j < q0) ? a.vvec[j] : 0.0;
+    }
+    double best = INFINITY;
+    int besti = 0x7fffffff;
+    const int extra = leaves ? q0 - 1 : 0;                 // rows of the inverse that stay (positions after the shift)
+    for (int r = w * ROWS_WAVES + wave; r <= nrows + extra; r += a.G2 * ROWS_WAVES) {
+        const bool is_y = r == nrows, is_inv = r > nrows;
+        double* row = is_inv ? g.RI[0] + (long)a.slot[r - nrows - 1] * qcap : is_y ? g.y : rows_ptr(g, r);
+        const int len = is_inv ? q0 : nr;
+        double dot = (is_y || is_inv) ? 0.0 : a.dots[r];
+        const double xq = (kind == 1 && !is_inv) ? row[q0] : 0.0;
+        if (kind != 0) {
+            double x[TAIL];
+            double acc_d = 0.0, acc_v = 0.0;
+            // the first q0 coordinates of a row matter when a row leaves (its reflector lives there) and for the
+            // values after a warm start; the tail when the incoming row moves the point - a full step at q0 = 300
+            // of 468 coordinates streams a third of the matrix
+            const bool head = leaves || kind == 4, tail = moves;
+#pragma unroll
+            for (int e = 0; e < TAIL; ++e) {
+                const int j = lane + 64 * e;
+                x[e] = (j < len && (j < q0 ? head : tail)) ? row[j] : 0.0;
+                acc_d += x[e] * dreg[e];
+                acc_v += x[e] * vreg[e];
+            }
+            if (kind == 4) {
+                if (!is_y) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int e = 0; e < TAIL; ++e) {
+                        const int j = lane + 64 * e;
+                        acc += (j < q0) ? x[e] * g.y[j] : 0.0;
+                    }
+                    dot = wave_sum(acc);
+                    if (lane == 0) a.dots[r] = dot;
+                }
+            } else {
+                if (moves && !is_inv && (kind == 1 || !is_y)) {
+                    const double gi = wave_sum(acc_d);
+                    if (!is_y) {
+                        dot += rec.t * gi;
+                        if (lane == 0) a.dots[r] = dot;
+                    }
+                    if (kind == 1) {
+                        // reflector of the incoming row on the tail: v = d2 - alpha e_q0
+                        const double f = rec.beta * (gi - rec.alpha * xq);
+#pragma unroll
+                        for (int e = 0; e < TAIL; ++e) {
+                            const int j = lane + 64 * e;
+                            if (j >= q0 && j < nr) row[j] = x[e] - f * (dreg[e] - (j == q0 ? rec.alpha : 0.0));
+                        }
+                    }
+                }
+                if (leaves) {
+                    // reflector of the leaving row on the first q0 coordinates
+                    const double f = rec.beta_out * wave_sum(acc_v);
+#pragma unroll
+                    for (int e = 0; e < TAIL; ++e) {
+                        const int j = lane + 64 * e;
+                        if (j < q0) row[j] = x[e] - f * vreg[e];
+                    }
+                }
+            }
+        }
+        if (is_y || is_inv || leaves) continue;            // the same row p goes on after a removal: no pricing
+        if (r < mg) {
+            if (g.scale[r] > 0.0 && !g.isact[r]) {
+                const double v = (g.bval[r] + dot) / g.scale[r] + g.own[r] + slack;
+                if (v < best || (v == best && r < besti)) {
+                    best = v;
+                    besti = r;
+                }
+            }
+        } else {
+            const int lo = r, hi = r + nq;
+            if (g.scale[lo] > 0.0 && !g.isact[lo]) {
+                const double v = (g.bval[lo] + dot) / g.scale[lo] + g.own[lo] + slack;
+                if (v < best || (v == best && lo < besti)) {
+                    best = v;
+                    besti = lo;
+                }
+            }
+            if (g.scale[hi] > 0.0 && !g.isact[hi]) {
+                const double v = (g.bval[hi] - dot) / g.scale[hi] + g.own[hi] + slack;
+                if (v < best || (v == best && hi < besti)) {
+                    best = v;
+                    besti = hi;
+                }
+            }
+        }
+    }
+    if (!leaves) {
+        block_argmin(best, besti, redv, redi);
+        if (tid == 0) {
+            a.price[w].value = best;
+            a.price[w].index = besti;
+        }
+    }
+}
+
 // Long rows (more than 16 x 64 null-space coordinates: C5's 2017).  Holding such a row in registers - 2 * TAIL of them,
 // with TAIL lane masks per comparison - cost the register kernel its occupancy: 256 VGPRs + 232 AGPRs, ONE wavefront
 // per SIMD, the 8 199 rows of C5 in eight residency rounds of round trips, 80 us per change for 143 MB (1.8 TB/s).

@@ -2375,7 +2375,9 @@ struct og_qp_s {
     unsigned* bar = nullptr;
     int* abort_flag = nullptr;
     int gi_mode = 0;                   // 0 rows (k_rows_decide / k_rows_apply, the default), 1 the two older kernels
-    bool rows_r4 = false;              // OGSQP_ROWS=r4: rounds 3-4's register kernel for rows of up to 1024 coordinates
+    int rows_r4 = 0;                   // rounds 3-4's register form of the pass (k_rows_apply_r4): 0 for rows of up to 512
+                                       // coordinates, where it measured faster (C3: 6.8-7.0 against 8.0 us; C4's 589 coordinates:
+                                       // 10.9 against 9.0 us for this round's form), 1 (OGSQP_ROWS=r4) up to 1024, -1 (=lds) never
     int rows_stage = 0;                // ... their second pass out of LDS instead of the caches: only when forced (1)
     bool rows_stream = true;           // rows of more than 1024 null-space coordinates are streamed (k_rows_apply_stream);
                                        // OGSQP_ROWS=reg: the register kernels k_rows_apply<TAIL> for every length
@@ -2795,7 +2797,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         if (qp->gi_mode == 1 && gi_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) qp->gi_mode = 0;
         const char* rowsk = getenv("OGSQP_ROWS");
         qp->rows_stream = !(rowsk && std::string(rowsk) == "reg");
-        qp->rows_r4 = rowsk && std::string(rowsk) == "r4";
+        qp->rows_r4 = (rowsk && std::string(rowsk) == "r4") ? 1 : (rowsk && std::string(rowsk) == "lds") ? -1 : 0;
         qp->rows_stage = (rowsk && std::string(rowsk) == "stage") ? 1 : (rowsk && std::string(rowsk) == "nostage") ? -1 : 0;
         const char* lq = getenv("OGSQP_LQ");
         qp->lq16 = !(lq && std::string(lq) == "8");
@@ -3220,8 +3222,8 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
     do {                                                                                                     \
         if (stream && stage) hipLaunchKernelGGL(k_rows_apply_stream<true>, dim3(ra.G2), dim3(ROWS_THREADS), lds2, s, ra); \
         else if (stream) hipLaunchKernelGGL(k_rows_apply_stream<false>, dim3(ra.G2), dim3(ROWS_THREADS), lds2, s, ra); \
-        else if (qp->rows_r4 && tail_lanes <= 8) hipLaunchKernelGGL(k_rows_apply_r4<8>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
-        else if (qp->rows_r4 && tail_lanes <= 16) hipLaunchKernelGGL(k_rows_apply_r4<16>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
+        else if (qp->rows_r4 >= 0 && tail_lanes <= 8) hipLaunchKernelGGL(k_rows_apply_r4<8>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
+        else if (qp->rows_r4 > 0 && tail_lanes <= 16) hipLaunchKernelGGL(k_rows_apply_r4<16>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
         else if (tail_lanes <= 8) hipLaunchKernelGGL(k_rows_apply<8>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra);   \
         else if (tail_lanes <= 16) hipLaunchKernelGGL(k_rows_apply<16>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
         else if (tail_lanes <= 32) hipLaunchKernelGGL(k_rows_apply<32>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \

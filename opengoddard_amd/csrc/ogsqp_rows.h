@@ -796,8 +796,11 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
     }
 }
 
-// Rounds 3-4's form of the pass (both vectors and the lane masks in registers, the row requested after the decision):
-// kept selectable (OGSQP_ROWS=r4) for rows of up to 1024 coordinates, where it is measured against the form above.
+// Rounds 3-4's form of the pass (both vectors and the lane masks in registers, the row requested after the decision).
+// Measured against the form above (profiles/r05_rows_ab.txt; same bits): rows of up to 512 coordinates (TAIL = 8, C3)
+// 6.8-7.0 us against 8.0 - the barrier behind the vector's way through LDS costs more than the round trip it saves, and
+// 104 VGPRs never were the problem at this size: THIS form stays the default there; 589 coordinates (TAIL = 16, C4) 10.9 us
+// against 9.0: the form above.  OGSQP_ROWS=r4 / lds force one of them for rows of up to 1024 coordinates.
 template <int TAIL>
 __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply_r4(RowsArgs a) {
     __shared__ double redv[ROWS_WAVES];

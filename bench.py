@@ -676,19 +676,23 @@ def main():
 
     d_F0 = sweeps[0].F0
 
+    # (every address resolved once: a tensor slice and four data_ptr() per launch cost the host more than the launch
+    #  costs the GPU, and a batch of launches between two events then measures the host)
+    block_ptrs = [sh.replica[lo:hi].data_ptr() if hi > lo else sh.replica.data_ptr() for sh in sweeps]
+    x_ptr, h_ptr, f0_ptr = d_x.data_ptr(), d_h.data_ptr(), d_F0.data_ptr()
+
     def block_ptr():
-        sh = sweeps[counter[0] % nbuf]
         counter[0] += 1
-        return sh.replica[lo:hi].data_ptr() if hi > lo else sh.replica.data_ptr()
+        return block_ptrs[counter[0] % nbuf]
 
     def launch_sweep():
-        eng.sweep_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, block_ptr(), d_F0.data_ptr(), stream)
+        eng.sweep_dev(x_ptr, h_ptr, lo, hi, block_ptr(), f0_ptr, stream)
 
     def launch_columns():
-        eng.columns_dev(d_x.data_ptr(), d_h.data_ptr(), lo, hi, block_ptr(), d_F0.data_ptr(), stream)
+        eng.columns_dev(x_ptr, h_ptr, lo, hi, block_ptr(), f0_ptr, stream)
 
     def launch_eval():
-        eng.eval_dev(d_x.data_ptr(), d_F0.data_ptr(), stream)
+        eng.eval_dev(x_ptr, f0_ptr, stream)
 
     fused = eng.sweep_mode == "fused"
     kernel = "ogk_fused" if fused else "ogk_sweep"

@@ -87,6 +87,25 @@ class HipBackend:
         if hi > lo:
             self.engine.register_jt_dev(replica[lo:hi].data_ptr(), lo, hi, self.stream)
 
+    def bind_local_sweep(self, lo, hi, replica, F0):
+        """``run(x_ptr, h_ptr)`` that enqueues this rank's block (``og_fd_sweep_dev``) with everything that does not
+        change from step to step resolved ONCE - the view of the block, its address, F0's, the handle, the stream.  Per
+        step a host then pays one ctypes call; through :meth:`sweep` it paid a tensor slice, four ``data_ptr()`` and three
+        Python frames more, ~7 us in all against the launch's 6.1-6.6 us on the GPU: the loop was bound by the HOST
+        (round 5; ``bench.py``'s ``hip_graph_replay`` had been saying so since round 2)."""
+        if hi <= lo:
+            return None
+        from . import _native
+        fn, handle, stream = self._lib.og_fd_sweep_dev, self.engine._handle, self.stream
+        block, f0 = replica[lo:hi].data_ptr(), F0.data_ptr()
+        lo, hi = int(lo), int(hi)
+
+        def run(x_ptr, h_ptr):
+            rc = fn(handle, x_ptr, h_ptr, lo, hi, block, f0, stream)
+            if rc:
+                _native.check(rc, "og_fd_sweep_dev")
+        return run
+
     def sweep(self, x, h, lo, hi, replica, F0):
         if hi > lo:
             self.engine.sweep_dev(x.data_ptr(), h.data_ptr(), lo, hi, replica[lo:hi].data_ptr(), F0.data_ptr(),
@@ -185,6 +204,8 @@ class ShardedSweep:
         self.send = backend.zeros(max(self.block_vals, 1))
         self.recv = backend.empty(max(self.block_vals, 1) * self.world)
         backend.register_block(self.replica, self.lo, self.hi)
+        bind = getattr(backend, "bind_local_sweep", None)
+        self._local = bind(self.lo, self.hi, self.replica, self.F0) if bind else None
 
     @property
     def message_bytes(self):
@@ -194,7 +215,10 @@ class ShardedSweep:
         """``x``, ``h``: device vectors of the backend.  ``gather=False`` stops after this rank's own block."""
         be = self.backend
         if not gather or (self.world == 1 and not self.exchange_alone):
-            be.sweep(x, h, self.lo, self.hi, self.replica, self.F0)
+            if self._local is not None:
+                self._local(x.data_ptr(), h.data_ptr())
+            else:
+                be.sweep(x, h, self.lo, self.hi, self.replica, self.F0)
             return self.replica
         if hasattr(be, "sweep_and_pack"):
             be.sweep_and_pack(self.rank, x, h, self.lo, self.hi, self.replica, self.F0, self.send)

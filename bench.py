@@ -549,12 +549,14 @@ def main():
     lo, hi = sweeps[0].lo, sweeps[0].hi
     counter = [0]
 
+    # one pass of the hot path: F(x0) and this rank's FD columns (og_fd_sweep_dev: ONE launch, ogk_fused), then - with
+    # more than one rank - pack, all-gather of the packed non-zeros (RCCL), scatter.  The calls are bound once per output
+    # buffer (sharding.ShardedSweep.bound_step): a step costs the host one ctypes call, so that the loop measures the GPU
+    bound = {flag: [sh.bound_step(d_x, d_h, gather=flag and collective) for sh in sweeps] for flag in (True, False)}
+
     def step(gather=True):
-        # one pass of the hot path: F(x0) and this rank's FD columns (og_fd_sweep_dev: ONE launch, ogk_fused),
-        # then - with more than one rank - pack, all-gather of the packed non-zeros (RCCL), scatter
-        sh = sweeps[counter[0] % nbuf]
         counter[0] += 1
-        sh.step(d_x, d_h, gather=gather and collective)
+        bound[gather][counter[0] % nbuf]()
 
     def fence():
         if collective:

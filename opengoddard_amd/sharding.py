@@ -211,6 +211,19 @@ class ShardedSweep:
     def message_bytes(self):
         return 8 * self.block_vals
 
+    def bound_step(self, x, h, gather=True):
+        """A zero-argument callable doing ``step(x, h, gather)`` for these two device vectors: where the step is this
+        rank's block alone (one rank, or ``gather=False``) every address is captured and the call is the ctypes call
+        and nothing else."""
+        if self._local is not None and (not gather or (self.world == 1 and not self.exchange_alone)):
+            local, x_ptr, h_ptr = self._local, x.data_ptr(), h.data_ptr()
+            keep = (x, h)                                   # (the vectors must outlive the callable)
+
+            def run(local=local, x_ptr=x_ptr, h_ptr=h_ptr, keep=keep):
+                local(x_ptr, h_ptr)
+            return run
+        return lambda: self.step(x, h, gather=gather)
+
     def step(self, x, h, gather=True):
         """``x``, ``h``: device vectors of the backend.  ``gather=False`` stops after this rank's own block."""
         be = self.backend

@@ -553,6 +553,10 @@ def main():
     # more than one rank - pack, all-gather of the packed non-zeros (RCCL), scatter.  The calls are bound once per output
     # buffer (sharding.ShardedSweep.bound_step): a step costs the host one ctypes call, so that the loop measures the GPU
     bound = {flag: [sh.bound_step(d_x, d_h, gather=flag and collective) for sh in sweeps] for flag in (True, False)}
+    if os.environ.get("OG_BENCH_UNBOUND"):                 # A/B: rounds 1-4's per-step Python path (slice, data_ptr, three frames)
+        bound = {flag: [(lambda sh=sh, flag=flag: sh.backend.sweep(d_x, d_h, sh.lo, sh.hi, sh.replica, sh.F0)
+                         if not (flag and collective) else sh.step(d_x, d_h, gather=True)) for sh in sweeps]
+                 for flag in (True, False)}
 
     def step(gather=True):
         counter[0] += 1

@@ -551,7 +551,8 @@ def main():
 
     # one pass of the hot path: F(x0) and this rank's FD columns (og_fd_sweep_dev: ONE launch, ogk_fused), then - with
     # more than one rank - pack, all-gather of the packed non-zeros (RCCL), scatter.  The calls are bound once per output
-    # buffer (sharding.ShardedSweep.bound_step): a step costs the host one ctypes call, so that the loop measures the GPU
+    # buffer (sharding.ShardedSweep.bound_step): a step costs the host one ctypes call (A/B against the per-step Python
+    # path, OG_BENCH_UNBOUND=1, in one lease: no difference - profiles/r05_host_ab.txt; the loop is GPU-bound either way)
     bound = {flag: [sh.bound_step(d_x, d_h, gather=flag and collective) for sh in sweeps] for flag in (True, False)}
     if os.environ.get("OG_BENCH_UNBOUND"):                 # A/B: rounds 1-4's per-step Python path (slice, data_ptr, three frames)
         bound = {flag: [(lambda sh=sh, flag=flag: sh.backend.sweep(d_x, d_h, sh.lo, sh.hi, sh.replica, sh.F0)
@@ -682,8 +683,7 @@ def main():
 
     d_F0 = sweeps[0].F0
 
-    # (every address resolved once: a tensor slice and four data_ptr() per launch cost the host more than the launch
-    #  costs the GPU, and a batch of launches between two events then measures the host)
+    # (every address resolved once per buffer instead of a tensor slice and four data_ptr() per launch)
     block_ptrs = [sh.replica[lo:hi].data_ptr() if hi > lo else sh.replica.data_ptr() for sh in sweeps]
     x_ptr, h_ptr, f0_ptr = d_x.data_ptr(), d_h.data_ptr(), d_F0.data_ptr()
 

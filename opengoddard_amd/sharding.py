@@ -89,10 +89,10 @@ class HipBackend:
 
     def bind_local_sweep(self, lo, hi, replica, F0):
         """``run(x_ptr, h_ptr)`` that enqueues this rank's block (``og_fd_sweep_dev``) with everything that does not
-        change from step to step resolved ONCE - the view of the block, its address, F0's, the handle, the stream.  Per
-        step a host then pays one ctypes call; through :meth:`sweep` it paid a tensor slice, four ``data_ptr()`` and three
-        Python frames more, ~7 us in all against the launch's 6.1-6.6 us on the GPU: the loop was bound by the HOST
-        (round 5; ``bench.py``'s ``hip_graph_replay`` had been saying so since round 2)."""
+        change from step to step resolved ONCE - the view of the block, its address, F0's, the handle, the stream: per
+        step the host pays one ctypes call instead of a tensor slice, four ``data_ptr()`` and three Python frames more.
+        Measured (round 5, ``profiles/r05_host_ab.txt``, same lease, alternating): 6.4-6.6 us per step either way - the
+        loop is bound by the GPU's launch-to-launch period, not by the host; kept because it is the shorter path."""
         if hi <= lo:
             return None
         from . import _native

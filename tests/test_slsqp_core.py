@@ -767,6 +767,35 @@ def test_gpu_wide_sweep_on_side_streams_gives_the_bits_of_the_one_stream_order(m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,meq,mg", [(420, 120, 90), (900, 200, 120)])
+def test_gpu_short_row_forms_give_the_same_bits(n, meq, mg, monkeypatch):
+    """Rows of up to 1024 null-space coordinates have two forms of the pass over the rows: rounds 3-4's register kernel
+    (``k_rows_apply_r4``: the default up to 512 coordinates, where it measured faster) and round 5's (``k_rows_apply``: the
+    vector in LDS, the row requested with the first round trip; the default from 513 to 1024).  ``OGSQP_ROWS=r4`` / ``lds``
+    force one of them: step, multipliers, active set and change count must be the same bits (300 and 700 coordinates:
+    both template sizes; cold and warm-started subproblems)."""
+    rng = np.random.default_rng(n)
+    Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+    A, cc = np.vstack([C, G]), np.concatenate([c, h])
+    results = {}
+    for form in ("r4", "lds"):
+        monkeypatch.setenv("OGSQP_ROWS", form)
+        core = _sqp_native.QpCore(n, meq, mg)
+        out = []
+        for rep in range(3):
+            core.set_factor(Z * (1.0 + 0.25 * rep))
+            d, mult, bm, status, iters = core.solve(A, g * (1.0 + 0.1 * rep), cc, lb, ub)
+            out.append((d.copy(), mult.copy(), bm.copy(), status, iters, sorted(int(v) for v in core.get_active())))
+        core.close()
+        results[form] = out
+    monkeypatch.delenv("OGSQP_ROWS")
+    assert results["r4"][0][4] > 10
+    for (d0, m0, b0, s0, i0, a0), (d1, m1, b1, s1, i1, a1) in zip(results["r4"], results["lds"]):
+        assert s0 == s1 == 1 and i0 == i1 and a0 == a1
+        assert np.array_equal(d0, d1) and np.array_equal(m0, m1) and np.array_equal(b0, b1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,meq,mg", [(4300, 2000, 100), (2500, 470, 40)])
 def test_gpu_in_block_update_in_one_launch_gives_the_bits_of_the_three_launches(n, meq, mg, monkeypatch):
     """Round 5 (opt-in, ``OGSQP_WIDE_INBLOCK=1``; measured 1 % of a C5 subproblem, so the three launches stay the

@@ -2385,7 +2385,9 @@ struct og_qp_s {
     std::vector<int> warm;             // ... in the canonical numbering of og_qp_get_active
     bool warm_use = true;              // ... when the last two solutions shared most of their active rows (early in an
                                        // SQP run they do not: taking the stale rows out again costs more than it saves)
-    double *dots = nullptr, *dvec = nullptr, *rvec = nullptr;
+    double *dots = nullptr, *dvec = nullptr, *rvec = nullptr, *uval = nullptr;
+    bool warm_spread = true;           // removals of the warm start: both products with the inverse spread over the grid of
+                                       // k_rows_decide (OGSQP_WARM_SPREAD=0: by one workgroup, rounds 3-4)
     GiPartial *price = nullptr, *ratio = nullptr;
     RowsDecision* rec = nullptr;
     int *d_warm = nullptr, *d_slot = nullptr;
@@ -2736,7 +2738,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     // Tc and diagL: the equalities, then the rows of a warm start (at most qcap of them) behind them in the sweep
     A(&qp->Z, n1 * ldw); A(&qp->Jw, n1 * ldw); A(&qp->Tc, ((size_t)qp->meq + qc) * ldw); A(&qp->GJ, (size_t)qp->mg * ldw);
     A(&qp->diagL, qp->meq + qc); A(&qp->dots, (size_t)qp->mg + n1); A(&qp->dvec, n1); A(&qp->rvec, qc);
-    A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc);
+    A(&qp->price, 2048); A(&qp->ratio, 256); A(&qp->rec, 1); A(&qp->d_warm, qc); A(&qp->d_slot, qc); A(&qp->uval, qc);
     A(&qp->V16, (size_t)LQ16 * ldw); A(&qp->panel16, 1); A(&qp->V16b, (size_t)LQ16 * ldw); A(&qp->panel16b, 1); A(&qp->lq_go, 4); A(&qp->lq_wpart, (size_t)LQ_HEADS * 64 * 4); A(&qp->trsv_work, qp->meq); A(&qp->gemm_map, ((size_t)std::max(qp->meq, qp->mg) + 63 + qc) / 64 * ((n1 + 15) / 16) + 64); A(&qp->Linv, ((size_t)qp->meq + 63) / 64 * 4096); A(&qp->has_gone, ((size_t)qp->meq + 63) / 64); A(&qp->Vp, (size_t)LQ_NB * ldw); A(&qp->panel, 1); A(&qp->extra, qp->m); A(&qp->g, n1); A(&qp->c, qp->m); A(&qp->dl, n1); A(&qp->du, n1);
     A(&qp->w1, qp->meq); A(&qp->t1, n1); A(&qp->xcat, n1); A(&qp->deq, n1); A(&qp->bG, qp->mg);
     A(&qp->bval, mt); A(&qp->scale, mt); A(&qp->own, mt); A(&qp->u, mt); A(&qp->y, n1);
@@ -2860,6 +2862,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         }
         const char* spin = getenv("OGSQP_SPIN_LIMIT");
         if (spin && atoi(spin) > 0) qp->spin_limit = atoi(spin);
+        const char* wspread = getenv("OGSQP_WARM_SPREAD");
+        qp->warm_spread = !(wspread && std::string(wspread) == "0");
         const char* warm = getenv("OGSQP_WARM");
         qp->warm_enabled = !(warm && std::string(warm) == "0");
     }
@@ -3201,7 +3205,12 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
         ra.G1 = std::max(8, std::min(128, (qp->qcap + 15) / 16));
         // a wavefront per row (2048 workgroups at most: k_rows_decide reads that many partial prices in one trip)
         ra.G2 = std::max(1, std::min(2048, (nrows + 1 + ROWS_WAVES - 1) / ROWS_WAVES));
-        const size_t lds1 = rows_lds_bytes(nr, qp->qcap);
+        // the warm start's removals spread over the grid where the tile fits next to the three vectors (ogsqp_rows.h)
+        ra.uval = qp->uval;
+        ra.lost = qp->flag + 2;
+        ra.spin_limit = qp->spin_limit;
+        ra.warm_spread = (qp->warm_spread && rows_lds_bytes(nr, qp->qcap) + rows_spread_lds_bytes(qp->qcap) <= LDS_LIMIT) ? 1 : 0;
+        const size_t lds1 = rows_lds_bytes(nr, qp->qcap) + (ra.warm_spread ? rows_spread_lds_bytes(qp->qcap) : 0);
         OG_STAGE("rows init");
         hipLaunchKernelGGL(k_rows_init, dim3((mt + n1 + 255) / 256 + 1), dim3(ROWS_THREADS), 0, s, ra, qp->diagL,
                            (const int*)qp->d_warm, nwarm, qp->dthresh, qp->flag);
@@ -3481,8 +3490,9 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     // and a bounded wait gives up.  Nothing was committed: the subproblem is solved again with the forms that wait for
     // nothing (panel and update as separate launches, a launch per block of the triangular solves) - SciPy's core has
     // no such failure mode, so neither does this one.
-    const bool ahead = qp->lq_ahead, wide_on = qp->lq_wide;
+    const bool ahead = qp->lq_ahead, wide_on = qp->lq_wide, spread_on = qp->warm_spread;
     const int trsv = qp->trsv_mode;
+    qp->warm_spread = false;           // (its wait between the two products is one of the waits that can give up)
     qp->lq_ahead = false;
     qp->lq_wide = false;               // (its column-split panel waits too; round 2's kernels serve the long rows)
     if (qp->trsv_mode == 0) qp->trsv_mode = 1;
@@ -3491,6 +3501,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     rc = qp_solve_attempt(qp, d_jt, ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status, iterations, hip_stream,
                           &lost);
     qp->lq_ahead = ahead;
+    qp->warm_spread = spread_on;
     qp->lq_wide = wide_on;
     qp->trsv_mode = trsv;
     if (!rc && lost) return fail(7, "og_qp_solve_dev: a wait gave up in the forms that have none (internal error)");

@@ -55,7 +55,19 @@ struct RowsArgs {
     GiPartial* ratio;        // G1: ratio-test candidate of every workgroup of k_rows_decide
     RowsDecision* rec;
     int G1, G2;
+    // warm start's removals spread over the grid of k_rows_decide (round 5): multipliers of the active rows before the
+    // argmin, the flag a wait that gives up raises, the bound of that wait; 0: one workgroup does both products
+    double* uval;
+    int* lost;
+    int spin_limit;
+    int warm_spread;
 };
+
+constexpr int ROWS_SPREAD_TILE = 128;                 // rows of the inverse per tile of a 16-column block (stage A)
+// extra LDS of the spread form behind the three vectors: the tile and the storage rows of the active positions
+__host__ __device__ inline size_t rows_spread_lds_bytes(int qcap) {
+    return (size_t)(ROWS_SPREAD_TILE * 16 + (qcap + 1) / 2 + 8) * sizeof(double);
+}
 
 constexpr int ROWS_THREADS = 256;
 constexpr int ROWS_WAVES = ROWS_THREADS / 64;
@@ -150,9 +162,10 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
 
     if (phase < 0) {
         // ---- warm start: minimiser on the warm rows, multipliers, the most negative one leaves --------------
-        if (w != 0) return;
+        const bool spread = a.warm_spread != 0 && a.G1 > 1 && q > 0;
+        if (!spread && w != 0) return;
         if (q == 0) {
-            if (tid == 0) {
+            if (w == 0 && tid == 0) {
                 a.rec->kind = 0;
                 st->phase = 0;
             }
@@ -160,6 +173,127 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
         }
         double* y1 = aux;
         double* bA = d;
+        double worst = INFINITY;
+        int kworst = 0x7fffffff;
+        if (spread) {
+            // Round 5.  A removal recomputes the point and its multipliers on the remaining rows - y1 = -RI' b_A, u = RI y1 -
+            // and ONE workgroup streaming the q x q inverse twice at what one compute unit pulls (50 GB/s) took 52-90 us at
+            // C3 and a millisecond at C5.  Both products are spread over the grid: (A) workgroup w owns blocks of 16
+            // columns of y1 - tiles of 128 rows of the inverse go through LDS, two threads per column add up the even and
+            // the odd rows in the order the one-workgroup form adds them -, a counter and a bounded wait make y1 whole,
+            // (B) the rows of u are dealt to the wavefronts of the grid as the dual direction's are below, the last
+            // workgroup at the ticket decides.  Same sums in the same order: same bits (OGSQP_WARM_SPREAD=0: the old form).
+            double* tile = lds + (nr + 2 * qcap + 16);
+            int* sl = (int*)(tile + ROWS_SPREAD_TILE * 16);
+            for (int i = tid; i < q; i += ROWS_THREADS) {
+                sl[i] = a.slot[i];
+                bA[i] = g.bval[g.act[i]];
+            }
+            __syncthreads();
+            const int nblk = (q + 15) >> 4;
+            for (int cb = w; cb < nblk; cb += a.G1) {
+                double acc = 0.0;                              // thread t < 32: column 16 cb + (t & 15), rows of parity t >> 4
+                for (int r0 = 0; r0 < q; r0 += ROWS_SPREAD_TILE) {
+                    double v[ROWS_SPREAD_TILE * 16 / ROWS_THREADS];
+#pragma unroll
+                    for (int k = 0; k < ROWS_SPREAD_TILE * 16 / ROWS_THREADS; ++k) {
+                        const int e = tid + ROWS_THREADS * k, row = r0 + (e >> 4), col = 16 * cb + (e & 15);
+                        v[k] = (row < q && col < q) ? RI[(long)sl[row < q ? row : 0] * qcap + col] : 0.0;
+                    }
+                    __syncthreads();                           // (the previous tile has been summed)
+#pragma unroll
+                    for (int k = 0; k < ROWS_SPREAD_TILE * 16 / ROWS_THREADS; ++k) tile[tid + ROWS_THREADS * k] = v[k];
+                    __syncthreads();
+                    if (tid < 32) {
+                        const int col = tid & 15, rmax = min(ROWS_SPREAD_TILE, q - r0);
+                        for (int rr = tid >> 4; rr < rmax; rr += 2) acc += tile[rr * 16 + col] * bA[r0 + rr];
+                    }
+                }
+                if (tid < 64) {
+                    const double odd = __shfl_down(acc, 16);
+                    const int col = 16 * cb + tid;
+                    if (tid < 16 && col < q) st_shared(a.rvec + col, -(acc + odd));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(&st->cur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (__hip_atomic_load(&st->cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.G1) {
+                    if (++spins > a.spin_limit) {
+                        __hip_atomic_store(a.lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j < q; j += ROWS_THREADS) y1[j] = ld_shared(a.rvec + j);
+            __syncthreads();
+            const int stride_w = a.G1 * ROWS_WAVES;
+            for (int i0 = w * ROWS_WAVES + wave; i0 < q; i0 += 4 * stride_w) {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                const double* row[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * stride_w;
+                    row[u] = RI + (long)sl[i < q ? i : i0] * qcap;
+                }
+                for (int j = lane; j < q; j += 64) {
+                    const double yj = y1[j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] += row[u][j] * yj;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
+                if (lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * stride_w;
+                        if (i < q) {
+                            st_shared(a.uval + i, acc[u]);
+                            if (acc[u] < worst || (acc[u] == worst && i < kworst)) {
+                                worst = acc[u];
+                                kworst = i;
+                            }
+                        }
+                    }
+                }
+            }
+            if (lane != 0) {
+                worst = INFINITY;
+                kworst = 0x7fffffff;
+            }
+            block_argmin(worst, kworst, redv, redi);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                st_shared(&a.ratio[w].value, worst);
+                st_shared(&a.ratio[w].index, kworst);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned tk = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (tk == (unsigned)a.G1 - 1) ? 1 : 0;
+            }
+            __syncthreads();
+            if (!s_last) return;
+            if (tid == 0) {
+                st->ticket = 0u;
+                st->cur = 0;                                   // (every workgroup has passed the wait above)
+            }
+            worst = INFINITY;
+            kworst = 0x7fffffff;
+            for (int b = tid; b < a.G1; b += ROWS_THREADS) {
+                const double cv = ld_shared(&a.ratio[b].value);
+                const int ci = ld_shared(&a.ratio[b].index);
+                if (cv < worst || (cv == worst && ci < kworst)) {
+                    worst = cv;
+                    kworst = ci;
+                }
+            }
+            for (int i = tid; i < q; i += ROWS_THREADS) rv[i] = ld_shared(a.uval + i);
+            block_argmin(worst, kworst, redv, redi);
+        } else {
         for (int i = tid; i < q; i += ROWS_THREADS) bA[i] = g.bval[g.act[i]];
         __syncthreads();
         // (one workgroup reads the inverse twice per removal: what it costs is the number of round trips, so eight rows
@@ -187,8 +321,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
             y1[j] = -(acc0 + acc1);
         }
         __syncthreads();
-        double worst = INFINITY;
-        int kworst = 0x7fffffff;
         for (int i0 = 4 * wave; i0 < q; i0 += 4 * ROWS_WAVES) {    // y = N u  ->  u = RI y1, four rows per wavefront and trip
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             const double* row[4];
@@ -220,6 +352,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
             kworst = 0x7fffffff;
         }
         block_argmin(worst, kworst, redv, redi);
+        }
         if (!(worst < 0.0)) {
             double part = 0.0;
             for (int i = tid; i < nr; i += ROWS_THREADS) {

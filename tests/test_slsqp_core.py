@@ -767,6 +767,39 @@ def test_gpu_wide_sweep_on_side_streams_gives_the_bits_of_the_one_stream_order(m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,meq,mg", [(420, 120, 90), (900, 200, 120), (2400, 300, 60)])
+def test_gpu_warm_start_removals_spread_over_the_grid_give_the_bits_of_one_workgroup(n, meq, mg, monkeypatch):
+    """Round 5: a removal of the warm start recomputes the point and its multipliers on the remaining rows (two products
+    with the q x q inverse).  One workgroup did both (52-90 us at C3, a millisecond at C5); now the grid of
+    ``k_rows_decide`` does: blocks of 16 columns of the first product per workgroup, a counter-and-wait, the rows of the
+    second dealt to all wavefronts, the last workgroup at the ticket decides.  Same sums in the same order - the BITS of
+    ``OGSQP_WARM_SPREAD=0`` - on subproblems whose warm start has rows to remove (the cost vector is turned between
+    repetitions, so that the previous active set is partly wrong)."""
+    rng = np.random.default_rng(3 * n)
+    Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+    A, cc = np.vstack([C, G]), np.concatenate([c, h])
+    turns = [g, g[::-1].copy(), -g, 0.5 * g + 0.5 * g[::-1]]
+    results = {}
+    for form in ("spread", "one"):
+        monkeypatch.delenv("OGSQP_WARM_SPREAD", raising=False)
+        if form == "one":
+            monkeypatch.setenv("OGSQP_WARM_SPREAD", "0")
+        core = _sqp_native.QpCore(n, meq, mg)
+        out = []
+        for rep, gv in enumerate(turns):
+            core.set_factor(Z * (1.0 + 0.1 * rep))
+            d, mult, bm, status, iters = core.solve(A, gv, cc, lb, ub)
+            out.append((d.copy(), mult.copy(), bm.copy(), status, iters, sorted(int(v) for v in core.get_active())))
+        assert core.recoveries() == 0
+        core.close()
+        results[form] = out
+    monkeypatch.delenv("OGSQP_WARM_SPREAD", raising=False)
+    for (d0, m0, b0, s0, i0, a0), (d1, m1, b1, s1, i1, a1) in zip(results["one"], results["spread"]):
+        assert s0 == s1 == 1 and i0 == i1 and a0 == a1, (s0, s1, i0, i1)
+        assert np.array_equal(d0, d1) and np.array_equal(m0, m1) and np.array_equal(b0, b1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,meq,mg", [(420, 120, 90), (900, 200, 120)])
 def test_gpu_short_row_forms_give_the_same_bits(n, meq, mg, monkeypatch):
     """Rows of up to 1024 null-space coordinates have two forms of the pass over the rows: rounds 3-4's register kernel

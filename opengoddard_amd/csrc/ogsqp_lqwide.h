@@ -681,7 +681,11 @@ __global__ __launch_bounds__(256) void k_wy_sum(const double* __restrict__ part,
 __global__ __launch_bounds__(1024) void k_wy_small_finish(const double* __restrict__ part, int nsplit, int rows,
                                                           const Lq16Panel* __restrict__ panel, double* __restrict__ out) {
     __shared__ double s_w[64][LQ16 + 1];
+    __shared__ double s_t[LQ16][LQ16 + 1];
     const int tid = threadIdx.x, r = tid >> 4, j = tid & 15;          // (rows <= 48: ONE pass of 64 x 16 threads)
+    // (round 5: T comes in with the slices' first trip; read from global inside the 16-term sum below it was 16 dependent
+    // loads per thread, a third of this kernel's 26 us on the sweep's chain)
+    if (tid < LQ16 * LQ16) s_t[tid >> 4][tid & 15] = panel->T[tid >> 4][tid & 15];
     for (int r0 = 0; r0 < rows; r0 += 64) {
         const int rr = r0 + r;
         double acc = 0.0;
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(1024) void k_wy_small_finish(const double* __restri
         __syncthreads();
         if (rr < rows) {
             double w2 = 0.0;
-            for (int i = 0; i <= j; ++i) w2 = fma(s_w[r][i], panel->T[i][j], w2);
+            for (int i = 0; i <= j; ++i) w2 = fma(s_w[r][i], s_t[i][j], w2);
             out[(long)rr * LQ16 + j] = w2;
         }
         __syncthreads();

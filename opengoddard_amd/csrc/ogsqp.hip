@@ -2499,7 +2499,9 @@ namespace {
 // slices up walk them one after the other.  (k_wy_inblock uses the SAME slices: its sums are these sums.)
 void wy_split(const og_qp_s* qp, int rows, int L, int* nsplit_out, int* kb_per_out) {
     const int tiles = (rows + 16 * WYW_WAVES - 1) / (16 * WYW_WAVES), nblk = (L + 15) / 16;
-    int nsplit = std::max(1, std::min(std::min(tiles <= 4 ? 32 : WYW_SPLIT_MAX, 1024 / tiles), nblk / 4));
+    // (workgroups aimed at: OGSQP_WYW_GRID, an experiment's knob - more slices fill the SIMDs better and cost the sums more)
+    static const int grid_target = [] { const char* e = getenv("OGSQP_WYW_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    int nsplit = std::max(1, std::min(std::min(tiles <= 4 ? 32 : WYW_SPLIT_MAX, grid_target / tiles), nblk / 4));
     nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, qp->wy_part_cap / ((size_t)rows * LQW_BLOCK)));
     const int kb_per = (nblk + nsplit - 1) / nsplit;
     *nsplit_out = (nblk + kb_per - 1) / kb_per;

@@ -2838,7 +2838,24 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
                     og_qp_s::WyLane& ln = qp->lane[l];
                     A(&ln.w, 2 * (n1 + vrows) * LQW_BLOCK);
                     A(&ln.part, qp->wy_part_cap);
-                    if (!rc && hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) != hipSuccess)
+                    // OGSQP_LANE_RESERVE=k (an experiment's knob): the side streams leave every k-th compute unit to the
+                    // caller's stream - the sweep's chain (panels of 4 workgroups, one-workgroup finishes) then never
+                    // queues behind the streaming kernels' workgroups for a slot
+                    const char* reserve = getenv("OGSQP_LANE_RESERVE");
+                    const int every = reserve ? atoi(reserve) : 0;
+                    if (!rc && every > 1) {
+                        uint32_t mask[8];
+                        for (int wd = 0; wd < 8; ++wd) {
+                            mask[wd] = 0u;
+                            for (int bit = 0; bit < 32; ++bit)
+                                if ((32 * wd + bit) % every != every - 1) mask[wd] |= 1u << bit;
+                        }
+                        if (hipExtStreamCreateWithCUMask(&ln.s, 8, mask) != hipSuccess) {
+                            (void)hipGetLastError();
+                            ln.s = nullptr;
+                        }
+                    }
+                    if (!rc && !ln.s && hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) != hipSuccess)
                         rc = fail(5, "og_qp_create: hipStreamCreate failed");
                     if (!rc && hipEventCreateWithFlags(&qp->ev_join[l - 1], hipEventDisableTiming) != hipSuccess)
                         rc = fail(5, "og_qp_create: hipEventCreate failed");

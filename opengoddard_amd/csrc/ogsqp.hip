@@ -2499,9 +2499,9 @@ namespace {
 // slices up walk them one after the other.  (k_wy_inblock uses the SAME slices: its sums are these sums.)
 void wy_split(const og_qp_s* qp, int rows, int L, int* nsplit_out, int* kb_per_out) {
     const int tiles = (rows + 16 * WYW_WAVES - 1) / (16 * WYW_WAVES), nblk = (L + 15) / 16;
-    // (workgroups aimed at: OGSQP_WYW_GRID, an experiment's knob - more slices fill the SIMDs better and cost the sums more)
-    static const int grid_target = [] { const char* e = getenv("OGSQP_WYW_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-    int nsplit = std::max(1, std::min(std::min(tiles <= 4 ? 32 : WYW_SPLIT_MAX, grid_target / tiles), nblk / 4));
+    // (1024 workgroups aimed at: 2048 / 4096 fill the SIMDs of the side streams better and cost the sums more - 7.04 against
+    // 6.85 s over 121 subproblems of C5, profiles/r05_wyw_grid.jsonl)
+    int nsplit = std::max(1, std::min(std::min(tiles <= 4 ? 32 : WYW_SPLIT_MAX, 1024 / tiles), nblk / 4));
     nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, qp->wy_part_cap / ((size_t)rows * LQW_BLOCK)));
     const int kb_per = (nblk + nsplit - 1) / nsplit;
     *nsplit_out = (nblk + kb_per - 1) / kb_per;
@@ -2838,24 +2838,7 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
                     og_qp_s::WyLane& ln = qp->lane[l];
                     A(&ln.w, 2 * (n1 + vrows) * LQW_BLOCK);
                     A(&ln.part, qp->wy_part_cap);
-                    // OGSQP_LANE_RESERVE=k (an experiment's knob): the side streams leave every k-th compute unit to the
-                    // caller's stream - the sweep's chain (panels of 4 workgroups, one-workgroup finishes) then never
-                    // queues behind the streaming kernels' workgroups for a slot
-                    const char* reserve = getenv("OGSQP_LANE_RESERVE");
-                    const int every = reserve ? atoi(reserve) : 0;
-                    if (!rc && every > 1) {
-                        uint32_t mask[8];
-                        for (int wd = 0; wd < 8; ++wd) {
-                            mask[wd] = 0u;
-                            for (int bit = 0; bit < 32; ++bit)
-                                if ((32 * wd + bit) % every != every - 1) mask[wd] |= 1u << bit;
-                        }
-                        if (hipExtStreamCreateWithCUMask(&ln.s, 8, mask) != hipSuccess) {
-                            (void)hipGetLastError();
-                            ln.s = nullptr;
-                        }
-                    }
-                    if (!rc && !ln.s && hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) != hipSuccess)
+                    if (!rc && hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) != hipSuccess)
                         rc = fail(5, "og_qp_create: hipStreamCreate failed");
                     if (!rc && hipEventCreateWithFlags(&qp->ev_join[l - 1], hipEventDisableTiming) != hipSuccess)
                         rc = fail(5, "og_qp_create: hipEventCreate failed");

@@ -131,6 +131,10 @@ struct og_problem_s {
     bool have_pattern = false;
     std::vector<int64_t> indptr;
     std::vector<int32_t> rows;
+    // the same pattern as runs of consecutive rows per column (the defect rows of a variable's own state are one run of
+    // N): the host's scatter of a downloaded block is one memcpy per run instead of one store per entry
+    std::vector<int64_t> run_ptr;       // n + 1: runs of column j = [run_ptr[j], run_ptr[j + 1])
+    std::vector<int32_t> run_row, run_len;
     int64_t* d_indptr = nullptr;
     int32_t* d_rows = nullptr;          // the pattern's row indices, flat (pack / unpack read them coalesced)
     // host-pointer entry points: pinned staging ([x | h] up, [packed non-zeros | F | non-finite count] down)
@@ -257,6 +261,20 @@ int ensure_pattern(og_problem_s* p) {
         return fail(100 + (int)e, std::string("og_pattern: ") + hipGetErrorString(e));
     }
     p->d_rows = d_rows;
+    p->run_ptr.assign((size_t)n + 1, 0);
+    p->run_row.clear();
+    p->run_len.clear();
+    for (int j = 0; j < n; ++j) {
+        const int64_t lo = p->indptr[(size_t)j], hi = p->indptr[(size_t)j + 1];
+        for (int64_t i = lo; i < hi;) {
+            int64_t e = i + 1;
+            while (e < hi && p->rows[(size_t)e] == p->rows[(size_t)e - 1] + 1) ++e;
+            p->run_row.push_back(p->rows[(size_t)i]);
+            p->run_len.push_back((int32_t)(e - i));
+            i = e;
+        }
+        p->run_ptr[(size_t)j + 1] = (int64_t)p->run_row.size();
+    }
     p->have_pattern = true;
     return 0;
 }
@@ -341,12 +359,14 @@ int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, cons
     }
     const int m = p->m;
     const double* v = p->h_down;
+    // (run by run: 83 541 single stores at C3 were a third of the call's 0.09 ms; the runs are 10 x fewer)
     for (int j = lo; j < hi; ++j) {
         double* row = JT + (size_t)(j - lo) * (size_t)m;
-        const int32_t* r = p->rows.data() + p->indptr[(size_t)j];
-        const int64_t cnt = p->indptr[(size_t)j + 1] - p->indptr[(size_t)j];
-        for (int64_t i = 0; i < cnt; ++i) row[r[i]] = v[i];
-        v += cnt;
+        for (int64_t k = p->run_ptr[(size_t)j]; k < p->run_ptr[(size_t)j + 1]; ++k) {
+            const int32_t len = p->run_len[(size_t)k];
+            memcpy(row + p->run_row[(size_t)k], v, sizeof(double) * (size_t)len);
+            v += len;
+        }
     }
     return 0;
 }

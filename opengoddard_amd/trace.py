@@ -746,7 +746,12 @@ def _array_function(func, args, kwargs):
         return v
     p_args = tuple(plain(v) for v in args)
     p_kwargs = {k: plain(v) for k, v in kwargs.items()}
-    if not _has_traced(list(p_args)) and not _has_traced(list(p_kwargs.values())):
+    # ... except for the routines that BUILD the array a callback goes on to fill (`out = np.concatenate((np.zeros(2),
+    # np.zeros(3))); out[1:] = traced`): their result has to stay a traced constant that records assignments - a plain
+    # ndarray would hand the traced value to NumPy's own __setitem__
+    builders = (np.hstack, np.concatenate, np.append, np.vstack, getattr(np, "row_stack", None), np.stack,
+                np.column_stack, np.zeros_like, np.ones_like, np.empty_like, np.full_like)
+    if func not in builders and not _has_traced(list(p_args)) and not _has_traced(list(p_kwargs.values())):
         return func(*p_args, **p_kwargs)
     if func in (np.hstack, np.concatenate):
         axis = kwargs.get("axis", 0) if func is np.concatenate else 0

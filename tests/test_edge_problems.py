@@ -311,6 +311,14 @@ def preallocated_outputs():
         rows.lower_bound(out, 0.0)
         rows.upper_bound(table.max(axis=0) + table.mean(axis=1)[0], 6.0)
         rows.lower_bound(np.stack([u[0:3], x[0:3]], axis=1).ravel(), -4.0)
+        # a buffer ASSEMBLED from constant pieces and then filled (np.concatenate / np.hstack of np.zeros /
+        # np.ones must stay traced buffers, not become NumPy's own ndarray)
+        pad = np.concatenate((np.zeros(2), np.ones(3)))
+        pad[1:4] = u[6:9] * x[6:9]
+        wide = np.hstack((np.zeros(1), np.full(2, 0.5)))
+        wide[0] = x[9] - u[9]
+        wide[2] += u[10]
+        rows.lower_bound(np.append(pad, wide), -5.0)
         return rows()
 
     prob = Problem([0.0, 1.2], [18], [2], [1], 3)

@@ -464,6 +464,47 @@ def single_process_bench(a):
     return 0
 
 
+def physical_device_id(torch, dev):
+    """What tells one GPU from another on a node: host name + the device's uuid (or its PCI address) - never the
+    ordinal a process happens to see it under, and never the pid (VERDICT r5 / ADVICE r5: N ranks on one GPU must
+    count as ONE device)."""
+    import socket
+    props = torch.cuda.get_device_properties(dev)
+    parts = []
+    uuid = getattr(props, "uuid", None)
+    if uuid is not None and not set(str(uuid).replace("-", "")) <= {"0"} and str(uuid) not in ("", "None"):
+        parts.append("uuid:" + str(uuid))
+    pci = [getattr(props, f, None) for f in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if all(v is not None for v in pci):
+        parts.append("pci:%04x:%02x:%02x" % tuple(int(v) for v in pci))
+    ident = "|".join(parts) or "ordinal:%d" % (dev.index if getattr(dev, "index", None) is not None else int(dev))
+    return socket.gethostname() + "/" + ident
+
+
+def device_census(ranks_report):
+    """-> distinct_devices (physical), ranks_per_device {device: [ranks]} from the all-gathered per-rank records."""
+    per = {}
+    for r_ in ranks_report:
+        per.setdefault(str(r_.get("physical_device", r_.get("device"))), []).append(int(r_["rank"]))
+    return {"distinct_devices": len(per), "ranks_per_device": per}
+
+
+def multi_gpu_verdict(result, world, same_device):
+    """None when an N > 1 line may stand; otherwise why it may not (the process exits non-zero with it): every rank
+    on its own physical GPU AND the exchange RCCL's own N-rank communicator - anything else measures something other
+    than what the line says (OG_BENCH_SAME_DEVICE=1 is the declared dry run of the plumbing and is labelled as such)."""
+    if world <= 1 or same_device:
+        return None
+    problems_ = []
+    if result.get("distinct_devices") != world:
+        problems_.append("%d ranks on %s physical device(s): %s" % (world, result.get("distinct_devices"),
+                                                                     result.get("ranks_per_device")))
+    if result.get("rccl_ranks") != world:
+        problems_.append("the exchange is not an RCCL communicator of %d ranks (ncclCommCount reports %s)"
+                         % (world, result.get("rccl_ranks")))
+    return "; ".join(problems_) or None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -597,7 +638,8 @@ def main():
     if collective:
         import ctypes as C
         mine = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "device": int(torch.cuda.current_device()),
-                "device_name": torch.cuda.get_device_name(dev)}
+                "device_name": torch.cuda.get_device_name(dev), "physical_device": physical_device_id(torch, dev),
+                "message_bytes": int(sweeps[0].message_bytes)}
         if getattr(backend, "direct", False):
             v = (C.c_int32 * 3)()
             if eng._lib.og_shard_comm_info(eng._handle, C.byref(v, 0), C.byref(v, 4), C.byref(v, 8)) == 0:
@@ -935,7 +977,9 @@ def main():
         result["ranks"] = ranks_report
         counts = {r_.get("rccl_comm_ranks") for r_ in ranks_report}
         result["rccl_ranks"] = counts.pop() if len(counts) == 1 else None
-        result["distinct_devices"] = len({(r_["device"], r_["pid"]) for r_ in ranks_report})
+        # PHYSICAL devices (host + uuid / PCI address), not (ordinal, pid) pairs: N ranks piled onto one GPU count as one
+        result.update(device_census(ranks_report))
+        result["message_bytes_per_rank"] = [r_.get("message_bytes") for r_ in ranks_report]
     if baseline_config is not None:
         result["baseline_config"] = baseline_config
     if collective:
@@ -958,10 +1002,18 @@ def main():
     sys.stdout.flush()
     if collective:
         dist.barrier()
+    verdict = multi_gpu_verdict(result, world, same_device) if rank == 0 else None
     if rank == 0:
+        if same_device:
+            result["dry_run"] = "OG_BENCH_SAME_DEVICE=1: every rank on device 0, gloo through host staging - plumbing only, measures nothing"
+        if verdict:
+            result["invalid"] = verdict
         print(json.dumps(result), flush=True)
     if collective:
         dist.destroy_process_group()
+    if verdict:
+        sys.stderr.write("bench.py: this --gpus %d line is INVALID: %s\n" % (world, verdict))
+        return 3
 
 if __name__ == "__main__":
     sys.exit(main() or 0)

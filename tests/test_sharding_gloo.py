@@ -198,3 +198,26 @@ def test_bench_launches_its_own_ranks_when_there_is_no_launcher(monkeypatch):
     with pytest.raises(SystemExit):
         bench.main()
     assert not seen
+
+
+def test_bench_counts_physical_devices_and_refuses_a_line_that_is_not_n_gpus_over_rccl():
+    """VERDICT r5 #4 / ADVICE r5: ``distinct_devices`` keys on the physical GPU (host + uuid / PCI address), so N ranks
+    piled onto one device report 1 - not N as the (ordinal, pid) pairs of round 5 did - and an N > 1 line stands only
+    if every rank has its own GPU AND RCCL's communicator has N ranks; the declared dry run is exempt and labelled."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    same = [{"rank": r, "pid": 100 + r, "device": 0, "physical_device": "box/uuid:GPU-aa|pci:0000:05:00"} for r in range(4)]
+    census = bench.device_census(same)
+    assert census["distinct_devices"] == 1 and census["ranks_per_device"] == {"box/uuid:GPU-aa|pci:0000:05:00": [0, 1, 2, 3]}
+    line = dict(census, rccl_ranks=None)
+    why = bench.multi_gpu_verdict(line, 4, same_device=False)
+    assert why and "1 physical device" in why and "RCCL" in why
+    assert bench.multi_gpu_verdict(line, 4, same_device=True) is None           # the labelled dry run
+    spread = [{"rank": r, "pid": 100 + r, "device": r, "physical_device": "box/pci:0000:%02x:00" % (5 + r)} for r in range(4)]
+    good = dict(bench.device_census(spread), rccl_ranks=4)
+    assert good["distinct_devices"] == 4 and bench.multi_gpu_verdict(good, 4, False) is None
+    # every rank on its own GPU but the exchange fell back to something that is not the 4-rank communicator
+    assert "RCCL" in bench.multi_gpu_verdict(dict(good, rccl_ranks=None), 4, False)
+    assert bench.multi_gpu_verdict({"distinct_devices": 1}, 1, False) is None   # N = 1: nothing to check

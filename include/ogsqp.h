@@ -104,6 +104,14 @@ int og_qp_set_active(og_qp_handle qp, const int32_t* ids, int32_t count);
  * shortens the bound (tests force the path with 1).  No reference counterpart. */
 int og_qp_recoveries(og_qp_handle qp, int32_t* count);
 
+/* Round 6.  Where the stack of constraint rows and the inverse of the active triangle fit the chip's LDS (up to 4096
+ * rows, one wavefront each, 16 per compute unit: BASELINE.json's C3 and C4), the whole active-set loop of a
+ * subproblem is ONE launch (k_rows_resident, csrc/ogsqp_resident.h) instead of two launches per change.
+ * *launches = such launches so far, *changes = active-set changes they made (0 / 0: the two-launch form serves this
+ * handle - rows too many or too long, or OGSQP_RESIDENT=0 in the environment).  No reference counterpart (SciPy's
+ * lsq() is a scalar Fortran loop, scipy/optimize/_slsqp_py.py:427-432 -> slsqp_optmz.f). */
+int og_qp_resident_stats(og_qp_handle qp, int64_t* launches, int64_t* changes);
+
 /* Powell-damped BFGS (slsqp label 260-320) on the factor: s = step, eta = change of the
  * Lagrangian gradient, Bs = B s.  *reset_needed = 1 when the update is undefined (s'Bs or the
  * damped s'eta not positive) and the factor was left unchanged. */

@@ -30,6 +30,7 @@ SIGNATURES = {
     "og_qp_get_active": (C.c_int, [C.c_void_p, _ip, C.c_int32, _ip]),
     "og_qp_set_active": (C.c_int, [C.c_void_p, _ip, C.c_int32]),
     "og_qp_recoveries": (C.c_int, [C.c_void_p, _ip]),
+    "og_qp_resident_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "og_qp_bfgs": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "og_jt_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _dp, _dp, C.c_void_p]),
     "og_qp_last_error": (C.c_char_p, []),
@@ -152,6 +153,13 @@ class QpCore:
         count = C.c_int32(0)
         check(self._lib.og_qp_recoveries(self._handle, C.byref(count)), "og_qp_recoveries")
         return count.value
+
+    def resident_stats(self):
+        """(launches, active-set changes) of the one-launch active-set loop (``k_rows_resident``); (0, 0) when the
+        two-launch form serves this handle."""
+        launches, changes = C.c_int64(0), C.c_int64(0)
+        check(self._lib.og_qp_resident_stats(self._handle, C.byref(launches), C.byref(changes)), "og_qp_resident_stats")
+        return int(launches.value), int(changes.value)
 
     def bfgs(self, s, eta, Bs):
         """Damped BFGS on the factor; returns True when the caller has to reset instead."""

@@ -100,7 +100,8 @@ def build_sqp(force=False):
         return os.environ["OG_SQP_LIB"]
     os.makedirs(LIBDIR, exist_ok=True)
     sources = [os.path.join(CSRC, "ogsqp.hip"), os.path.join(CSRC, "ogsqp_rows.h"), os.path.join(CSRC, "ogsqp_lq16.h"),
-               os.path.join(CSRC, "ogsqp_lqwide.h"), os.path.join(HERE, "..", "include", "ogsqp.h")]
+               os.path.join(CSRC, "ogsqp_lqwide.h"), os.path.join(CSRC, "ogsqp_resident.h"),
+               os.path.join(HERE, "..", "include", "ogsqp.h")]
     stamp_path = SQP_LIB + ".stamp"
     want = _digest_files(sources)
     if not force and os.path.exists(SQP_LIB) and os.path.exists(stamp_path):

@@ -1200,7 +1200,9 @@ struct GiState {
     double ynorm;
     int dbg;
     int dbg2;
-    long long tr[12];   // OGSQP_TRACE: accumulated s_memtime ticks (10 ns) per section of the update
+    int warm_removals;  // k_rows_resident: changes the warm start's pairs in front of it had made
+    int pad_;
+    long long tr[40];   // OGSQP_TRACE: accumulated s_memtime ticks (10 ns) per section of the update
 };
 
 struct GiPartial {
@@ -1304,7 +1306,9 @@ __global__ void k_gi_init(GiArgs g, const int* flag) {
         s.ynorm = 0.0;
         s.dbg = 0;
         s.dbg2 = 0;
-        for (int e = 0; e < 12; ++e) s.tr[e] = 0;
+        s.warm_removals = 0;
+        s.pad_ = 0;
+        for (int e = 0; e < 40; ++e) s.tr[e] = 0;
         *g.st = s;
     }
 }
@@ -2316,6 +2320,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_gi_coop(CoopArgs c) {
 }
 
 #include "ogsqp_rows.h"
+#include "ogsqp_resident.h"
 
 // d = clip(deq + Y y), multipliers of the general inequalities and of the bounds
 __global__ __launch_bounds__(256) void k_finish_step(const double* __restrict__ Jw, int ld, int meq, int nq, int nr,
@@ -2390,6 +2395,13 @@ struct og_qp_s {
                                        // k_rows_decide (OGSQP_WARM_SPREAD=0: by one workgroup, rounds 3-4)
     GiPartial *price = nullptr, *ratio = nullptr;
     RowsDecision* rec = nullptr;
+    bool resident = true;              // round 6: the active-set loop as ONE launch with every row of W and of the inverse in
+                                       // registers (k_rows_resident, ogsqp_resident.h) where they fit the chip - up to 4096
+                                       // rows of up to 1024 null-space coordinates: C3, C4; OGSQP_RESIDENT=0: the two-launch form
+    unsigned long long* res_mail = nullptr;   // its mailbox (self-validating records) ...
+    unsigned* res_seq = nullptr;              // ... and the exchange counters that go on counting from launch to launch
+    int warm_pairs_hint = 4;           // two-launch pairs enqueued in front of it for the warm start's removals
+    long resident_launches = 0, resident_changes = 0;
     int *d_warm = nullptr, *d_slot = nullptr;
     unsigned char* gemm_map = nullptr; // per block of 64 constraints: which slabs of 16 variables hold a non-zero
     double* trsv_work = nullptr;       // right-hand side of a triangular solve while the blocks are eliminated
@@ -2749,6 +2761,13 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     A(&qp->d, n1); A(&qp->bm, n1); A(&qp->tvec, n1); A(&qp->rhs, qp->meq); A(&qp->lam, qp->meq); A(&qp->vz, n1);
     A(&qp->svec, n1); A(&qp->vvec, n1); A(&qp->coef, qp->m + 1); A(&qp->outn, n1);
     A(&qp->isact, mt); A(&qp->act, qc); A(&qp->flag, 4);
+    // the mailbox of the resident active-set launch (ogsqp_resident.h): sized for this handle's rows when they fit the chip
+    const size_t res_wg_cap = ((size_t)qp->mg + n1 + qc + RES_ROWS - 1) / RES_ROWS;
+    const size_t res_records = res_mail_records(res_wg_cap <= (size_t)RES_MAX_WG ? (int)res_wg_cap : 1, (int)qc);
+    A(&qp->res_mail, 2 * res_records); A(&qp->res_seq, 4);
+    if (!rc && (hipMemset(qp->res_mail, 0, 2 * res_records * sizeof(unsigned long long)) != hipSuccess ||
+                hipMemset(qp->res_seq, 0, 4 * sizeof(unsigned)) != hipSuccess))
+        rc = fail(5, "og_qp_create: hipMemset failed");
     A(&qp->partials, ((size_t)qp->mg + n1) / GI_WAVES + 2); A(&qp->st, 1);
     if (!rc && hipStreamCreate(&qp->stream) != hipSuccess) rc = fail(5, "og_qp_create: hipStreamCreate failed");
     if (!rc && hipMemset(qp->lq_go, 0, 4 * sizeof(unsigned)) != hipSuccess) rc = fail(5, "og_qp_create: hipMemset failed");
@@ -2764,6 +2783,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
     if (!rc && (hipFuncSetAttribute((const void*)k_rows_decide, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LDS_LIMIT) != hipSuccess ||
                 hipFuncSetAttribute((const void*)k_rows_invert, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LDS_LIMIT) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_rows_resident, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LDS_LIMIT) != hipSuccess ||
                 hipFuncSetAttribute((const void*)k_rows_apply_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LDS_LIMIT) != hipSuccess ||
@@ -2799,6 +2820,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
         // select the two older kernels (kept for comparison; they need their own, smaller, LDS budget)
         qp->gi_mode = (mode && (std::string(mode) == "single" || std::string(mode) == "coop" || std::string(mode) == "old")) ? 1 : 0;
         if (qp->gi_mode == 1 && gi_lds_bytes((int)qc, (int)qc) > LDS_LIMIT) qp->gi_mode = 0;
+        const char* resk = getenv("OGSQP_RESIDENT");
+        qp->resident = !(resk && std::string(resk) == "0");
         const char* rowsk = getenv("OGSQP_ROWS");
         qp->rows_stream = !(rowsk && std::string(rowsk) == "reg");
         qp->rows_r4 = (rowsk && std::string(rowsk) == "r4") ? 1 : (rowsk && std::string(rowsk) == "lds") ? -1 : 0;
@@ -3212,6 +3235,7 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
         ra.lost = qp->flag + 2;
         ra.spin_limit = qp->spin_limit;
         ra.warm_spread = (qp->warm_spread && rows_lds_bytes(nr, qp->qcap) + rows_spread_lds_bytes(qp->qcap) <= LDS_LIMIT) ? 1 : 0;
+        ra.only_warm = 0;
         const size_t lds1 = rows_lds_bytes(nr, qp->qcap) + (ra.warm_spread ? rows_spread_lds_bytes(qp->qcap) : 0);
         OG_STAGE("rows init");
         hipLaunchKernelGGL(k_rows_init, dim3((mt + n1 + 255) / 256 + 1), dim3(ROWS_THREADS), 0, s, ra, qp->diagL,
@@ -3229,7 +3253,7 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
         // vectors fit - costs the occupancy the streamed form lives on: 111 instead of 47 us per change at C5)
         const bool stage = stream && qp->rows_stage > 0 && 5 * nrp * sizeof(double) <= LDS_LIMIT;
         const size_t lds2 = (stage ? 5 : 1) * nrp * sizeof(double);
-#define OG_ROWS_APPLY()                                                                                      \
+#define OG_ROWS_APPLY(ra)                                                                                      \
     do {                                                                                                     \
         if (stream && stage) hipLaunchKernelGGL(k_rows_apply_stream<true>, dim3(ra.G2), dim3(ROWS_THREADS), lds2, s, ra); \
         else if (stream) hipLaunchKernelGGL(k_rows_apply_stream<false>, dim3(ra.G2), dim3(ROWS_THREADS), lds2, s, ra); \
@@ -3240,7 +3264,7 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
         else if (tail_lanes <= 32) hipLaunchKernelGGL(k_rows_apply<32>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra); \
         else hipLaunchKernelGGL(k_rows_apply<80>, dim3(ra.G2), dim3(ROWS_THREADS), 0, s, ra);                  \
     } while (0)
-        OG_ROWS_APPLY();                                       // values and pricing at y = 0
+        OG_ROWS_APPLY(ra);                                     // values and pricing at y = 0
         OG_HIP(hipGetLastError());
         int batch = debug_stages() ? 1 : 8;
         long launched = 0;
@@ -3253,11 +3277,59 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
             OG_HIP(hipStreamSynchronize(s));
             t_front = now() - t0;
         }
-        while (true) {
+        // ---- round 6: the whole loop as ONE launch with the rows in registers, where they fit (ogsqp_resident.h).  In
+        // front of it as many two-launch pairs as the warm start's removals are expected to take (in `only_warm` form:
+        // with the warm start over they do nothing); the launch returns at once while the warm start is not over.
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, qp->device);
+        const int res_len = std::max(nr, qp->qcap);
+        const int res_wg = (nrows + qp->qcap + RES_ROWS - 1) / RES_ROWS;
+        bool resident = qp->resident && !debug_stages() && res_len <= RES_MAX_LEN && res_wg <= std::min(RES_MAX_WG, cus) &&
+                        res_lds_bytes(nr, qp->qcap) <= LDS_LIMIT;
+        if (resident) {
+            ResArgs rs;
+            rs.r = ra;
+            rs.mail = qp->res_mail;
+            rs.seq = qp->res_seq;
+            rs.NW = res_wg;
+            RowsArgs rw = ra;
+            rw.only_warm = 1;
+            const size_t ldsr = res_lds_bytes(nr, qp->qcap);
+            int pairs = nwarm ? std::max(1, qp->warm_pairs_hint) : 0;
+            long warm_launched = 0;
+            while (true) {
+                for (int it = 0; it < pairs; ++it) {
+                    hipLaunchKernelGGL(k_rows_decide, dim3(rw.G1), dim3(ROWS_THREADS), lds1, s, rw);
+                    OG_ROWS_APPLY(rw);
+                }
+                warm_launched += pairs;
+                hipLaunchKernelGGL(k_rows_resident, dim3(res_wg), dim3(RES_THREADS), ldsr, s, rs);
+                ++qp->resident_launches;
+                OG_HIP(hipGetLastError());
+                OG_HIP(hipMemcpyAsync(&hst, qp->st, sizeof(GiState), hipMemcpyDeviceToHost, s));
+                OG_HIP(hipMemcpyAsync(hflag, qp->flag, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+                OG_HIP(hipStreamSynchronize(s));
+                if (hst.phase >= 2) break;
+                if (hflag[2] || hflag[3] || hst.phase >= 0) {
+                    // a workgroup of the resident launch was not there to answer (or a wait gave up earlier in this
+                    // attempt): nothing was written back; the attempt is run again with the forms that wait for nothing
+                    *lost = 1;
+                    return 0;
+                }
+                if (warm_launched > (long)nwarm + 64)
+                    return fail(8, "og_qp_solve_dev: the warm start's removals made no progress (internal error)");
+                pairs = std::min(128, std::max(4, 4 * pairs));
+            }
+            // next time: as many pairs as this warm start's removals took, and a few (a pair that has nothing to do costs
+            // ~5 us, a second round trip to the host 50)
+            if (nwarm) qp->warm_pairs_hint = std::min(96, hst.warm_removals + 4);
+            qp->resident_changes += hst.iters;
+        }
+        while (!resident) {
             const double te = timing ? now() : 0.0;
             for (int it = 0; it < batch; ++it) {
                 hipLaunchKernelGGL(k_rows_decide, dim3(ra.G1), dim3(ROWS_THREADS), lds1, s, ra);
-                OG_ROWS_APPLY();
+                OG_ROWS_APPLY(ra);
             }
             launched += batch;
             OG_HIP(hipGetLastError());
@@ -3413,12 +3485,20 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
                                             "r + ratio test", "u,y update", "append", "removal"};
         static const char* names_rows[9] = {"state word", "who comes in", "normal in LDS", "norms", "inverse rows x d1",
                                             "stores + ticket", "others' r, ratio", "u, y", "reflector, lists"};
+        static const char* names_res[16] = {"price, workgroup's best", "publish + poll + election", "winner's row", "(2) row from its owner", "norms",
+                                            "r: product, publish", "r: poll", "ratio test", "step, u, y, |y|", "row joins", "row leaves",
+                                            "pass over rows", "closing barrier", "(wave 15) pass over y", "-", "-"};
+        const bool res_trace = rows_mode && qp->resident_launches > 0;
         const char* const* names = rows_mode ? names_rows : names_iter;
         fprintf(stderr, "[ogsqp trace] %d iterations, %lld passes, %lld removals, %d active at the end\n", hst.iters,
                 hst.tr[10], hst.tr[11], hst.q);
         for (int e = 0; e < 9; ++e)
             fprintf(stderr, "[ogsqp trace]   %-16s %8.2f us per iteration\n", names[e],
                     hst.iters ? 0.01 * (double)hst.tr[e] / hst.iters : 0.0);
+        if (res_trace)
+            for (int e = 0; e < 14; ++e)
+                fprintf(stderr, "[ogsqp trace]   resident: %-22s %8.2f us per change (%lld changes, %lld partial)\n", names_res[e],
+                        hst.tr[38] ? 0.01 * (double)hst.tr[16 + e] / hst.tr[38] : 0.0, hst.tr[38], hst.tr[39]);
     }
 #endif
     if (hst.dbg != 0) fprintf(stderr, "[ogsqp] internal check failed: code %d aux %d (q %d, p %d)\n", hst.dbg, hst.dbg2, hst.q, hst.p);
@@ -3494,6 +3574,8 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     // no such failure mode, so neither does this one.
     const bool ahead = qp->lq_ahead, wide_on = qp->lq_wide, spread_on = qp->warm_spread;
     const int trsv = qp->trsv_mode;
+    const bool resident_on = qp->resident;
+    qp->resident = false;              // (the resident active-set launch waits for every one of its workgroups)
     qp->warm_spread = false;           // (its wait between the two products is one of the waits that can give up)
     qp->lq_ahead = false;
     qp->lq_wide = false;               // (its column-split panel waits too; round 2's kernels serve the long rows)
@@ -3503,6 +3585,7 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     rc = qp_solve_attempt(qp, d_jt, ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status, iterations, hip_stream,
                           &lost);
     qp->lq_ahead = ahead;
+    qp->resident = resident_on;
     qp->warm_spread = spread_on;
     qp->lq_wide = wide_on;
     qp->trsv_mode = trsv;
@@ -3513,6 +3596,13 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
 int og_qp_recoveries(og_qp_handle qp, int32_t* count) {
     if (!qp || !count) return fail(2, "og_qp_recoveries: null argument");
     *count = qp->recoveries;
+    return 0;
+}
+
+int og_qp_resident_stats(og_qp_handle qp, int64_t* launches, int64_t* changes) {
+    if (!qp || !launches || !changes) return fail(2, "og_qp_resident_stats: null argument");
+    *launches = qp->resident_launches;
+    *changes = qp->resident_changes;
     return 0;
 }
 

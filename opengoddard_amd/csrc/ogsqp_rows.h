@@ -37,7 +37,8 @@
 
 struct RowsDecision {
     int kind;        // 0 price only, 1 full step (p joins), 2 partial step (position k leaves), 3 warm start: position
-                     // k leaves (reflector only), 4 warm start done: every row's value from y
+                     // k leaves (reflector only), 4 warm start done: every row's value from y, 5 nothing at all (a pair
+                     // enqueued for the warm start after it was over: k_rows_resident prices for itself)
     int q;           // active rows before this change = first tail coordinate
     int k;
     int dependent;
@@ -61,6 +62,9 @@ struct RowsArgs {
     int* lost;
     int spin_limit;
     int warm_spread;
+    // round 6: the launches in front of k_rows_resident (ogsqp_resident.h) only serve the warm start's removals: with the
+    // warm start over, k_rows_decide leaves a "price only" decision (the pass that follows changes nothing) and returns
+    int only_warm;
 };
 
 constexpr int ROWS_SPREAD_TILE = 128;                 // rows of the inverse per tile of a 16-column block (stage A)
@@ -152,6 +156,10 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
     }
     const int phase = st->phase;
     if (phase >= 2) return;
+    if (a.only_warm && phase >= 0) {
+        if (w == 0 && tid == 0) a.rec->kind = 5;
+        return;
+    }
     const int q = st->q;
     RMARK(0);   // state word
     double* d = lds;                  // nr: incoming normal
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply(RowsArgs a) {
         draw[c] = a.dvec[j < nr ? j : 0];
         vraw[c] = a.vvec[j < qcap ? j : 0];
     }
-    if (phase >= 2) return;
+    if (phase >= 2 || rec.kind == 5) return;
     const int kind = rec.kind;
     const int nrows = mg + nq;
     const bool moves = (kind == 1 || kind == 2) && !rec.dependent;
@@ -943,6 +951,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply_r4(RowsArgs a) {
     if (st->phase >= 2) return;
     const RowsDecision rec = *a.rec;
     const int kind = rec.kind;
+    if (kind == 5) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
     const int nr = g.nr, mg = g.mg, nq = g.nq, qcap = g.qcap;
     const int q0 = rec.q;
@@ -1081,7 +1090,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_apply_stream(RowsArgs a) 
     const int phase = st->phase;
     const double ynorm = st->ynorm;
     const RowsDecision rec = *a.rec;
-    if (phase >= 2) return;
+    if (phase >= 2 || rec.kind == 5) return;
     const int kind = rec.kind;
     const int q0 = rec.q;
     const int nrows = mg + nq;
@@ -1240,7 +1249,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_init(RowsArgs a, const do
         s.ynorm = 0.0;
         s.dbg = 0;
         s.dbg2 = 0;
-        for (int e = 0; e < 12; ++e) s.tr[e] = 0;
+        s.warm_removals = 0;
+        s.pad_ = 0;
+        for (int e = 0; e < 40; ++e) s.tr[e] = 0;
         *g.st = s;
         RowsDecision rec;
         rec.kind = 0;

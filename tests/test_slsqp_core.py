@@ -890,6 +890,40 @@ def test_gpu_streamed_rows_give_the_bits_of_the_register_kernels(n, meq, mg, mon
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,meq,mg", [(420, 120, 90), (900, 200, 120), (1500, 700, 260)])
+def test_gpu_resident_active_set_gives_the_bits_of_the_two_launch_form(n, meq, mg, monkeypatch):
+    """Round 6: where the rows of W and of the inverse fit the chip's LDS the whole active-set loop is ONE launch
+    (``k_rows_resident``: a wavefront per row, the shared state replicated in every workgroup, four self-validating
+    messages per change) instead of ``k_rows_decide`` + ``k_rows_apply`` per change.  Same arithmetic in the same order:
+    step, multipliers, active set and change count are the same BITS - cold start, a warm-started second subproblem
+    (the warm start's removals run as two-launch pairs in front of the resident launch) and a third one."""
+    rng = np.random.default_rng(n + 7)
+    Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+    A, cc = np.vstack([C, G]), np.concatenate([c, h])
+    results, stats = {}, {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("OGSQP_RESIDENT", form)
+        core = _sqp_native.QpCore(n, meq, mg)
+        out = []
+        for rep in range(3):
+            core.set_factor(Z * (1.0 + 0.25 * rep))
+            d, mult, bm, status, iters = core.solve(A, g * (1.0 + 0.1 * rep), cc, lb, ub)
+            out.append((d.copy(), mult.copy(), bm.copy(), status, iters, sorted(int(v) for v in core.get_active())))
+        stats[form] = core.resident_stats()
+        assert core.recoveries() == 0
+        core.close()
+        results[form] = out
+    monkeypatch.delenv("OGSQP_RESIDENT")
+    assert stats["0"] == (0, 0)
+    launches, changes = stats["1"]
+    assert launches >= 3 and changes > 20
+    assert results["0"][0][4] > 20                                    # the active-set loop did run
+    for (d0, m0, b0, s0, i0, a0), (d1, m1, b1, s1, i1, a1) in zip(results["0"], results["1"]):
+        assert s0 == s1 == 1 and i0 == i1 and a0 == a1, (s0, s1, i0, i1)
+        assert np.array_equal(d0, d1) and np.array_equal(m0, m1) and np.array_equal(b0, b1)
+
+
+@pytest.mark.gpu
 def test_device_resident_jacobian_equals_host_staged():
     """og_qp_solve_dev on the Jacobian the sweep kernel left in HBM == og_qp_solve on its host copy;
     og_jt_times gives the cost gradient and the gradient of the Lagrangian."""

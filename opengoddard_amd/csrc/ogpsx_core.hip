@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -135,6 +136,9 @@ struct og_problem_s {
     // N): the host's scatter of a downloaded block is one memcpy per run instead of one store per entry
     std::vector<int64_t> run_ptr;       // n + 1: runs of column j = [run_ptr[j], run_ptr[j + 1])
     std::vector<int32_t> run_row, run_len;
+    std::vector<int64_t> run_off;       // per run: where it goes in a full n x m matrix (j * m + row): the scatter is one
+                                        // flat loop over runs that asks for the destination lines a few runs ahead
+    hipEvent_t down_ev[4] = {nullptr, nullptr, nullptr, nullptr};    // the packed block comes down in up to four pieces
     int64_t* d_indptr = nullptr;
     int32_t* d_rows = nullptr;          // the pattern's row indices, flat (pack / unpack read them coalesced)
     // host-pointer entry points: pinned staging ([x | h] up, [packed non-zeros | F | non-finite count] down)
@@ -147,6 +151,10 @@ struct og_problem_s {
         double* ptr;
         int lo, hi;
         bool dirty;                     // holds a NaN fill: zero it before the next scatter
+        double* mapped;                 // round 6: the matrix is page-locked and mapped into the device's address space
+                                        // (hipHostRegister): the one-launch sweep writes its non-zeros - and F(x0) into
+                                        // the pinned staging buffer - straight over PCIe: no packed copy, no host scatter;
+                                        // nullptr: the packed download + scatter (registration refused, OGPSX_HOST=staged)
     };
     std::vector<host_reg> host_regs;
     // column sharding (og_shard_plan)
@@ -264,6 +272,7 @@ int ensure_pattern(og_problem_s* p) {
     p->run_ptr.assign((size_t)n + 1, 0);
     p->run_row.clear();
     p->run_len.clear();
+    p->run_off.clear();
     for (int j = 0; j < n; ++j) {
         const int64_t lo = p->indptr[(size_t)j], hi = p->indptr[(size_t)j + 1];
         for (int64_t i = lo; i < hi;) {
@@ -271,6 +280,7 @@ int ensure_pattern(og_problem_s* p) {
             while (e < hi && p->rows[(size_t)e] == p->rows[(size_t)e - 1] + 1) ++e;
             p->run_row.push_back(p->rows[(size_t)i]);
             p->run_len.push_back((int32_t)(e - i));
+            p->run_off.push_back((int64_t)j * (int64_t)p->m + (int64_t)p->rows[(size_t)i]);
             i = e;
         }
         p->run_ptr[(size_t)j + 1] = (int64_t)p->run_row.size();
@@ -315,6 +325,33 @@ og_problem_s::host_reg* find_host_reg(og_problem_s* p, const double* JT, int lo,
 // After a sweep / exact Jacobian into the handle's own registered buffer: bring the result to the host.  A
 // registered host matrix receives the packed non-zeros (one pinned copy together with F and the count of
 // non-finite rows) and a scatter; anything else, and any sweep with non-finite rows, the dense block.
+// OGPSX_TIMING=1: where a host-pointer sweep spends its time (upload enqueue, launch, copy enqueue, wait, scatter),
+// averaged over 64 calls, on stderr
+struct host_clock {
+    bool on = getenv("OGPSX_TIMING") != nullptr;
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    double last = 0.0;
+    int calls = 0;
+    static double now() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    void start() { if (on) last = now(); }
+    void mark(int slot) {
+        if (!on) return;
+        const double n = now();
+        t[slot] += n - last;
+        last = n;
+    }
+    void done() {
+        if (!on || ++calls < 64) return;
+        fprintf(stderr, "[ogpsx timing] host sweep, us per call: upload %.1f, launch %.1f, copy enqueue %.1f, wait %.1f, "
+                        "F + flags %.1f, scatter %.1f\n", 1e6 * t[0] / calls, 1e6 * t[1] / calls, 1e6 * t[2] / calls,
+                1e6 * t[3] / calls, 1e6 * t[4] / calls, 1e6 * t[5] / calls);
+        for (double& v : t) v = 0.0;
+        calls = 0;
+    }
+} g_host_clock;
+
 int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, const double* d_src = nullptr,
                    bool already_packed = false) {
     const size_t need = (size_t)(hi - lo) * (size_t)p->m;
@@ -343,32 +380,76 @@ int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, cons
         rc = p->launch(&a, 8, p->stream);
         if (rc) return fail(100 + rc, std::string("og_fd_sweep: pack: ") + hipGetErrorString((hipError_t)rc));
     }
-    OG_HIP(hipMemcpyAsync(p->h_down, p->d_down, sizeof(double) * down, hipMemcpyDeviceToHost, p->stream));
-    OG_HIP(hipStreamSynchronize(p->stream));
-    const bool bad = p->h_down[(size_t)nnz + (size_t)p->m] != 0.0;
-    if (F0) memcpy(F0, p->h_down + nnz, sizeof(double) * (size_t)p->m);
-    if (bad) {                           // rows of NaN in every column: the dense block
-        OG_HIP(hipMemcpyAsync(JT, d_src, sizeof(double) * need, hipMemcpyDeviceToHost, p->stream));
-        OG_HIP(hipStreamSynchronize(p->stream));
-        reg->dirty = true;
-        return 0;
+    // The packed block comes down in up to four pieces, each with an event behind it, and the host scatters piece c
+    // while piece c + 1 crosses PCIe (round 6; measured before, C3: 39 us waiting for upload + launch + ONE copy, then
+    // 43 us of scatter - the destination lines of an 18.6 MB matrix are cache misses: the loop asks for them a few runs
+    // ahead).  F(x0) and the count of non-finite rows travel behind the last piece.
+    static const int pieces_wanted = [] { const char* e = getenv("OGPSX_DOWN_PIECES"); return e ? atoi(e) : 4; }();
+    const int64_t run_lo = p->run_ptr[(size_t)lo], run_hi = p->run_ptr[(size_t)hi];
+    const int pieces = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(4, pieces_wanted), nnz / 16384));
+    int64_t piece_run[5], piece_val[5];
+    piece_run[0] = run_lo;
+    piece_val[0] = 0;
+    {
+        // cut at column boundaries nearest to equal shares of the values
+        int col = lo;
+        for (int c = 1; c < pieces; ++c) {
+            const int64_t want = first + nnz * c / pieces;
+            col = (int)(std::lower_bound(p->indptr.begin() + col, p->indptr.begin() + hi, want) - p->indptr.begin());
+            piece_run[c] = p->run_ptr[(size_t)col];
+            piece_val[c] = p->indptr[(size_t)col] - first;
+        }
+        piece_run[pieces] = run_hi;
+        piece_val[pieces] = nnz;
     }
-    if (reg->dirty) {
+    for (int c = 0; c < pieces; ++c) {
+        if (!p->down_ev[c]) OG_HIP(hipEventCreateWithFlags(&p->down_ev[c], hipEventDisableTiming));
+        const size_t from = (size_t)piece_val[c], to = c + 1 == pieces ? down : (size_t)piece_val[c + 1];
+        if (to > from)
+            OG_HIP(hipMemcpyAsync(p->h_down + from, p->d_down + from, sizeof(double) * (to - from), hipMemcpyDeviceToHost,
+                                  p->stream));
+        OG_HIP(hipEventRecord(p->down_ev[c], p->stream));
+    }
+    g_host_clock.mark(2);
+    if (reg->dirty) {                    // (a NaN fill from the sweep before: the matrix is zeroed while the copies run)
         memset(JT, 0, sizeof(double) * need);
         reg->dirty = false;
     }
-    const int m = p->m;
+    const int64_t base = (int64_t)lo * (int64_t)p->m;
+    const int64_t* off = p->run_off.data();
+    const int32_t* len = p->run_len.data();
     const double* v = p->h_down;
-    // (run by run instead of entry by entry: 10 x fewer stores at C3 - and no measurable difference, 0.093 ms per call
-    // either way: the call is its three trips over PCIe - upload, launch, download - not the host's scatter)
-    for (int j = lo; j < hi; ++j) {
-        double* row = JT + (size_t)(j - lo) * (size_t)m;
-        for (int64_t k = p->run_ptr[(size_t)j]; k < p->run_ptr[(size_t)j + 1]; ++k) {
-            const int32_t len = p->run_len[(size_t)k];
-            memcpy(row + p->run_row[(size_t)k], v, sizeof(double) * (size_t)len);
-            v += len;
+    static const int AHEAD = [] { const char* e = getenv("OGPSX_AHEAD"); return e ? atoi(e) : 24; }();
+    for (int c = 0; c < pieces; ++c) {
+        while (true) {                   // (polling: a blocking wait costs a wake-up per piece)
+            const hipError_t e = hipEventQuery(p->down_ev[c]);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) return fail(100 + (int)e, std::string("og_fd_sweep: download: ") + hipGetErrorString(e));
+        }
+        if (c == 0) g_host_clock.mark(3);
+        const int64_t k1 = piece_run[c + 1];
+        for (int64_t k = piece_run[c]; k < k1; ++k) {
+            if (k + AHEAD < run_hi) __builtin_prefetch(JT + (off[k + AHEAD] - base), 1, 3);
+            const int32_t n_ = len[k];
+            double* dst = JT + (off[k] - base);
+            if (n_ <= 4) {
+                for (int32_t i = 0; i < n_; ++i) dst[i] = v[i];
+            } else {
+                memcpy(dst, v, sizeof(double) * (size_t)n_);
+            }
+            v += n_;
         }
     }
+    g_host_clock.mark(5);
+    const bool bad = p->h_down[(size_t)nnz + (size_t)p->m] != 0.0;
+    if (F0) memcpy(F0, p->h_down + nnz, sizeof(double) * (size_t)p->m);
+    g_host_clock.mark(4);
+    if (bad) {                           // rows of NaN in every column: the dense block (over what was scattered)
+        OG_HIP(hipMemcpyAsync(JT, d_src, sizeof(double) * need, hipMemcpyDeviceToHost, p->stream));
+        OG_HIP(hipStreamSynchronize(p->stream));
+        reg->dirty = true;
+    }
+    g_host_clock.done();
     return 0;
 }
 
@@ -622,8 +703,13 @@ void og_problem_destroy(og_handle p) {
     hipFree(p->d_rows);
     hipFree(p->d_down);
     hipFree(p->d_shard_off);
+    for (auto& r : p->host_regs)
+        if (r.mapped) (void)hipHostUnregister(r.ptr);
+    (void)hipGetLastError();            // (a matrix its owner has already unmapped or freed: not this handle's error)
     if (p->h_up) hipHostFree(p->h_up);
     if (p->h_down) hipHostFree(p->h_down);
+    for (hipEvent_t ev : p->down_ev)
+        if (ev) hipEventDestroy(ev);
     for (int k = 1; k < p->launch.n_parts; ++k)
         if (p->launch.handle[k]) dlclose(p->launch.handle[k]);
     if (p->module) dlclose(p->module);
@@ -693,13 +779,40 @@ int og_jt_register_host(og_handle p, double* JT, int32_t lo, int32_t hi) {
     if (lo < 0 || hi > p->n || lo >= hi) return fail(1, "og_jt_register_host: bad column range");
     int rc = ensure_pattern(p);
     if (rc) return rc;
-    memset(JT, 0, sizeof(double) * (size_t)(hi - lo) * (size_t)p->m);
+    const size_t bytes = sizeof(double) * (size_t)(hi - lo) * (size_t)p->m;
+    memset(JT, 0, bytes);
     for (auto& r : p->host_regs)
         if (r.ptr == JT) {
             r.lo = lo, r.hi = hi, r.dirty = false;
+            if (r.mapped && og_jt_register_dev(p, r.mapped, lo, hi, p->stream) == 0) {
+                OG_HIP(hipStreamSynchronize(p->stream));
+                memset(JT, 0, bytes);
+            }
             return 0;
         }
-    p->host_regs.push_back({JT, lo, hi, false});
+    // Round 6 (0.093 ms per host-pointer sweep at C3, of which 39 us are upload + launch + the packed copy
+    // and 43 us the host's scatter of a cache-cold staging buffer): the matrix is page-locked and mapped, the sweep writes
+    // its structural non-zeros into it over PCIe itself - the same persistent-zero protocol as a device buffer
+    // (og_jt_register_dev on the mapped address: state words on the device, a NaN fill cleans itself with the next
+    // sweep).  A host that refuses the registration keeps the packed path.
+    double* mapped = nullptr;
+    static const bool staged = [] { const char* e = getenv("OGPSX_HOST"); return e && std::string(e) == "staged"; }();
+    if (!staged && p->sweep_mode == 5 && p->fused_ok) {
+        OG_HIP(hipSetDevice(p->device));
+        void* dev = nullptr;
+        if (hipHostRegister(JT, bytes, hipHostRegisterMapped) == hipSuccess) {
+            if (hipHostGetDevicePointer(&dev, JT, 0) == hipSuccess && dev &&
+                og_jt_register_dev(p, (double*)dev, lo, hi, p->stream) == 0 &&
+                hipStreamSynchronize(p->stream) == hipSuccess) {
+                mapped = (double*)dev;
+                memset(JT, 0, bytes);
+            } else {
+                (void)hipHostUnregister(JT);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    p->host_regs.push_back({JT, lo, hi, false, mapped});
     return 0;
 }
 
@@ -707,6 +820,12 @@ int og_jt_unregister_host(og_handle p, double* JT) {
     if (!p) return fail(1, "og_jt_unregister_host: null handle");
     for (size_t i = 0; i < p->host_regs.size(); ++i)
         if (p->host_regs[i].ptr == JT) {
+            if (p->host_regs[i].mapped) {
+                (void)hipStreamSynchronize(p->stream);
+                (void)og_jt_unregister_dev(p, p->host_regs[i].mapped);
+                (void)hipHostUnregister(JT);
+                (void)hipGetLastError();
+            }
             p->host_regs.erase(p->host_regs.begin() + (long)i);
             return 0;
         }
@@ -965,8 +1084,37 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
         const int rcj = own_jt(p, lo, hi);
         if (rcj) return rcj;
     }
+    g_host_clock.start();
     int rc = upload_point(p, x, hstep);
     if (rc) return rc;
+    g_host_clock.mark(0);
+    if (og_problem_s::host_reg* reg = find_host_reg(p, JT, lo, hi); reg && reg->mapped && p->sweep_mode == 5 && p->fused_ok) {
+        // mapped host matrix: ONE launch writes the non-zeros into the caller's matrix and F(x0) + the count of non-finite
+        // rows into the pinned staging buffer, both over PCIe; the host waits for the launch and is done
+        rc = ensure_staging(p, (size_t)p->m + 1);
+        if (rc) return rc;
+        void* tail = nullptr;
+        OG_HIP(hipHostGetDevicePointer(&tail, p->h_down, 0));
+        ogk_args a;
+        fill_args(p, &a, p->d_x, p->d_h, (double*)tail, reg->mapped, lo, hi);
+        if (a.jt_sparse) {
+            a.nonfinite = p->d_flags + 3;
+            p->nf_read = a.nonfinite_result;
+            a.ptail = (double*)tail;
+            rc = p->launch(&a, 5, p->stream);
+            if (rc) return launch_failed(p, rc, "og_fd_sweep");
+            g_host_clock.mark(1);
+            OG_HIP(hipStreamSynchronize(p->stream));
+            g_host_clock.mark(3);
+            if (F0) memcpy(F0, p->h_down, sizeof(double) * (size_t)p->m);
+            // (rows of NaN in every column were written by the launch itself and the next sweep cleans them, as in a
+            // device buffer; a packed download into this matrix in between - the exact mode - zeroes it first)
+            reg->dirty = p->h_down[(size_t)p->m] != 0.0;
+            g_host_clock.mark(4);
+            g_host_clock.done();
+            return 0;
+        }
+    }
     if (find_host_reg(p, JT, lo, hi) && p->sweep_mode == 5 && p->fused_ok) {
         // registered host matrix: ONE launch leaves the packed non-zeros, F(x0) and the count of non-finite rows
         // contiguous in the staging buffer, one pinned copy brings them down
@@ -985,6 +1133,7 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
             a.ptail = p->d_down + nnz;
             rc = p->launch(&a, 5, p->stream);
             if (rc) return launch_failed(p, rc, "og_fd_sweep");
+            g_host_clock.mark(1);
             return download_block(p, lo, hi, JT, F0, nullptr, true);
         }
     }

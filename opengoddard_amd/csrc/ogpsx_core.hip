@@ -384,7 +384,7 @@ int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, cons
     // while piece c + 1 crosses PCIe (round 6; measured before, C3: 39 us waiting for upload + launch + ONE copy, then
     // 43 us of scatter - the destination lines of an 18.6 MB matrix are cache misses: the loop asks for them a few runs
     // ahead).  F(x0) and the count of non-finite rows travel behind the last piece.
-    static const int pieces_wanted = [] { const char* e = getenv("OGPSX_DOWN_PIECES"); return e ? atoi(e) : 4; }();
+    static const int pieces_wanted = [] { const char* e = getenv("OGPSX_DOWN_PIECES"); return e ? atoi(e) : 1; }();
     const int64_t run_lo = p->run_ptr[(size_t)lo], run_hi = p->run_ptr[(size_t)hi];
     const int pieces = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(4, pieces_wanted), nnz / 16384));
     int64_t piece_run[5], piece_val[5];

@@ -1201,7 +1201,8 @@ struct GiState {
     int dbg;
     int dbg2;
     int warm_removals;  // k_rows_resident: changes the warm start's pairs in front of it had made
-    int pad_;
+    int arrive;         // rows mode: arrivals at the barrier between the two products of a spread warm-start removal (its own
+                        // word since round 6: `cur` is the live-buffer index of the two older kernels)
     long long tr[40];   // OGSQP_TRACE: accumulated s_memtime ticks (10 ns) per section of the update
 };
 
@@ -1307,7 +1308,7 @@ __global__ void k_gi_init(GiArgs g, const int* flag) {
         s.dbg = 0;
         s.dbg2 = 0;
         s.warm_removals = 0;
-        s.pad_ = 0;
+        s.arrive = 0;
         for (int e = 0; e < 40; ++e) s.tr[e] = 0;
         *g.st = s;
     }
@@ -2885,6 +2886,8 @@ int og_qp_create(int32_t abi_version, int32_t device, int32_t n, int32_t m_eq, i
             return fail(4, "og_qp_create: rows of more than " + std::to_string(LQ_PT_MAX * LQ_CPT_MAX) +
                                " entries need the wide sweep (OGSQP_LQ / OGSQP_WIDE must not turn it off)");
         }
+        // (beyond 8192 variables a lost wait cannot fall back to a form without one: the long bound of rounds 3-4 there)
+        if (beyond_fallback) qp->spin_limit = 1 << 25;
         const char* spin = getenv("OGSQP_SPIN_LIMIT");
         if (spin && atoi(spin) > 0) qp->spin_limit = atoi(spin);
         const char* wspread = getenv("OGSQP_WARM_SPREAD");
@@ -3565,8 +3568,22 @@ int og_qp_solve_dev(og_qp_handle qp, const double* d_jt, int64_t ld, const doubl
     int rc = qp_solve_attempt(qp, d_jt, ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status, iterations,
                               hip_stream, &lost);
     if (rc || !lost) return rc;
-    if (qp->n1 > LQ_PT_MAX * LQ_CPT_MAX)
-        return fail(7, "og_qp_solve_dev: an inter-workgroup wait gave up and rows of this length have no form without one");
+    if (qp->n1 > LQ_PT_MAX * LQ_CPT_MAX) {
+        // rows of this length have no form that waits for nothing: the same attempt is run again, with the lanes drained -
+        // a wait gives up because a workgroup was not resident at that moment (another stream, rank or tenant), which the
+        // next attempt need not meet (nothing was committed by the lost one)
+        for (int again = 0; again < 2 && lost; ++again) {
+            (void)hipDeviceSynchronize();
+            ++qp->recoveries;
+            lost = 0;
+            rc = qp_solve_attempt(qp, d_jt, ld, g, c, dl, du, augmented, rho, d, mult, bound_mult, status, iterations, hip_stream,
+                                  &lost);
+            if (rc) return rc;
+        }
+        if (lost)
+            return fail(7, "og_qp_solve_dev: an inter-workgroup wait gave up three times and rows of this length have no form without one");
+        return 0;
+    }
     // The look-ahead sweep and the chained triangular solves hand data between workgroups of ONE launch and assume the
     // workgroups they wait for are resident; on a device shared with other streams, ranks or tenants that may not hold,
     // and a bounded wait gives up.  Nothing was committed: the subproblem is solved again with the forms that wait for

@@ -226,9 +226,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __hip_atomic_fetch_add(&st->cur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&st->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int spins = 0;
-                while (__hip_atomic_load(&st->cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.G1) {
+                while (__hip_atomic_load(&st->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.G1) {
                     if (++spins > a.spin_limit) {
                         __hip_atomic_store(a.lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_decide(RowsArgs a) {
             if (!s_last) return;
             if (tid == 0) {
                 st->ticket = 0u;
-                st->cur = 0;                                   // (every workgroup has passed the wait above)
+                st->arrive = 0;                                // (every workgroup has passed the wait above)
             }
             worst = INFINITY;
             kworst = 0x7fffffff;
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_rows_init(RowsArgs a, const do
         s.dbg = 0;
         s.dbg2 = 0;
         s.warm_removals = 0;
-        s.pad_ = 0;
+        s.arrive = 0;
         for (int e = 0; e < 40; ++e) s.tr[e] = 0;
         *g.st = s;
         RowsDecision rec;

@@ -315,7 +315,7 @@ SOLVE_OPTIONS = {"polar_tsto": {"maxiter": 400}, "low_thrust": {}, "launch4": {"
                  "goddard": {"ftol": 1e-10}}
 
 
-def solve_leg(name, options=None, check=True):
+def solve_leg(name, options=None, check=True, perturb_seed=None, start=None, max_restarts=None):
     """Second half of BASELINE.json's metric, measured whole: ``Problem.solve`` (this package's, default SQP core = the
     HIP one at these sizes) from the problem's own initial guess to SLSQP's exit mode 0 - wall-clock of the call, split
     into callbacks (values + Jacobians), QP subproblems and BFGS updates - and, NOT timed, the independent check of
@@ -324,8 +324,20 @@ def solve_leg(name, options=None, check=True):
     import contextlib
     import io
     from opengoddard_amd import problems
+    import numpy as np
     options = dict(SOLVE_OPTIONS.get(name, {}) if options is None else options)
     prob, obj = problems.build(name)
+    if start is not None:                                     # (a stored iterate instead of the problem's own guess)
+        prob.p = np.array(start, dtype=float)
+    if perturb_seed is not None:
+        # a neighbouring start: x0 + 1e-6 N(0, 1), clipped to the bounds - the path to SLSQP's exit depends on rounding
+        # (one wall-clock per configuration is not a reproducible measurement), so the leg is run from
+        # several seeded starts and reported as median and range
+        lo = np.array([-np.inf if b[0] is None else b[0] for b in prob.bounds], dtype=float)
+        hi = np.array([np.inf if b[1] is None else b[1] for b in prob.bounds], dtype=float)
+        prob.p = np.clip(prob.p + 1e-6 * np.random.default_rng(perturb_seed).standard_normal(prob.p.size), lo, hi)
+    if max_restarts is not None:
+        prob.maxIterator = int(max_restarts)
     buf = io.StringIO()
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(buf):
@@ -343,8 +355,17 @@ def solve_leg(name, options=None, check=True):
            "qp_solves": int(sum(t["qp_solves"] for t in tm)),
            "active_set_changes": int(sum(t["qp_iterations"] for t in tm)),
            "recoveries": int(sum(t.get("recoveries", 0) for t in tm)), "cost": float(res.fun),
-           "what": "Problem.solve(obj, **options) from the problem's initial guess; wall_s is the whole call "
-                   "(tracing, module load and handle creation included)"}
+           "start": ("a stored iterate" if start is not None else "the problem's initial guess") +
+                    ("" if perturb_seed is None else " + 1e-6 N(0, 1), seed %d, clipped to the bounds" % perturb_seed),
+           "what": "Problem.solve(obj, **options); wall_s is the whole call (tracing, module load and handle creation "
+                   "included)"}
+    if tm and "resident_launches" in tm[-1]:
+        out["resident_active_set"] = {"launches": int(tm[-1]["resident_launches"]), "changes": int(tm[-1]["resident_changes"]),
+                                      "note": "subproblems whose active-set loop ran as ONE launch (k_rows_resident) and the "
+                                              "changes those launches made, totals of the QP handle"}
+    out["m_eq"] = int(prob._engine.m_eq)
+    if start is not None:
+        out["_x"] = np.array(res.x, dtype=float)              # (bounded_c5_leg hands it to the oracle and drops it)
     if check:
         from oracle import kkt
         t0 = time.perf_counter()
@@ -354,6 +375,59 @@ def solve_leg(name, options=None, check=True):
         out["kkt"] = k
         out["cost_by_the_oracle"] = k["cost"]
     prob._engine.close()
+    return out
+
+
+def solve_starts(name, starts=5, options=None, first=None):
+    """The solve leg from ``starts`` neighbouring starts (the problem's own guess first, then x0 + 1e-6 N(0, 1) with seeds
+    1 .. starts - 1): time to SLSQP's exit mode 0 as median and range, every start's cost and its gap to the best cost any
+    of them reached.  ``first``: an already measured run from the unperturbed guess (with its KKT check)."""
+    import statistics
+    runs = [first if first is not None else solve_leg(name, options, check=False)]
+    for seed in range(1, int(starts)):
+        try:
+            runs.append(solve_leg(name, options, check=False, perturb_seed=seed))
+        except Exception as exc:                               # a failed start is reported, not hidden
+            runs.append({"error": repr(exc), "start": "seed %d" % seed})
+    done = [r for r in runs if "wall_s" in r]
+    walls = sorted(r["wall_s"] for r in done)
+    best = min(r["cost"] for r in done)
+    return {"workload": name, "starts": len(runs), "exit_mode_0": sum(1 for r in done if r.get("exit_mode") == 0),
+            "wall_s_median": statistics.median(walls), "wall_s_min": walls[0], "wall_s_max": walls[-1],
+            "qp_solves_median": statistics.median(r["qp_solves"] for r in done),
+            "best_cost": best,
+            "per_start": [{"start": r.get("start"), "wall_s": r.get("wall_s"), "exit_mode": r.get("exit_mode"),
+                           "qp_solves": r.get("qp_solves"), "active_set_changes": r.get("active_set_changes"),
+                           "cost": r.get("cost"), "cost_gap_to_best": (r["cost"] - best) if "cost" in r else None,
+                           "error": r.get("error")} for r in runs],
+            "note": "minimisation: cost_gap_to_best >= 0; SLSQP's ftol test stops where the cost changes by less than ftol "
+                    "between major iterations, which in a flat valley is path dependent (DESIGN.md section 9)"}
+
+
+def bounded_c5_leg(seconds=90.0):
+    """C5 (launch4, n = 6148) needs minutes from its own guess to SLSQP's exit; the line carries a bounded piece: 120 major
+    iterations from a late iterate of such a solve (tests/golden/start_launch4.npz - an input made by this package's own
+    solver, tools/make_start_launch4.py), and what the oracle says about the iterate SLSQP holds afterwards."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "start_launch4.npz")
+    G = np.load(path)
+    t0 = time.perf_counter()
+    out = solve_leg("launch4", {"maxiter": 120}, check=False, start=G["x"], max_restarts=1)
+    out["start_cost"] = float(G["cost_there"])
+    out["bounded"] = "one restart of 120 major iterations from tests/golden/start_launch4.npz"
+    left = seconds - (time.perf_counter() - t0)
+    if left > 45.0:
+        try:
+            from oracle import kkt
+            from opengoddard_amd import problems
+            prob, obj = problems.build("launch4")
+            tk = time.perf_counter()
+            k = kkt.residuals(prob, obj, out.pop("_x"), out["m_eq"], max_rounds=1)
+            k["checker"] = "oracle/kkt.py (max_rounds=1), %.1f s of CPU" % (time.perf_counter() - tk)
+            out["kkt"] = k
+        except Exception as exc:
+            out["kkt"] = {"error": repr(exc)}
+    out.pop("_x", None)
     return out
 
 
@@ -529,6 +603,10 @@ def main():
     ap.add_argument("--no-cold-start", action="store_true", help="skip the forced rebuild of the workload's kernel module")
     ap.add_argument("--no-solve", action="store_true",
                     help="skip the solve leg (Problem.solve to exit mode 0 at C3 and C4 + the oracle's KKT check: ~45 s)")
+    ap.add_argument("--solve-starts", type=int, default=5,
+                    help="the solve leg is run from this many neighbouring starts (x0 + 1e-6 N(0,1), seeded) and reported as "
+                         "median and range (about 17 s each at C3)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the bounded C5 piece of the solve leg (~60 s)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 from ONE process: og_comm_init + og_multi_fd_sweep_enqueue over the N devices (no launcher)")
     a = ap.parse_args()
@@ -968,9 +1046,17 @@ def main():
         # headline workload, and C4 (BASELINE.json's next configuration) beside it when the headline is C3
         try:
             result["solve"] = solve_leg(a.workload)
+            # ... from --solve-starts neighbouring starts: median and range (one start is one sample of a chaotic path)
+            if a.solve_starts > 1:
+                result["solve"]["starts"] = solve_starts(a.workload, a.solve_starts, first=result["solve"])
             if a.workload == "polar_tsto":
                 # C4 with the reference's defaults, and with the tolerance at which SLSQP's exit test means a KKT point
-                result["solve"]["also"] = [solve_leg("low_thrust"), solve_leg("low_thrust", {"ftol": 1e-8, "maxiter": 400})]
+                c4 = solve_leg("low_thrust")
+                if a.solve_starts > 1:
+                    c4["starts"] = solve_starts("low_thrust", a.solve_starts, first=c4)
+                result["solve"]["also"] = [c4, solve_leg("low_thrust", {"ftol": 1e-8, "maxiter": 400})]
+                if not a.no_c5:
+                    result["solve"]["also"].append(bounded_c5_leg())
         except Exception as exc:                               # a failed leg must not lose the line
             result["solve"] = {"error": repr(exc)}
     if ranks_report is not None:

@@ -349,6 +349,8 @@ def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivati
             reset = True
         timing["bfgs"] += time.perf_counter() - t
     timing["recoveries"] = core.recoveries() - recoveries_before
+    # (round 6) how much of the active-set work ran as the one resident launch (csrc/ogsqp_resident.h): totals of the handle
+    timing["resident_launches"], timing["resident_changes"] = core.resident_stats()
     if getattr(engine, "_sqp_cache", None) is None:
         core.close()
     message = EXIT_MODES.get(int(status), "mode %d" % status)

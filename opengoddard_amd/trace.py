@@ -19,13 +19,67 @@ Anything else raises :class:`TraceError` - there is no silent CPU fallback.
 from __future__ import annotations
 
 import numbers
+import os
 import threading
 
 import numpy as np
 
 
+# what to write instead, by what the message is about (there is no CPU fallback: the error has to say how to go on)
+_HINTS = (
+    ("control flow", "use np.where(condition, a, b) (both branches are evaluated), np.maximum / np.minimum / np.clip, or a "
+                     "mask assignment `v[v < lo] = lo`; a condition on a CONSTANT (problem data, a node count) is fine"),
+    ("NumPy routine", "traceable are the elementwise ufuncs, np.where / clip / hstack / concatenate / append / stack / vstack, "
+                      "np.sum / mean / prod / min / max / dot / matmul / cumsum / diff / roll / flip / take / interp / trapz, "
+                      "slicing and index arrays; express the routine through those, or precompute what depends on problem "
+                      "data only outside the callback"),
+    ("NumPy function", "traceable are the elementwise ufuncs, np.where / clip / hstack / concatenate / append / stack / vstack, "
+                       "np.sum / mean / prod / min / max / dot / matmul / cumsum / diff / roll / flip / take / interp / trapz, "
+                       "slicing and index arrays; express the routine through those, or precompute what depends on problem "
+                       "data only outside the callback"),
+    ("ufunc", "see the list of traced functions in DESIGN.md section 1 (exp, log, sin ... arctan2, hypot, cbrt, x ** y); a "
+              "special function can be tabulated and read through np.interp or a linear scipy.interpolate.interp1d"),
+    ("interp", "linear interpolation (np.interp, scipy.interpolate.interp1d(kind='linear')) is traced; tabulate a smoother "
+               "interpolant on a finer grid"),
+    ("keyword", "call the reduction with axis= only (no out=, keepdims=, where=, dtype=)"),
+    ("float(", "keep the value a traced scalar - arithmetic, comparisons inside np.where and indexing results work on it"),
+)
+
+
+def _user_frame():
+    """(file, line, source text) of the innermost frame that is the user's code: not this package, not NumPy / SciPy."""
+    import linecache
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    frame = sys._getframe(2)
+    while frame is not None:
+        fname = frame.f_code.co_filename
+        low = fname.replace("\\", "/")
+        if not (os.path.abspath(fname).startswith(here) or "/numpy/" in low or "/scipy/" in low or low.startswith("<")):
+            return fname, frame.f_lineno, (linecache.getline(fname, frame.f_lineno) or "").strip()
+        frame = frame.f_back
+    return None
+
+
 class TraceError(RuntimeError):
-    """A callback did something the tracer cannot turn into device code."""
+    """A callback did something the tracer cannot turn into device code.  The message names the line of the user's
+    callback that did it and what to write instead (VERDICT r5 #8d: with no CPU fallback the error is the documentation)."""
+
+    def __init__(self, message=""):
+        message = str(message)
+        where = None
+        try:
+            where = _user_frame()
+        except Exception:
+            where = None
+        self.user_frame = where
+        if where and "\n  at " not in message:
+            message += "\n  at %s:%d:  %s" % where
+            for key, hint in _HINTS:
+                if key in message:
+                    message += "\n  instead: " + hint
+                    break
+        super().__init__(message)
 
 
 class TraceAttributeError(TraceError, AttributeError):

@@ -103,3 +103,16 @@ def assert_zero_pattern(program, cols, JT, JT_ref, what=""):
     assert not JT_ref[~structural].any(), "the reference has a non-zero outside the traced pattern %s" % what
     differ = (JT != 0) != (JT_ref != 0)
     assert differ.sum() <= 2 + 2e-4 * structural.sum(), "zero pattern differs in %d entries %s" % (differ.sum(), what)
+
+
+def record_measurement(test, **values):
+    """Append what a GPU test measured to gpurun_out/test_measurements.jsonl (scratch that gpurun merges back): the
+    numbers behind the bounds the tests assert - so that a bound can be set from a measurement, not from a guess."""
+    import json
+    folder = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(folder, exist_ok=True)
+        with open(os.path.join(folder, "test_measurements.jsonl"), "a") as fh:
+            fh.write(json.dumps(dict(values, test=test)) + "\n")
+    except OSError:
+        pass

@@ -160,7 +160,11 @@ def _kkt_of_a_solve(name, options, capsys, start=None):
 # with 1e-8; C3's second stage has a bang-bang tangential thrust, whose switching nodes keep a residual of 1.3e-2 ..
 # 2.9e-2 however long SLSQP runs (ftol 1e-8: 16 000 subproblems, exit mode 9, cost -0.023434 < -0.022789; exact Jacobians:
 # the same) - "exit mode 0" there is SLSQP's flat-valley stop, which SciPy's own core shares by construction.
-STATIONARITY_BOUND = {"polar_tsto": 5e-2, "low_thrust": 1e-4}
+# (round 6, ADVICE r5: the C3 bound follows what was measured - 1.6e-2 on the default path, up to 2.9e-2 on its variants -
+# with a small margin, where round 5 allowed 5e-2; and the cost has to lie in the band every stop of that valley has shown
+# since round 1, -0.02348 .. -0.02279, not merely "within 5 %")
+STATIONARITY_BOUND = {"polar_tsto": 3.5e-2, "low_thrust": 1e-4}
+COST_BAND = {"polar_tsto": (-0.0236, -0.0227), "low_thrust": (41.4540, 41.4550)}
 
 
 @pytest.mark.parametrize("name,options", [("polar_tsto", {"maxiter": 400}), ("low_thrust", {})])
@@ -171,7 +175,45 @@ def test_converged_optimum_satisfies_the_oracles_kkt_conditions(name, options, c
     res, k, wall = _kkt_of_a_solve(name, options, capsys)
     assert abs(res.fun - k["cost"]) <= 1e-9 * max(1.0, abs(k["cost"]))       # the GPU's cost IS the reference path's
     assert k["feasibility"] <= 1e-6 and k["dual"] <= KKT_BOUND and k["complementarity"] <= KKT_BOUND
+    from conftest import record_measurement
+    record_measurement("converged_optimum_kkt", name=name, wall_s=wall, cost=float(k["cost"]), stationarity=float(k["stationarity"]),
+                       feasibility=float(k["feasibility"]))
     assert k["stationarity"] <= STATIONARITY_BOUND[name], k
+    assert COST_BAND[name][0] <= k["cost"] <= COST_BAND[name][1], k["cost"]
+
+
+def test_both_sqp_cores_reach_exit_mode_0_at_the_same_optimum_of_a_mid_size_problem(capsys):
+    """"SciPy's own core shares this stop by construction" was an argument, not a test.  C4's problem on 30 LGL
+    nodes (n = 301, above the size from which ``sqp_core="auto"`` takes the HIP core) is small enough for SciPy's Fortran
+    core to finish: both cores, same callbacks (the GPU's), the reference's defaults - both stop with exit mode 0, at the
+    same cost to 1e-4, and the oracle's KKT residuals of the two points are of one size (the HIP core's at most 3 x
+    SciPy's, feasibility and multiplier signs to 1e-6 on both)."""
+    import __graft_entry__ as entry
+    from oracle import kkt
+    found = {}
+    for core in ("scipy", "hip"):
+        prob, obj = problems.build("low_thrust", nodes=entry.BOTH_CORES_NODES)
+        assert prob.number_of_variables == 301
+        t0 = time.perf_counter()
+        prob.solve(obj, sqp_core=core)
+        wall = time.perf_counter() - t0
+        res = prob.last_result
+        k = kkt.residuals(prob, obj, res.x, prob._engine.m_eq)
+        found[core] = (res, k, wall)
+        prob._engine.close()
+    capsys.readouterr()
+    for core, (res, k, wall) in found.items():
+        print("low_thrust x 30, %s core: exit mode %d in %.1f s, cost %.9g, oracle: kkt %.2e feasibility %.2e stationarity %.2e"
+              % (core, res.status, wall, res.fun, k["kkt"], k["feasibility"], k["stationarity"]))
+    from conftest import record_measurement
+    record_measurement("both_cores_mid_size", **{core: {"wall_s": w, "cost": float(r.fun), "kkt": float(k["kkt"]), "status": int(r.status)}
+                                                 for core, (r, k, w) in found.items()})
+    (rs, ks, _), (rh, kh, _) = found["scipy"], found["hip"]
+    assert rs.status == 0 and rh.status == 0
+    assert abs(rh.fun - rs.fun) <= 1e-4 * abs(rs.fun)
+    for k in (ks, kh):
+        assert k["feasibility"] <= 1e-6 and k["dual"] <= KKT_BOUND and k["complementarity"] <= KKT_BOUND
+    assert kh["kkt"] <= max(3.0 * ks["kkt"], 2e-4), (kh["kkt"], ks["kkt"])
 
 
 def test_a_tighter_ftol_brings_the_kkt_residual_of_the_smooth_configuration_below_1e_5(capsys):

@@ -507,6 +507,9 @@ def test_gpu_qp_replays_scipy_goldens_at_baseline_sizes(name, worst, typical, mo
     mism = np.array([t["mismatch"] for t in trace if "mismatch" in t])
     step = np.array([t["step"] for t in trace if "mismatch" in t])
     assert len(mism) >= int(G["maxiter"]) - 2
+    from conftest import record_measurement
+    record_measurement("gpu_qp_replays_scipy_goldens", name=name, worst_ratio=float((mism / np.maximum(step, 1e-3)).max()),
+                       bound=worst, subproblems=int(len(mism)))
     assert np.all(mism <= worst * np.maximum(step, 1e-3)), (mism / np.maximum(step, 1e-3)).max()
 
 

@@ -485,8 +485,14 @@ def test_gpu_qp_replays_scipy_iterates(name, maxiter, ftol, update, monkeypatch)
     assert np.median(mism / np.maximum(step, 1e-12)) <= 1e-9
 
 
+# (round 6, VERDICT r5 #5: the GPU replay's bounds follow what it measures - gpurun_out/test_measurements.jsonl, copied to
+# profiles/r06_test_measurements.jsonl: worst mismatch / step 2.9e-5 at C3, 4.2e-11 at C4, 5.7e-5 at C5 - with a margin of
+# 3-4 x, where round 5 allowed 1e-4 / 1e-4 / 2e-3; the referee puts either solver at 1e-5 .. 4e-5 of C5's first step)
+GPU_REPLAYS = [("polar_tsto", 1e-4, 1e-5), ("low_thrust", 1e-9, 1e-10), ("launch4", 2e-4, 2e-4)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,worst,typical", BASELINE_REPLAYS + [("launch4", 2e-3, 2e-4)])
+@pytest.mark.parametrize("name,worst,typical", GPU_REPLAYS)
 def test_gpu_qp_replays_scipy_goldens_at_baseline_sizes(name, worst, typical, monkeypatch):
     """C3, C4 and (round 4) C5: SciPy's golden iterates reproduced with every QP subproblem - the relaxed ones included -
     solved by the HIP core in its default configuration (row-parallel active-set method, warm-started from the previous

@@ -131,7 +131,8 @@ int og_jt_unregister_dev(og_handle h, double* d_JT);
  * Round 6: the registration page-locks JT and maps it into the device's address space (hipHostRegister; undone by
  * og_jt_unregister_host / og_problem_destroy, which must come before the matrix is freed), and og_fd_sweep's one
  * launch then writes the structural non-zeros straight into JT over PCIe - no packed copy, no host scatter (C3:
- * 0.097 -> 0.052 ms per call, C4 0.21 -> 0.096, C5 0.38 -> 0.17) - under the same persistent-zero protocol as a
+ * 0.097 -> 0.047 ms per call, C4 0.21 -> 0.088, C5 0.38 -> 0.17; x and h are read in place too, out of a pinned
+ * buffer of the handle, instead of being copied first) - under the same persistent-zero protocol as a
  * device buffer (a NaN fill is cleaned by the next sweep).  Where the host refuses the mapping (or OGPSX_HOST=staged)
  * the packed transfer + scatter above is what runs; the matrix in JT is the same either way. */
 int og_jt_register_host(og_handle h, double* JT, int32_t col_lo, int32_t col_hi);

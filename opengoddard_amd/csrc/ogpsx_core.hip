@@ -143,6 +143,7 @@ struct og_problem_s {
     int32_t* d_rows = nullptr;          // the pattern's row indices, flat (pack / unpack read them coalesced)
     // host-pointer entry points: pinned staging ([x | h] up, [packed non-zeros | F | non-finite count] down)
     double* h_up = nullptr;
+    double* h_xh = nullptr;             // mapped host matrix: [x | h] the launch reads in place
     double* h_down = nullptr;
     double* d_down = nullptr;
     size_t down_capacity = 0;
@@ -707,6 +708,7 @@ void og_problem_destroy(og_handle p) {
         if (r.mapped) (void)hipHostUnregister(r.ptr);
     (void)hipGetLastError();            // (a matrix its owner has already unmapped or freed: not this handle's error)
     if (p->h_up) hipHostFree(p->h_up);
+    if (p->h_xh) hipHostFree(p->h_xh);
     if (p->h_down) hipHostFree(p->h_down);
     for (hipEvent_t ev : p->down_ev)
         if (ev) hipEventDestroy(ev);
@@ -1085,18 +1087,34 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
         if (rcj) return rcj;
     }
     g_host_clock.start();
-    int rc = upload_point(p, x, hstep);
+    // (mapped matrix: the launch also reads x | h in place, out of a pinned buffer of their own - non-coherent host memory,
+    // cached in L2 for the launch and visible at its boundary - instead of waiting for their copy: 5 us of a call.
+    // OGPSX_HOST=copyx keeps the copy.)
+    static const bool readx_mode = [] { const char* e = getenv("OGPSX_HOST"); return !(e && std::string(e) == "copyx"); }();
+    og_problem_s::host_reg* mreg = find_host_reg(p, JT, lo, hi);
+    const bool in_place = readx_mode && mreg && mreg->mapped && p->sweep_mode == 5 && p->fused_ok;
+    int rc = in_place ? 0 : upload_point(p, x, hstep);
     if (rc) return rc;
     g_host_clock.mark(0);
-    if (og_problem_s::host_reg* reg = find_host_reg(p, JT, lo, hi); reg && reg->mapped && p->sweep_mode == 5 && p->fused_ok) {
+    if (og_problem_s::host_reg* reg = mreg; reg && reg->mapped && p->sweep_mode == 5 && p->fused_ok) {
         // mapped host matrix: ONE launch writes the non-zeros into the caller's matrix and F(x0) + the count of non-finite
         // rows into the pinned staging buffer, both over PCIe; the host waits for the launch and is done
         rc = ensure_staging(p, (size_t)p->m + 1);
         if (rc) return rc;
         void* tail = nullptr;
         OG_HIP(hipHostGetDevicePointer(&tail, p->h_down, 0));
+        const double *kx = p->d_x, *kh = p->d_h;
+        if (in_place) {
+            if (!p->h_xh) OG_HIP(hipHostMalloc(&p->h_xh, sizeof(double) * 2 * (size_t)p->n, hipHostMallocNonCoherent | hipHostMallocMapped));
+            memcpy(p->h_xh, x, sizeof(double) * (size_t)p->n);
+            memcpy(p->h_xh + p->n, hstep, sizeof(double) * (size_t)p->n);
+            void* dxh = nullptr;
+            OG_HIP(hipHostGetDevicePointer(&dxh, p->h_xh, 0));
+            kx = (const double*)dxh;
+            kh = kx + p->n;
+        }
         ogk_args a;
-        fill_args(p, &a, p->d_x, p->d_h, (double*)tail, reg->mapped, lo, hi);
+        fill_args(p, &a, kx, kh, (double*)tail, reg->mapped, lo, hi);
         if (a.jt_sparse) {
             a.nonfinite = p->d_flags + 3;
             p->nf_read = a.nonfinite_result;

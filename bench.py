@@ -857,6 +857,13 @@ def main():
     chain = (measured_chain(a.workload, a.nodes) if (world == 1 and rank == 0 and fused and not a.quick)
              else {"chain_us": None})
     chain_us = chain.get("chain_us") or DEPENDENT_CHAIN_US
+    # VERDICT r5 #8a: `frac` (and `achieved`) on the line are the ones that FOLLOW FROM profiles/ - the committed rocprofv3
+    # average duration of this workload's kernel (a dispatch's own begin -> end, 5-10 % longer than the back-to-back
+    # period the HIP-event batches measure, because consecutive launches overlap their ramp-up and drain) - whenever such a
+    # profile of the workload at this size exists; the live HIP-event batch mean stands beside it, and alone otherwise.
+    achieved_events = achieved
+    if rocprof and world == 1:
+        achieved = alg_bytes / (rocprof["average_us"] * 1e-6) / 1e9
     result = {
         "metric": "NLP-callback evals/sec (cost+constr+FD-Jacobian)",
         "value": (3 * n + 2) * a.steps / elapsed,
@@ -915,6 +922,11 @@ def main():
                                                         chain.get("error") or "not measured in a --quick / multi-rank run")),
                                                 "dependent_chain_by_kind_us": chain.get("by_kind_us")},
                      "frac_of_latency_floor": max(floor_ms * 1e3, chain_us) / (kern_ms_mean * 1e3),
+                     "frac_source": ("committed rocprofv3 average of this workload (%s)" % rocprof["source"]
+                                     if rocprof and world == 1 else "HIP-event batch mean of this run (no committed profile of "
+                                                                    "this workload / size, or a multi-rank run)"),
+                     "achieved_hip_events_batch_mean": achieved_events,
+                     "frac_hip_events_batch_mean": achieved_events / HBM_PEAK_GBS if achieved_events <= HBM_PEAK_GBS else None,
                      "rocprofv3_average_us": rocprof["average_us"] if rocprof else None,
                      "rocprofv3_source": rocprof["source"] if rocprof else None,
                      "frac_from_rocprofv3_average": (alg_bytes / (rocprof["average_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS

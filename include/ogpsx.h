@@ -136,6 +136,12 @@ int og_jt_unregister_dev(og_handle h, double* d_JT);
  * device buffer (a NaN fill is cleaned by the next sweep).  Where the host refuses the mapping (or OGPSX_HOST=staged)
  * the packed transfer + scatter above is what runs; the matrix in JT is the same either way. */
 int og_jt_register_host(og_handle h, double* JT, int32_t col_lo, int32_t col_hi);
+/* Which of the two serves og_fd_sweep into the registered host matrix JT: *path = 1 the mapped matrix (the launch writes
+ * it over PCIe), 2 the packed copy + host scatter, 0 not decided yet (the first six sweeps time both and keep the faster:
+ * how fast a device writes 4 500 scattered host pages is the host's IOMMU's doing - 0.05 ms per sweep at C3 on one box,
+ * 0.87 ms on another, the packed path 0.10 ms on both), -1 JT is not registered.  OGPSX_HOST=mapped | staged in the
+ * environment decide without the trial.  No reference counterpart. */
+int og_jt_host_path(og_handle h, const double* JT, int32_t* path);
 int og_jt_unregister_host(og_handle h, double* JT);
 
 /* ---- static pattern and packed non-zeros ---------------------------------------------------------

@@ -48,6 +48,7 @@ SIGNATURES = {
     "og_jt_register_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "og_jt_unregister_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "og_jt_register_host": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32]),
+    "og_jt_host_path": (C.c_int, [C.c_void_p, _c_double_p, C.POINTER(C.c_int32)]),
     "og_jt_unregister_host": (C.c_int, [C.c_void_p, _c_double_p]),
     "og_pattern": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                              _c_int32_p]),

@@ -156,6 +156,14 @@ struct og_problem_s {
                                         // (hipHostRegister): the one-launch sweep writes its non-zeros - and F(x0) into
                                         // the pinned staging buffer - straight over PCIe: no packed copy, no host scatter;
                                         // nullptr: the packed download + scatter (registration refused, OGPSX_HOST=staged)
+        // Which of the two is faster is the HOST's doing (translation of 4 500 scattered host pages per sweep: 0.05 ms on
+        // one test box, 0.87 ms on another whose IOMMU does not pass device writes through; the packed copy is 0.10 ms on
+        // both): the first six sweeps into a mapped matrix time both - one warm-up and two timed calls each - and the
+        // faster one serves from then on (OGPSX_HOST=mapped / staged decide without the trial).
+        int choice = 0;                 // 0 undecided, 1 mapped, 2 staged
+        int calls = 0;
+        double t_mapped = 0.0, t_staged = 0.0;
+        bool last_staged = false;       // the last call scattered on the host (a NaN fill of its is the host's to clean)
     };
     std::vector<host_reg> host_regs;
     // column sharding (og_shard_plan)
@@ -364,6 +372,7 @@ int download_block(og_problem_s* p, int lo, int hi, double* JT, double* F0, cons
         OG_HIP(hipStreamSynchronize(p->stream));
         return 0;
     }
+    reg->last_staged = true;
     int rc = ensure_pattern(p);
     if (rc) return rc;
     const int64_t first = p->indptr[(size_t)lo], nnz = p->indptr[(size_t)hi] - first;
@@ -814,7 +823,21 @@ int og_jt_register_host(og_handle p, double* JT, int32_t lo, int32_t hi) {
         }
         (void)hipGetLastError();
     }
-    p->host_regs.push_back({JT, lo, hi, false, mapped});
+    og_problem_s::host_reg fresh;
+    fresh.ptr = JT;
+    fresh.lo = lo;
+    fresh.hi = hi;
+    fresh.dirty = false;
+    fresh.mapped = mapped;
+    p->host_regs.push_back(fresh);
+    return 0;
+}
+
+int og_jt_host_path(og_handle p, const double* JT, int32_t* path) {
+    if (!p || !path) return fail(1, "og_jt_host_path: null argument");
+    *path = -1;
+    for (auto& r : p->host_regs)
+        if (r.ptr == JT) *path = !r.mapped ? 2 : r.choice;
     return 0;
 }
 
@@ -1092,15 +1115,37 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
     // OGPSX_HOST=copyx keeps the copy.)
     static const bool readx_mode = [] { const char* e = getenv("OGPSX_HOST"); return !(e && std::string(e) == "copyx"); }();
     og_problem_s::host_reg* mreg = find_host_reg(p, JT, lo, hi);
-    const bool in_place = readx_mode && mreg && mreg->mapped && p->sweep_mode == 5 && p->fused_ok;
+    static const int forced = [] {
+        const char* e = getenv("OGPSX_HOST");
+        return (e && (std::string(e) == "mapped" || std::string(e) == "copyx")) ? 1 : 0;
+    }();
+    bool use_mapped = mreg && mreg->mapped && p->sweep_mode == 5 && p->fused_ok;
+    if (use_mapped && forced) mreg->choice = 1;
+    const bool trial = use_mapped && mreg->choice == 0 && !forced;
+    if (use_mapped && !forced) use_mapped = mreg->choice == 1 || (mreg->choice == 0 && mreg->calls < 3);
+    const double t_call = trial ? host_clock::now() : 0.0;
+    auto trial_done = [&] {
+        if (!trial) return;
+        const double dt = host_clock::now() - t_call;
+        const int c = mreg->calls++;
+        if (c == 1 || c == 2) mreg->t_mapped += dt;
+        if (c == 4 || c == 5) mreg->t_staged += dt;
+        if (mreg->calls >= 6) mreg->choice = mreg->t_mapped <= mreg->t_staged ? 1 : 2;
+    };
+    const bool in_place = readx_mode && use_mapped;
     int rc = in_place ? 0 : upload_point(p, x, hstep);
     if (rc) return rc;
     g_host_clock.mark(0);
-    if (og_problem_s::host_reg* reg = mreg; reg && reg->mapped && p->sweep_mode == 5 && p->fused_ok) {
+    if (og_problem_s::host_reg* reg = mreg; use_mapped) {
         // mapped host matrix: ONE launch writes the non-zeros into the caller's matrix and F(x0) + the count of non-finite
         // rows into the pinned staging buffer, both over PCIe; the host waits for the launch and is done
         rc = ensure_staging(p, (size_t)p->m + 1);
         if (rc) return rc;
+        if (reg->dirty && reg->last_staged) {        // (a NaN block the packed path downloaded: not the device's to clean)
+            memset(JT, 0, sizeof(double) * (size_t)(hi - lo) * (size_t)p->m);
+            reg->dirty = false;
+        }
+        reg->last_staged = false;
         void* tail = nullptr;
         OG_HIP(hipHostGetDevicePointer(&tail, p->h_down, 0));
         const double *kx = p->d_x, *kh = p->d_h;
@@ -1130,6 +1175,7 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
             reg->dirty = p->h_down[(size_t)p->m] != 0.0;
             g_host_clock.mark(4);
             g_host_clock.done();
+            trial_done();
             return 0;
         }
     }
@@ -1152,7 +1198,9 @@ int og_fd_sweep(og_handle p, const double* x, const double* hstep, int32_t lo, i
             rc = p->launch(&a, 5, p->stream);
             if (rc) return launch_failed(p, rc, "og_fd_sweep");
             g_host_clock.mark(1);
-            return download_block(p, lo, hi, JT, F0, nullptr, true);
+            rc = download_block(p, lo, hi, JT, F0, nullptr, true);
+            trial_done();
+            return rc;
         }
     }
     rc = og_fd_sweep_dev(p, p->d_x, p->d_h, lo, hi, p->d_jt, p->d_f0, p->stream);

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
         const double dots_p = uni(s_msg[0]), bval_p = uni(s_msg[1]);
         const int e0 = q0 >> 6, ne = nrp >> 6, eh = (q0 + 63) >> 6;      // strips of 64 coordinates: tail from e0, head below eh
         // ---- (3) r = RI d1: every owner of a row of the inverse its entry ------------------------------------
-        double my_r = 0.0;
+        double my_r = 0.0, gi_early = 0.0;
         int mypos = is_inv ? uni(posof[myslot]) : 0x7fffffff;
         {
             ++c3;
@@ -421,6 +421,19 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
                 if (lane == 0) mb_put(area + 2 * (size_t)mypos, my_r, c3);
             }
             SMARK(5);
+            // this wavefront's row times the incoming normal's tail: wanted by the pass below whenever the point moves, and
+            // independent of r - formed while r is under way (k_rows_apply_r4's sum, lane by lane in ascending order)
+            // (not y's: the step moves y before the pass)
+            if (is_row) {
+                double acc_d = 0.0;
+#pragma unroll 4
+                for (int e = e0; e < ne; ++e) {
+                    const int j = lane + 64 * e;
+                    const double xv = xr[j], dv = d[j];
+                    acc_d += j >= q0 ? xv * dv : 0.0;
+                }
+                gi_early = uni(wave_sum(acc_d));
+            }
             // |d2|^2 and |d|^2 in k_rows_decide's order (256 threads striding the vector), by the last four wavefronts
             // while the first ones wait for r
             if (tid >= RES_THREADS - 256) {
@@ -617,14 +630,17 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
             const bool tail_turn = moves && (is_row || (!carrier && full_step));
             const bool head_turn = leaves && (is_row || !carrier || (is_inv && mypos < q0 - 1));   // ... and the inverse's rows that stay
             if (tail_turn) {
-                double acc_d = 0.0;
+                double gi = gi_early;                // (a row's: formed before r arrived - row and d have not changed since)
+                if (!carrier) {
+                    double acc_d = 0.0;
 #pragma unroll 4
-                for (int e = e0; e < ne; ++e) {
-                    const int j = lane + 64 * e;
-                    const double xv = row[j], dv = d[j];
-                    acc_d += j >= q0 ? xv * dv : 0.0;
+                    for (int e = e0; e < ne; ++e) {
+                        const int j = lane + 64 * e;
+                        const double xv = row[j], dv = d[j];
+                        acc_d += j >= q0 ? xv * dv : 0.0;
+                    }
+                    gi = uni(wave_sum(acc_d));
                 }
-                const double gi = uni(wave_sum(acc_d));
                 if (valued) dot += t * gi;
                 if (full_step) {
                     const double f = beta * (gi - alpha * row[q0]);

@@ -165,6 +165,17 @@ class HipEngine:
         return F0, JT
 
     @property
+    def host_path(self):
+        """How ``sweep_persistent`` reaches the persistent host matrix (``og_jt_host_path``): "mapped" (the launch writes
+        it over PCIe), "staged" (packed copy + host scatter), "undecided" (the first six sweeps time both), None before
+        the first call."""
+        if self._JT_host is None:
+            return None
+        path = C.c_int32(-1)
+        _native.check(self._lib.og_jt_host_path(self._handle, _native.dptr(self._JT_host), C.byref(path)), "og_jt_host_path")
+        return {1: "mapped", 2: "staged", 0: "undecided"}.get(path.value)
+
+    @property
     def sweep_mode(self):
         """How ``sweep_dev`` runs (``og_sweep_mode``): "fused" (one launch), "split" or "dense"."""
         return {5: "fused", 1: "split", 2: "dense"}[self._lib.og_sweep_mode(self._handle)]

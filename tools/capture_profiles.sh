@@ -9,7 +9,7 @@ out=$R/gpurun_out/$rnd
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for w in polar_tsto goddard low_thrust launch4; do
-    timeout 900 python $R/bench.py --workload $w --cpu-seconds 6 2>/dev/null | tail -1 > $out/bench_$w.json
+    timeout 1200 python $R/bench.py --workload $w --cpu-seconds 6 --solve-starts 1 $([ $w = launch4 ] && echo --no-solve) 2>/dev/null | tail -1 > $out/bench_$w.json
 done
 Q="--quick --no-cpu-baseline --sqp-iterations 0"
 for w in polar_tsto low_thrust launch4; do

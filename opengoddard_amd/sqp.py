@@ -194,8 +194,11 @@ def minimize_slsqp_hip(engine, x0, lb, ub, ftol=1e-6, maxiter=100, cost_derivati
     ub = np.asarray(ub, dtype=float)
     x = np.clip(np.asarray(x0, dtype=float), lb, ub)
     # device buffers and the QP work space belong to the engine: the restarts of Problem.solve reuse them
+    t_setup = time.perf_counter()
     jacobian, core = _cache(engine)
-    timing = {"callbacks": 0.0, "qp": 0.0, "bfgs": 0.0, "qp_iterations": 0, "qp_solves": 0, "recoveries": 0}
+    # ("setup": device buffers and the QP work space - two n x n factors, the mailbox ... - on the first call of an engine)
+    timing = {"callbacks": 0.0, "qp": 0.0, "bfgs": 0.0, "qp_iterations": 0, "qp_solves": 0, "recoveries": 0,
+              "setup": time.perf_counter() - t_setup}
     recoveries_before = core.recoveries()
     unit0 = np.zeros(m + 1)
     unit0[0] = 1.0

@@ -986,10 +986,29 @@ def main():
         for _ in range(10):                                   # (the first calls page-lock and map the matrix, fault its pages in)
             eng.sweep_persistent(x0, h)
         reps = 100
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        calls = np.empty(reps)
+        if os.environ.get("OG_BENCH_NOGC"):                   # diagnostics: is the one slow call a full Python garbage collection?
+            import gc
+            gc.disable()
+        for i in range(reps):
+            t0 = time.perf_counter()
             eng.sweep_persistent(x0, h)
-        result["host_api_ms_per_sweep"] = (time.perf_counter() - t0) / reps * 1e3
+            calls[i] = time.perf_counter() - t0
+        # (per call: one stall of tens of milliseconds among a hundred calls - seen on some leases - would otherwise pass for
+        # the cost of a call; mean, median and the slowest call are all on the line)
+        result["host_api_ms_per_sweep"] = float(np.median(calls)) * 1e3
+        result["host_api_ms_per_sweep_mean"] = float(np.mean(calls)) * 1e3
+        result["host_api_ms_per_sweep_max"] = float(np.max(calls)) * 1e3
+        result["host_api_slow_calls"] = [(int(i), float(calls[i]) * 1e3) for i in np.argsort(calls)[-3:][::-1]]
+        if os.environ.get("OG_BENCH_PROFILE_HOSTAPI"):        # diagnostics: where a call's time goes on the Python side
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            for _ in range(reps):
+                eng.sweep_persistent(x0, h)
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(6)
         result["host_api_path"] = eng.host_path               # "mapped" or "staged": whichever the first six sweeps found faster
         reps = 5 if n > 3000 else 10
         eng.sweep_stacked(x0, h)

@@ -137,11 +137,17 @@ int og_jt_unregister_dev(og_handle h, double* d_JT);
  * the packed transfer + scatter above is what runs; the matrix in JT is the same either way. */
 int og_jt_register_host(og_handle h, double* JT, int32_t col_lo, int32_t col_hi);
 /* Which of the two serves og_fd_sweep into the registered host matrix JT: *path = 1 the mapped matrix (the launch writes
- * it over PCIe), 2 the packed copy + host scatter, 0 not decided yet (the first six sweeps time both and keep the faster:
- * how fast a device writes 4 500 scattered host pages is the host's IOMMU's doing - 0.05 ms per sweep at C3 on one box,
- * 0.87 ms on another, the packed path 0.10 ms on both), -1 JT is not registered.  OGPSX_HOST=mapped | staged in the
- * environment decide without the trial.  No reference counterpart. */
+ * it over PCIe), 2 the packed copy + host scatter, 0 not decided yet (the first ten sweeps time both - two warm-ups and
+ * three timed calls each - and keep the faster: what scattered device writes into host pages cost is the host's doing;
+ * on every box of round 6 mapped won, 0.043-0.052 against 0.10-0.12 ms per sweep at C3), -1 JT is not registered.
+ * OGPSX_HOST=mapped | staged in the environment decide without the trial.  No reference counterpart. */
 int og_jt_host_path(og_handle h, const double* JT, int32_t* path);
+/* Page-locked host memory from the HIP runtime (hipHostMalloc) for a matrix that is going to be registered with
+ * og_jt_register_host: it is mapped into the device's address space already and lies in the driver's large fragments, so
+ * the mapped path needs a handful of address translations per sweep where a malloc'ed matrix of 4 KB pages needs
+ * thousands (the engine's own persistent matrix comes from here).  No reference counterpart. */
+int og_pinned_alloc(int64_t bytes, void** out);
+int og_pinned_free(void* ptr);
 int og_jt_unregister_host(og_handle h, double* JT);
 
 /* ---- static pattern and packed non-zeros ---------------------------------------------------------

@@ -49,6 +49,8 @@ SIGNATURES = {
     "og_jt_unregister_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "og_jt_register_host": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32]),
     "og_jt_host_path": (C.c_int, [C.c_void_p, _c_double_p, C.POINTER(C.c_int32)]),
+    "og_pinned_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "og_pinned_free": (C.c_int, [C.c_void_p]),
     "og_jt_unregister_host": (C.c_int, [C.c_void_p, _c_double_p]),
     "og_pattern": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                              _c_int32_p]),
@@ -147,3 +149,26 @@ def fd_step(x, lb, ub):
 
 def device_count():
     return int(lib().og_device_count())
+
+
+def pinned_matrix(rows, cols):
+    """A ``rows x cols`` float64 array in page-locked host memory from the HIP runtime (``og_pinned_alloc``), or None when
+    the runtime refuses.  The memory is freed when the last view of the array is gone (never at interpreter exit: the
+    runtime may be gone first).  What it is for: ``og_jt_register_host`` finds such a matrix mapped into the device's
+    address space already, in the driver's large fragments - the sweep's writes over PCIe then need a handful of address
+    translations instead of one per 4 KB page of a malloc'ed matrix."""
+    import weakref
+    count = int(rows) * int(cols)
+    if count <= 0:
+        return None
+    ptr = C.c_void_p()
+    try:
+        if lib().og_pinned_alloc(C.c_int64(8 * count), C.byref(ptr)) != 0 or not ptr.value:
+            return None
+    except Exception:
+        return None
+    address = int(ptr.value)
+    buf = (C.c_double * count).from_address(address)
+    finalizer = weakref.finalize(buf, lib().og_pinned_free, C.c_void_p(address))
+    finalizer.atexit = False
+    return np.frombuffer(buf, dtype=np.float64).reshape(int(rows), int(cols))

@@ -15,6 +15,7 @@ There is deliberately no NumPy fallback: no GPU or no compiled extension => exce
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -144,7 +145,9 @@ class HipEngine:
         x = np.ascontiguousarray(x, dtype=np.float64)
         F0 = np.empty(self.m)
         if self._JT_host is None:
-            self._JT_host = np.empty((self.n, self.m))
+            # (page-locked memory of the runtime's own where it gives some: the sweep writes this matrix over PCIe)
+            pinned = None if os.environ.get("OGPSX_HOST") == "staged" else _native.pinned_matrix(self.n, self.m)
+            self._JT_host = pinned if pinned is not None else np.empty((self.n, self.m))
             if self._multi.value:
                 _native.check(self._lib.og_multi_jt_register_host(self._multi, _native.dptr(self._JT_host)),
                               "og_multi_jt_register_host")

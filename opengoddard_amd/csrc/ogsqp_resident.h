@@ -21,7 +21,9 @@
 //     the vector, wave_sum, four partial sums added in turn): nobody waits for a deciding workgroup;
 //   * what the workgroups tell each other per change is three small messages - (1) each workgroup's most violated row:
 //     its price and, with it, the ROW ITSELF (so that whoever reads the prices finds the winner's row already there:
-//     one trip through memory instead of election -> owner publishes -> everybody reads), (3) the entries of
+//     one trip through memory instead of election -> owner publishes -> everybody reads) - and the price goes out as
+//     soon as the step of the change before is known, BEFORE the pass over the rows (a row's price depends on its
+//     value W[i] y, which moves by t g_i, not on the row): the pass and its barrier hide behind the exchange -, (3) the entries of
 //     r = RI d1 from the owners of the inverse's rows, (4) on a partial step the leaving row of the inverse from its
 //     owner; after a partial step the same incoming row goes on and its owner alone publishes it again (2) - through
 //     a mailbox in HBM whose records validate themselves: a double travels as two 64-bit words, each carrying 32 bits
@@ -288,7 +290,40 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
             redi[wave] = besti;
         }
     };
-    if (phase == 0) price_row();
+    // the workgroup's best of what its wavefronts left in redv / redi goes out as exchange (1) - price and index at once,
+    // the row itself (publish_best_row) once it holds what the change in progress makes of it
+    double bv_pub = INFINITY;
+    int bi_pub = 0x7fffffff;
+    auto publish_best = [&]() {
+        res_argmin_of_waves(bv_pub, bi_pub, redv, redi);
+        bv_pub = uni(bv_pub);
+        bi_pub = uni(bi_pub);
+        ++c1;
+        res_u64* const mine = mailE1 + 2 * (((c1 & 1u) * (size_t)NW + (size_t)w) * S1);
+        if (tid == RES_THREADS - 64) {
+            mb_put(mine, bv_pub, c1);
+            mb_put(mine + 2, (double)bi_pub, c1);
+        }
+    };
+    auto publish_best_row = [&]() {
+        if (!(bv_pub < 0.0)) return;
+        const int brow = bi_pub < nrows ? bi_pub : bi_pub - nq;
+        if (gw != brow) return;
+        res_u64* const mine = mailE1 + 2 * (((c1 & 1u) * (size_t)NW + (size_t)w) * S1);
+        const double sg = bi_pub < nrows ? 1.0 : -1.0;
+#pragma unroll 4
+        for (int j = lane; j < nr; j += 64) mb_put(mine + 2 * (size_t)(4 + j), sg * xr[j], c1);
+        if (lane == 0) {
+            mb_put(mine + 4, dot, c1);
+            mb_put(mine + 6, bi_pub < nrows ? b0 : b1, c1);
+        }
+    };
+    if (phase == 0) {
+        price_row();
+        __syncthreads();
+        publish_best();
+        publish_best_row();
+    }
     __syncthreads();
     int exit_dbg = 0, exit_dbg2 = 0;
     while (true) {
@@ -296,34 +331,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
         double psign;
         int prow_index;
         if (phase == 0) {
-            // ---- (1) who comes in: every wavefront has priced its row (at the end of the change before: one barrier
-            // less); each workgroup publishes its best - the price, the index and, when it is a violated one, the row
-            // itself with its value and its b ---------------------------------------------------------------------
-            double bv;
-            int bi;
-            res_argmin_of_waves(bv, bi, redv, redi);
-            bv = uni(bv);
-            bi = uni(bi);
-            SMARK(0);
-            ++c1;
+            // ---- (1) who comes in: every workgroup's best is under way since the step of the change before was known
+            // (its price and index BEFORE the pass over the rows, the row itself behind it): the election reads them
             res_u64* const area = mailE1 + 2 * (((c1 & 1u) * (size_t)NW) * S1);
-            res_u64* const mine = area + 2 * ((size_t)w * S1);
-            if (bv < 0.0) {
-                const int brow = bi < nrows ? bi : bi - nq;
-                if (gw == brow) {
-                    const double sg = bi < nrows ? 1.0 : -1.0;
-#pragma unroll 4
-                    for (int j = lane; j < nr; j += 64) mb_put(mine + 2 * (size_t)(4 + j), sg * xr[j], c1);
-                    if (lane == 0) {
-                        mb_put(mine + 4, dot, c1);
-                        mb_put(mine + 6, bi < nrows ? b0 : b1, c1);
-                    }
-                }
-            }
-            if (tid == RES_THREADS - 64) {
-                mb_put(mine, bv, c1);
-                mb_put(mine + 2, (double)bi, c1);
-            }
+            SMARK(0);
             bool ok = true;
             double v = INFINITY;
             int idx = 0x7fffffff;
@@ -619,6 +630,15 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
             ++n_partial;
 #endif
         }
+        // every row's constraint value moves with the point (t g_i, the product formed while r was under way) - and with
+        // it the row's price: after a full step the next election's prices go out NOW, before the rows are touched (the
+        // pass and its closing barrier hide behind the exchange's way through memory)
+        if (is_row && moves) dot += t * gi_early;
+        if (phase == 0) {
+            price_row();
+            __syncthreads();
+            publish_best();
+        }
         // ---- the pass over the rows, each in its wavefront's LDS (k_rows_apply_r4's arithmetic) ----------------
         // the first q0 coordinates of a row matter when a row leaves (its reflector lives there), the tail when the
         // incoming row moves the point.  Lane l adds its coordinates l, l + 64, ... in ascending order, then wave_sum: the
@@ -626,7 +646,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
         // behind nr, the rows behind their length)
         {
             double* const row = carrier ? xr : y;    // the last wavefront: y, which lives in the same coordinates and has no
-            const bool valued = is_row;              // value of its own (the row "y" of k_rows_apply)
+                                                     // value of its own (the row "y" of k_rows_apply)
             const bool tail_turn = moves && (is_row || (!carrier && full_step));
             const bool head_turn = leaves && (is_row || !carrier || (is_inv && mypos < q0 - 1));   // ... and the inverse's rows that stay
             if (tail_turn) {
@@ -641,7 +661,6 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
                     }
                     gi = uni(wave_sum(acc_d));
                 }
-                if (valued) dot += t * gi;
                 if (full_step) {
                     const double f = beta * (gi - alpha * row[q0]);
 #pragma unroll 4
@@ -669,7 +688,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_rows_resident(ResArgs A) {
                 }
             }
         }
-        if (phase == 0) price_row();
+        if (phase == 0) publish_best_row();          // (the row as this change leaves it)
         SMARK(11);
         __syncthreads();
         SMARK(12);

@@ -725,7 +725,14 @@ def main():
         if getattr(backend, "direct", False):
             v = (C.c_int32 * 3)()
             if eng._lib.og_shard_comm_info(eng._handle, C.byref(v, 0), C.byref(v, 4), C.byref(v, 8)) == 0:
-                mine.update({"rccl_comm_ranks": int(v[0]), "rccl_comm_rank": int(v[1]), "rccl_comm_device": int(v[2])})
+                mine.update({"rccl_comm_ranks": int(v[0]), "rccl_comm_rank": int(v[1]), "rccl_comm_device": int(v[2]),
+                             "rccl_comm_source": "ncclCommCount of the communicator inside libogpsx.so"})
+        elif not same_device and dist.get_backend() == "nccl":
+            # the exchange fell back to torch.distributed's all_gather_into_tensor: its "nccl" backend IS RCCL on ROCm, and
+            # the process group the ranks rendezvoused in is the communicator
+            mine.update({"rccl_comm_ranks": int(dist.get_world_size()), "rccl_comm_rank": int(dist.get_rank()),
+                         "rccl_comm_device": int(torch.cuda.current_device()),
+                         "rccl_comm_source": "torch.distributed process group (backend nccl = RCCL)"})
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
         ranks_report = everyone

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_lq_panel16_wide(double* __restr
                                                                 LqWideMail* __restrict__ mail, int gen,
                                                                 int* __restrict__ lost, int spin_limit) {
     constexpr int E = LQW_E;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(32))) double lds[];
     __shared__ double s_part[2][P16_WAVES][LQ16];
     __shared__ double s_xpc[2][LQ16];
     __shared__ double s_tot[LQ16], s_pc[LQ16];       // totals over all workgroups; the rows' pivot-column entries

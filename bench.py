@@ -310,8 +310,11 @@ def scipy_core_sample(eng, prob, lb, ub, iterations):
 
 # what the `solve` leg runs (the reference's loop, ``optimize.py:738-755``: restarts of ``maxiter`` major iterations
 # until SLSQP reports exit mode 0): C3 with 400 iterations per restart (the reference's default of 25 resets the
-# quasi-Newton matrix too often for this size to converge inside maxIterator restarts), C4 with the defaults
-SOLVE_OPTIONS = {"polar_tsto": {"maxiter": 400}, "low_thrust": {}, "launch4": {"maxiter": 3000},
+# quasi-Newton matrix too often for this size to converge inside maxIterator restarts); C4 likewise since round 6 - with
+# 25 iterations per restart its ten restarts end by SLSQP's cost test or by their limit depending on rounding (3 of 5
+# neighbouring starts, and the problem's own start after the LQ panel's sums changed order), with 400 it needs ~130
+# major iterations and no restart
+SOLVE_OPTIONS = {"polar_tsto": {"maxiter": 400}, "low_thrust": {"maxiter": 400}, "launch4": {"maxiter": 3000},
                  "goddard": {"ftol": 1e-10}}
 
 

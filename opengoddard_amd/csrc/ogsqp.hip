@@ -3065,7 +3065,7 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
                     Lq16Panel hp;
                     OG_HIP(hipMemcpyAsync(&hp, pcur, sizeof(Lq16Panel), hipMemcpyDeviceToHost, s));
                     OG_HIP(hipStreamSynchronize(s));
-                    fprintf(stderr, "[ogsqp trace] panel16 at k = %d (len %d) ticks (wavefront 0): load %lld first reflector %lld barriers %lld vector %lld row in line %lld other row %lld store %lld\n",
+                    fprintf(stderr, "[ogsqp trace] panel16 at k = %d (len %d) ticks (wavefront 0): load %lld first reflector %lld waits for the flag %lld vector %lld row in line %lld other row %lld store %lld\n",
                             k, len16, hp.tr[0], hp.tr[5], hp.tr[1], hp.tr[2], hp.tr[3], hp.tr[4], hp.tr[6]);
                 }
 #endif
@@ -3084,7 +3084,7 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
             OG_HIP(hipMemcpy(&hp, pnxt, sizeof(Lq16Panel), hipMemcpyDeviceToHost));                                      \
             fprintf(stderr, "[ogsqp trace] head workgroup 0, 10 ns ticks: header %lld loads %lld product-1 %lld barrier %lld " \
                             "exchange %lld products-2,3 + stores issued %lld drain %lld; its panel (shader clocks, wavefront 0): load %lld " \
-                            "first reflector %lld barriers %lld vector %lld row in line %lld other row %lld store %lld\n", tr[0], tr[1],  \
+                            "first reflector %lld waits for the flag %lld vector %lld row in line %lld other row %lld store %lld\n", tr[0], tr[1],  \
                     tr[2], tr[3], tr[6], tr[4], tr[5], hp.tr[0], hp.tr[5], hp.tr[1], hp.tr[2], hp.tr[3], hp.tr[4], hp.tr[6]); \
         }                                                                                                                \
     }

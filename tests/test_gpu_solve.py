@@ -167,10 +167,11 @@ STATIONARITY_BOUND = {"polar_tsto": 3.5e-2, "low_thrust": 1e-4}
 COST_BAND = {"polar_tsto": (-0.0236, -0.0227), "low_thrust": (41.4540, 41.4550)}
 
 
-@pytest.mark.parametrize("name,options", [("polar_tsto", {"maxiter": 400}), ("low_thrust", {})])
+@pytest.mark.parametrize("name,options", [("polar_tsto", {"maxiter": 400}), ("low_thrust", {"maxiter": 400})])
 def test_converged_optimum_satisfies_the_oracles_kkt_conditions(name, options, capsys):
-    """C3 (``maxiter=400`` per restart) and C4 (the reference's defaults) from their own initial guesses: the point SLSQP
-    stops at is feasible to 1e-6, its multipliers have the right signs, complementarity holds to 1e-5, the cost the GPU
+    """C3 and C4 (``maxiter=400`` per restart: with the reference's 25, whether C4's tenth restart ends by SLSQP's cost test
+    or by its limit depends on rounding - 3 of 5 neighbouring starts, ``bench.py``) from their own initial guesses: the
+    point SLSQP stops at is feasible to 1e-6, its multipliers have the right signs, complementarity holds to 1e-5, the cost the GPU
     reports is the reference path's to 1e-9, and the stationarity residual is what SLSQP's ftol test leaves (see above)."""
     res, k, wall = _kkt_of_a_solve(name, options, capsys)
     assert abs(res.fun - k["cost"]) <= 1e-9 * max(1.0, abs(k["cost"]))       # the GPU's cost IS the reference path's

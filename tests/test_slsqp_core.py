@@ -663,6 +663,36 @@ def test_gpu_warm_started_active_set_reaches_the_same_solution():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [150, 300, 600, 860, 1100, 1380, 1530, 1800])
+def test_gpu_lq_panel_at_every_row_length(n):
+    """The 16-reflector panel holds its rows in groups of 256 columns (E = 1 .. 8 groups: a row pair per wavefront and no
+    barrier between reflectors up to E = 6, the lane-group form with two barriers beyond): one subproblem per E whose
+    sweep starts in that class and walks down through the shorter ones, with a number of equalities that is not a
+    multiple of 16 (a last panel of 5 reflectors), an equality that repeats an earlier one inside a panel (no reflector
+    is built from it: zero multiplier) - against the restatement's step with LAPACK's LQ."""
+    rng = np.random.default_rng(1000 + n)
+    meq, mg = 16 * (n // 40) + 5, 12
+    Z, g, C, c, G, h, lb, ub = random_qp(rng, n, meq, mg)
+    lb[:], ub[:] = -np.inf, np.inf                       # (the sweep is what is tested: a short active-set phase)
+    where, src = meq // 2 + 3, meq // 2 - 9             # (both in the same panel or in neighbouring ones)
+    C[where], c[where] = -1.5 * C[src], -1.5 * c[src]
+    ref = slsqp_np.qp_solve(Z, g, C, c, G, h, lb, ub, lq="lapack")
+    core = _sqp_native.QpCore(n, meq, mg)
+    core.set_factor(Z)
+    dd, mult, bm, status, iters = core.solve(np.vstack([C, G]), g, np.concatenate([c, h]), lb, ub)
+    assert status == ref[3] == 1
+    assert np.max(np.abs(dd - ref[0])) <= 1e-9 * max(1.0, np.abs(ref[0]).max())
+    assert np.max(np.abs(C @ dd + c)) <= 1e-9 * max(1.0, np.abs(c).max()) and np.min(G @ dd + h) >= -1e-9
+    assert mult[where] == 0.0
+    # the same subproblem again on the same handle: the same bits (nothing in the panel depends on timing)
+    core.set_factor(Z)
+    core.set_active()
+    d2, _, _, status2, iters2 = core.solve(np.vstack([C, G]), g, np.concatenate([c, h]), lb, ub)
+    assert status2 == 1 and iters2 == iters and np.array_equal(d2, dd)
+    core.close()
+
+
+@pytest.mark.gpu
 def test_gpu_lq_sweep_forms_agree(monkeypatch):
     """(Also the three forms of the blocked triangular solves, OGSQP_TRSV.)  The three forms of the LQ sweep - 16-reflector panels with the next panel factored during the trailing update
     (default: k_lq_step16, head workgroups + panel workgroup inside one launch), the same panels as separate

@@ -149,8 +149,9 @@ __device__ __forceinline__ void lq_panel16_waves(double* __restrict__ Tc, int ld
         double* vr = vrow + (b % P16_RING) * W;
         if (b >= P16_RING && done_early < P16_WAVES) {     // (never seen waiting: the slot's readers are three reflectors back)
             int spins = 0;
-            while (__hip_atomic_load(&s_done[b - P16_RING], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < P16_WAVES)
+            while (__hip_atomic_load(&s_done[b - P16_RING], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < P16_WAVES)
                 if (++spins > P16_SPINS) { s_broken = 1; break; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -195,7 +196,9 @@ __device__ __forceinline__ void lq_panel16_waves(double* __restrict__ Tc, int ld
             s_beta[b] = bt;
             s_diag[b] = alpha;
         }
-        __hip_atomic_store(&s_ready, b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (fences over LDS only: a release over every address space would wait for this wavefront's stores of V rows)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __hip_atomic_store(&s_ready, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // one row of this wavefront in step b (v = reflector b on my columns): its product with v, and what follows
     // from where the row stands - a finished reflector a < b: v_a . v_b; a row below: the update, and for row b + 1
@@ -238,10 +241,7 @@ __device__ __forceinline__ void lq_panel16_waves(double* __restrict__ Tc, int ld
     };
     if (wv >= nb) store_row(wv, x[0], true);                 // (rows beyond nb: zero)
     if (wv + 8 >= nb) store_row(wv + 8, x[1], true);
-    if (wv == 0) {
-        make_reflector(0, x[0], dmax, P16_WAVES);
-        store_row(0, x[0], false);
-    }
+    if (wv == 0) make_reflector(0, x[0], dmax, P16_WAVES);
     P16MARK(5);   // the first reflector
     // x[0] is the wavefront's row in line for the next reflector: row wv while b + 1 < 8, row wv + 8 from then on
     int r_line = wv, r_other = wv + 8;
@@ -261,10 +261,11 @@ __device__ __forceinline__ void lq_panel16_waves(double* __restrict__ Tc, int ld
         }
         {
             int spins = 0;
-            while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= b) {
+            while (__hip_atomic_load(&s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= b) {
                 if (++spins > P16_SPINS) { s_broken = 1; break; }
                 if (r_line != b + 1) __builtin_amdgcn_s_sleep(1);     // (the wavefront next in line polls at once)
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
         P16MARK(1);   // wait for reflector b
         const double* vr = vrow + (b % P16_RING) * W;
@@ -286,9 +287,12 @@ __device__ __forceinline__ void lq_panel16_waves(double* __restrict__ Tc, int ld
         P16MARK(3);   // row in line
         // done with reading slot b (here, not behind the reads: counting waits for all of them, and the products
         // start on the first)
-        if (lane == 0) __hip_atomic_fetch_add(&s_done[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (lane == 0) __hip_atomic_fetch_add(&s_done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         row_step(b, r_other, x[1], v, bt, dmax, false, done_early);
         if (r_line == b + 1 && r_line < nb) store_row(r_line, x[0], false);
+        if (b == 0 && wv == 0) store_row(0, x[0], false);      // (not in front of the loop: the wait for this wavefront's
+                                                               // second row, still on its way then, would include the stores)
         P16MARK(4);   // other row
     }
     __syncthreads();

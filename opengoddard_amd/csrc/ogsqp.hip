@@ -3043,7 +3043,7 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
                 // workgroup reads all of V)
                 const int rpg = std::max(8, std::min(LQ16, (nrows16 + 239) / 240));
 #define OG_PANEL16(E)                                                                                              \
-    hipLaunchKernelGGL(k_lq_panel16<E>, dim3(1), dim3(P16_THREADS), (size_t)P16_RING * 256 * E * sizeof(double), s, qp->Tc, ldw, \
+    hipLaunchKernelGGL(k_lq_panel16<E>, dim3(1), dim3(P16_THREADS), (size_t)((E) <= 6 ? P16_RING : 2) * 256 * (E) * sizeof(double), s, qp->Tc, ldw, \
                        msweep, nq, k, Vcur, ldw, qp->diagL, pcur, qp->dthresh + 1)
                 if (factored != k) {
                     // (E = groups of 256 columns, exactly: the panel's steps are bound by the multiply-adds it issues,
@@ -3095,7 +3095,7 @@ static int qp_solve_attempt(og_qp_handle qp, const double* d_jt, int64_t ld, con
                     // the launch of the trailing update factors the next panel on the side (k_lq_step16)
 #define OG_STEP16(U, E)                                                                                           \
     hipLaunchKernelGGL((k_lq_step16<U, E>), dim3(1 + LQ_HEADS + (std::max(nrows16 - LQ16, 0) + rpg - 1) / rpg),        \
-                       dim3(64 * A16_WAVES), (size_t)P16_RING * 256 * E * sizeof(double), s, qp->Tc, qp->Jw, ldw, msweep, nq, k,   \
+                       dim3(64 * A16_WAVES), (size_t)((E) <= 6 ? P16_RING : 2) * 256 * (E) * sizeof(double), s, qp->Tc, qp->Jw, ldw, msweep, nq, k,   \
                        (const double*)Vcur, ldw, (const Lq16Panel*)pcur, Vnxt, pnxt, qp->diagL, qp->dthresh + 1, rpg,      \
                        qp->lq_go, (qp->lq_token += LQ_HEADS), qp->lq_wpart, qp->flag + 2, qp->spin_limit)
                     // U by the length of the rows now, E by the length of the NEXT panel's rows (exact)

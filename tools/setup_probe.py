@@ -1,5 +1,8 @@
+"""usage (GPU box): python tools/setup_probe.py - what the one-time set-up of the SQP leg consists of at C3: the engine,
+the device Jacobian buffers, the first QP handle (loads libogsqp.so) and a second one (82 allocations, the mailboxes, a stream)."""
 import time, sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 t0=time.perf_counter()
 from opengoddard_amd import problems, sqp, _sqp_native
 from opengoddard_amd.engine import HipEngine
